@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Pin the CPU oracle's *architecture and layout* against an independent implementation.
+
+The reference's own engine cannot be built here (ggml / encodec.cpp submodule absent), and it
+ships no golden vectors.  The closest independent implementation available offline is the
+PyTorch model that the reference's convert.py converts FROM: HuggingFace `transformers`
+Bark (modeling_bark.py) and EnCodec (modeling_encodec.py).  This script
+
+  1. writes the deterministic synthetic `toy` model file (tools/make_synth_model.py, seed 0),
+  2. loads the very same tensors into HF BarkCausalModel / BarkFineModel / EncodecDecoder
+     through the inverse of convert.py's name map (convert.py:222-267, 151-167),
+  3. runs single forward passes on fixed inputs and stores the outputs as
+     tests/golden/hf_toy_s0.npz.
+
+tests/test_oracle_golden.py then checks the oracle (with its ggml-specific rounding switched
+off and HF's erf GELU selected) against these vectors.  HF differs from bark.cpp *by design* in
+GELU flavour (erf vs tanh-LUT) and in f16 activation rounding, so this pins structure — layer
+order, tensor layout, masks, padding, gate order — not ggml's rounding.
+
+Run in the build container only (needs torch + transformers); the GPU box uses the .npz.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.make_synth_model import ensure_model  # noqa: E402
+
+
+def read_model_file(path: str):
+    """Minimal reader of the on-disk layout -> {section: (hparams, {name: ndarray (torch order)})}."""
+    buf = np.fromfile(path, dtype=np.uint8)
+    pos = 0
+
+    def i32(n=1):
+        nonlocal pos
+        v = struct.unpack_from("<%di" % n, buf, pos)
+        pos += 4 * n
+        return v if n > 1 else v[0]
+
+    def tensor():
+        nonlocal pos
+        n_dims, ln, tt = i32(3)
+        dims = [i32() for _ in range(n_dims)]
+        name = bytes(buf[pos:pos + ln]).decode()
+        pos += ln
+        n = int(np.prod(dims)) if dims else 1
+        dt = np.float16 if tt == 1 else np.float32
+        arr = np.frombuffer(buf, dtype=dt, count=n, offset=pos).reshape(list(reversed(dims)))
+        pos += n * arr.itemsize
+        return name, arr
+
+    assert i32() == 0x67676D6C
+    n_vocab = i32()
+    vocab = []
+    for _ in range(n_vocab):
+        ln = i32()
+        vocab.append(bytes(buf[pos:pos + ln]))
+        pos += ln
+    out = {"vocab": vocab}
+    for sec in ("semantic", "coarse", "fine"):
+        hp = dict(zip(["n_layer", "n_head", "n_embd", "block_size", "bias", "n_in", "n_out", "n_lm_heads", "n_wtes", "ftype"], i32(10)))
+        tens = dict(tensor() for _ in range(i32()))
+        out[sec] = (hp, tens)
+    assert i32() == 0x67676D6C
+    hp = dict(zip(["in_channels", "hidden_dim", "n_filters", "kernel_size", "residual_kernel_size", "n_bins", "bandwidth", "sr", "ftype"], i32(9)))
+    tens = {}
+    while pos < len(buf):
+        k, v = tensor()
+        tens[k] = v
+    out["codec"] = (hp, tens)
+    return out
+
+
+def build_hf_gpt(hp, tens, fine: bool):
+    import torch
+    from transformers.models.bark.configuration_bark import BarkFineConfig, BarkSemanticConfig
+    from transformers.models.bark.modeling_bark import BarkCausalModel, BarkFineModel
+
+    kw = dict(block_size=hp["block_size"], input_vocab_size=hp["n_in"], output_vocab_size=hp["n_out"],
+              num_layers=hp["n_layer"], num_heads=hp["n_head"], hidden_size=hp["n_embd"], dropout=0.0, bias=False)
+    if fine:
+        # the real checkpoints tie lm_heads[i] to input_embeds_layers[i+1]; the converted file stores both
+        # tensors and bark.cpp loads both independently, so the synthetic file keeps them independent
+        cfg = BarkFineConfig(n_codes_total=hp["n_wtes"], n_codes_given=hp["n_wtes"] - hp["n_lm_heads"],
+                             tie_word_embeddings=False, **kw)
+        cfg._attn_implementation = "eager"
+        model = BarkFineModel(cfg)
+    else:
+        cfg = BarkSemanticConfig(**kw)
+        cfg._attn_implementation = "eager"
+        model = BarkCausalModel(cfg)
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float32))
+    sd = {}
+    if fine:
+        for i in range(hp["n_wtes"]):
+            sd[f"input_embeds_layers.{i}.weight"] = t(tens[f"model/wte/{i}"])
+        for i in range(hp["n_lm_heads"]):
+            sd[f"lm_heads.{i}.weight"] = t(tens[f"model/lm_head/{i}"])
+    else:
+        sd["input_embeds_layer.weight"] = t(tens["model/wte/0"])
+        sd["lm_head.weight"] = t(tens["model/lm_head/0"])
+    sd["position_embeds_layer.weight"] = t(tens["model/wpe"])
+    sd["layernorm_final.weight"] = t(tens["model/ln_f/g"])
+    if "model/ln_f/b" in tens:
+        sd["layernorm_final.bias"] = t(tens["model/ln_f/b"])
+    for l in range(hp["n_layer"]):
+        p = f"model/h{l}"
+        sd[f"layers.{l}.layernorm_1.weight"] = t(tens[p + "/ln_1/g"])
+        sd[f"layers.{l}.layernorm_2.weight"] = t(tens[p + "/ln_2/g"])
+        if p + "/ln_1/b" in tens:
+            sd[f"layers.{l}.layernorm_1.bias"] = t(tens[p + "/ln_1/b"])
+            sd[f"layers.{l}.layernorm_2.bias"] = t(tens[p + "/ln_2/b"])
+        sd[f"layers.{l}.attn.att_proj.weight"] = t(tens[p + "/attn/c_attn/w"])
+        sd[f"layers.{l}.attn.out_proj.weight"] = t(tens[p + "/attn/c_proj/w"])
+        sd[f"layers.{l}.mlp.in_proj.weight"] = t(tens[p + "/mlp/c_fc/w"])
+        sd[f"layers.{l}.mlp.out_proj.weight"] = t(tens[p + "/mlp/c_proj/w"])
+    if fine:   # make sure no parameter is shared before loading independent tensors
+        for i in range(hp["n_lm_heads"]):
+            assert model.lm_heads[i].weight.data_ptr() != model.input_embeds_layers[i + 1].weight.data_ptr()
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if not m.endswith("attn.bias")]
+    assert not unexpected, unexpected
+    assert not missing, missing
+    return model.eval()
+
+
+def build_hf_codec(hp, tens):
+    import torch
+    from transformers.models.encodec.configuration_encodec import EncodecConfig
+    from transformers.models.encodec.modeling_encodec import EncodecDecoder
+
+    cfg = EncodecConfig(num_filters=hp["n_filters"], hidden_size=hp["hidden_dim"], codebook_size=hp["n_bins"],
+                        codebook_dim=hp["hidden_dim"], use_causal_conv=True, norm_type="time_group_norm")
+    # norm_type would be weight_norm in the real model; the file stores the already folded weight, so build
+    # plain convolutions and strip the GroupNorm that "time_group_norm" adds.
+    dec = EncodecDecoder(cfg)
+    for mod in dec.modules():
+        if hasattr(mod, "norm_type"):
+            mod.norm_type = "weight_norm"     # forward() then skips self.norm
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float32))
+    sd = {}
+    for name, arr in tens.items():
+        if not name.startswith("decoder."):
+            continue
+        k = name.replace("decoder.model.", "layers.")
+        k = k.replace(".convtr.convtr.", ".conv.").replace(".conv.conv.", ".conv.")
+        a = t(arr)
+        if k.endswith(".bias") and a.ndim == 0:
+            a = a.reshape(1)
+        sd[k] = a
+    own = dec.state_dict()
+    for k, v in sd.items():
+        assert k in own, k
+        assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+    load = {k: sd.get(k, v) for k, v in own.items()}
+    assert all(k in sd or ".norm." in k for k in own), [k for k in own if k not in sd and ".norm." not in k]
+    dec.load_state_dict(load)
+    return dec.eval()
+
+
+def main():
+    import torch
+
+    torch.set_num_threads(4)
+    path = ensure_model("toy", 0)
+    mf = read_model_file(path)
+    rng = np.random.default_rng(1234)
+    out = {}
+
+    with torch.no_grad():
+        # ---- semantic: merged 513-token prompt (257 rows) then two decode steps ------------------
+        hp, tens = mf["semantic"]
+        sem = build_hf_gpt(hp, tens, fine=False)
+        prompt = np.concatenate([rng.integers(10048, 129595, 40), np.full(216, 129595), np.full(256, 10000), [129599]]).astype(np.int64)
+        emb = sem.input_embeds_layer(torch.from_numpy(prompt)[None])
+        merged = torch.cat([emb[:, :256] + emb[:, 256:512], emb[:, 512:]], dim=1)
+        r = sem(inputs_embeds=merged, use_cache=True)
+        out["sem_prompt"] = prompt.astype(np.int32)
+        out["sem_logits0"] = r.logits[0, -1].numpy()
+        nxt = [int(out["sem_logits0"].argmax()), 4242]
+        pkv = r.past_key_values
+        for i, tok in enumerate(nxt):
+            r = sem(input_ids=torch.tensor([[tok]]), past_key_values=pkv, use_cache=True)
+            pkv = r.past_key_values
+            out[f"sem_logits{i + 1}"] = r.logits[0, -1].numpy()
+        out["sem_next"] = np.array(nxt, np.int32)
+
+        # ---- coarse: 300-token prefill then one decode step -------------------------------------
+        hp, tens = mf["coarse"]
+        co = build_hf_gpt(hp, tens, fine=False)
+        cprompt = np.concatenate([rng.integers(0, 10000, 256), [12050], rng.integers(10000, 12048, 43)]).astype(np.int64)
+        r = co(input_ids=torch.from_numpy(cprompt)[None], use_cache=True)
+        out["coarse_prompt"] = cprompt.astype(np.int32)
+        out["coarse_logits0"] = r.logits[0, -1].numpy()
+        r = co(input_ids=torch.tensor([[10777]]), past_key_values=r.past_key_values, use_cache=True)
+        out["coarse_logits1"] = r.logits[0, -1].numpy()
+
+        # ---- fine: N = 1024, codebooks 2 and 7 ------------------------------------------------------
+        hp, tens = mf["fine"]
+        fi = build_hf_gpt(hp, tens, fine=True)
+        ftok = rng.integers(0, 1024, (8, 1024)).astype(np.int64)
+        ftok[:, 900:] = 1024                       # padding rows, as bark.cpp:1990-1996 produces
+        out["fine_tokens"] = ftok.astype(np.int32)
+        rows = np.array([0, 1, 7, 100, 511, 512, 899, 900, 1023])
+        out["fine_rows"] = rows.astype(np.int32)
+        for nn in (2, 7):
+            r = fi(codebook_idx=nn, input_ids=torch.from_numpy(ftok.T.copy())[None])
+            out[f"fine_logits_nn{nn}"] = r.logits[0, rows].numpy()
+
+        # ---- codec: RVQ de-embedding + SEANet decoder -------------------------------------------------
+        hp, tens = mf["codec"]
+        dec = build_hf_codec(hp, tens)
+        for T in (3, 50):                                   # T=3 exercises the short-input reflect-pad rule
+            codes = rng.integers(0, 1024, (8, T)).astype(np.int64)
+            z = sum(torch.from_numpy(np.array(tens[f"quantizer.vq.layers.{q}._codebook.embed"]))[codes[q]] for q in range(8))
+            pcm = dec(z.T[None])[0, 0].numpy()
+            out[f"codec_codes_T{T}"] = codes.astype(np.int32)
+            out[f"codec_pcm_T{T}"] = pcm
+
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    dst = os.path.join(ROOT, "tests", "golden", "hf_toy_s0.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+    for k, v in out.items():
+        print(f"  {k:20s} {v.shape} {v.dtype}")
+
+
+if __name__ == "__main__":
+    main()
