@@ -128,16 +128,99 @@ static std::vector<float> to_f32(const Tensor & t) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------
+// dense kernels in CANONICAL summation order (DESIGN.md "Canonical numerics").
+//
+// ggml's CPU dot products sum in a SIMD-lane order that depends on the build (AVX2 / AVX-512 /
+// NEON use different accumulator counts), so the reference itself is not bit-stable across
+// hosts.  This oracle and the HIP engine therefore agree on ONE fixed order per operator, chosen
+// so that a GPU can reproduce it exactly with IEEE fp32 fma/add:
+//
+//  C1  weight dot  y = sum_k w[k]*x[k]   (mul_mat with f16/f32 weights, K padded with zeros to 128):
+//        the K axis is cut into 8-element chunks; chunk q belongs to chain (q mod 16); a chain
+//        walks its chunks in ascending order, and inside a chunk its 8 elements in ascending
+//        order, with acc = fmaf(w, x, acc) starting from +0.  The 16 chain sums are combined by
+//        the pairwise tree ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)) ... (butterfly xor 1,2,4,8).
+//  C2  attention score  s = sum_d k[d]*q[d]  : ONE chain, d ascending, acc = fmaf(k, q, acc).
+//  C5  attention mix    o[d] = sum_j v[j][d]*p[j] : key j belongs to chain (j mod 16), chains walk
+//        j ascending with acc = fmaf(v, p, acc); combined by the same 16-leaf tree as C1.
+// ------------------------------------------------------------------------------------
+static inline float hsum_tree16(__m256 lo, __m256 hi) {
+    alignas(32) float a[16];
+    _mm256_store_ps(a, lo); _mm256_store_ps(a + 8, hi);
+    float p[8], q[4], r[2];
+    for (int i = 0; i < 8; i++) p[i] = a[2 * i] + a[2 * i + 1];
+    for (int i = 0; i < 4; i++) q[i] = p[2 * i] + p[2 * i + 1];
+    for (int i = 0; i < 2; i++) r[i] = q[2 * i] + q[2 * i + 1];
+    return r[0] + r[1];
+}
+
+static inline int canon_kp(int K) { return (K + 127) & ~127; }
+
+// Chain-major image of one K-vector: dst[(b*8 + e)*16 + c] = src[b*128 + c*8 + e], zero padded.
+// (Padding is exact: fmaf(0, 0, acc) == acc.)
+static void canon_image_f32(const float * src, int K, float * dst) {
+    const int Kp = canon_kp(K);
+    for (int b = 0; b < Kp / 128; b++) for (int e = 0; e < 8; e++) for (int c = 0; c < 16; c++) {
+        const int k = b * 128 + c * 8 + e;
+        dst[(b * 8 + e) * 16 + c] = k < K ? src[k] : 0.0f;
+    }
+}
+// Weight matrices are re-imaged once at load time (CanonW); f16 weights stay f16 (exact).
+struct CanonW {
+    int M = 0, K = 0, Kp = 0; bool f16 = false;
+    uint8_t * data = nullptr; size_t bytes = 0;         // [M][Kp] in chain-major order
+    CanonW() = default;
+    CanonW(const CanonW &) = delete; CanonW & operator=(const CanonW &) = delete;
+    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), data(o.data), bytes(o.bytes) { o.data = nullptr; }
+    ~CanonW() { if (data) munmap(data, bytes); }
+    void build(const uint8_t * src, bool src_f16, int M_, int K_) {
+        M = M_; K = K_; Kp = canon_kp(K); f16 = src_f16;
+        const size_t es = f16 ? 2 : 4;
+        bytes = (size_t) M * Kp * es;
+        data = (uint8_t *) big_alloc(bytes);
+        #pragma omp parallel for schedule(static)
+        for (int m = 0; m < M; m++) {
+            const uint8_t * s = src + (size_t) m * K * es; uint8_t * d = data + (size_t) m * Kp * es;
+            for (int b = 0; b < Kp / 128; b++) for (int e = 0; e < 8; e++) for (int c = 0; c < 16; c++) {
+                const int k = b * 128 + c * 8 + e; const size_t o = (size_t) (b * 8 + e) * 16 + c;
+                if (k < K) memcpy(d + o * es, s + (size_t) k * es, es); else memset(d + o * es, 0, es);
+            }
+        }
+    }
+};
+
+template <bool A16> static inline void canon_load16(const uint8_t * p, __m256 & lo, __m256 & hi) {
+    if (A16) { lo = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *) p)); hi = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *) (p + 16))); }
+    else     { lo = _mm256_loadu_ps((const float *) p); hi = _mm256_loadu_ps((const float *) p + 8); }
+}
+
+template <bool A16, int NB>
+static inline void canon_dot(const uint8_t * w, const float * x, size_t ldx, int Kp, float * out, size_t ldo) {
+    __m256 a0[NB], a1[NB];
+    for (int r = 0; r < NB; r++) { a0[r] = _mm256_setzero_ps(); a1[r] = _mm256_setzero_ps(); }
+    const int steps = Kp / 16;
+    for (int p = 0; p < steps; p++) {
+        __m256 w0, w1; canon_load16<A16>(w + (size_t) p * 16 * (A16 ? 2 : 4), w0, w1);
+        for (int r = 0; r < NB; r++) {
+            a0[r] = _mm256_fmadd_ps(w0, _mm256_loadu_ps(x + r * ldx + p * 16), a0[r]);
+            a1[r] = _mm256_fmadd_ps(w1, _mm256_loadu_ps(x + r * ldx + p * 16 + 8), a1[r]);
+        }
+    }
+    for (int r = 0; r < NB; r++) out[r * ldo] = hsum_tree16(a0[r], a1[r]);
+}
+
 struct Layer {
     std::vector<float> ln1_g, ln1_b, ln2_g, ln2_b;         // *_b empty when absent
-    Tensor attn_w, proj_w, fc_w, mproj_w;                   // [out][in] row-major == ggml ne0 = in
+    CanonW attn_w, proj_w, fc_w, mproj_w;                   // file layout [out][in] row-major (ggml ne0 = in), re-imaged for C1
     std::vector<float> attn_b, proj_b, fc_b, mproj_b;       // empty when absent
 };
 
 struct Gpt {
     int n_layer = 0, n_head = 0, n_embd = 0, block_size = 0, bias = 0, n_in = 0, n_out = 0, n_lm_heads = 0, n_wtes = 0, ftype = 0;
     std::vector<float> lnf_g, lnf_b, wpe;
-    std::vector<Tensor> wtes, lm_heads;
+    std::vector<Tensor> wtes;
+    std::vector<CanonW> lm_heads;
     std::vector<Layer> layers;
     // KV cache, f32, [layer][position][n_embd]  (bark.cpp:976-991,1293-1300)
     float * mem_k = nullptr, * mem_v = nullptr;
@@ -181,10 +264,14 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
         if (it->second.ne[0] != ne0) return false;
         out = to_f32(it->second); return true;
     };
+    auto needw = [&](const std::string & n, CanonW & out, int64_t ne0, int64_t ne1) {
+        Tensor t; if (!need(n, t, ne0, ne1)) return false;
+        out.build(t.data, t.ttype == 1, (int) ne1, (int) ne0); return true;
+    };
     const int E = m.n_embd;
     bool ok = true;
     for (int i = 0; i < m.n_wtes; i++) ok = ok && need("model/wte/" + std::to_string(i), m.wtes[i], E, m.n_in);
-    for (int i = 0; i < m.n_lm_heads; i++) ok = ok && need("model/lm_head/" + std::to_string(i), m.lm_heads[i], E, m.n_out);
+    for (int i = 0; i < m.n_lm_heads; i++) ok = ok && needw("model/lm_head/" + std::to_string(i), m.lm_heads[i], E, m.n_out);
     { Tensor t; ok = ok && need("model/wpe", t, E, m.block_size); if (ok) m.wpe = to_f32(t); }
     ok = ok && vec("model/ln_f/g", m.lnf_g, E, true) && vec("model/ln_f/b", m.lnf_b, E, false);
     for (int l = 0; l < m.n_layer && ok; l++) {
@@ -192,8 +279,8 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
         Layer & L = m.layers[l];
         ok = ok && vec(p + "/ln_1/g", L.ln1_g, E, true) && vec(p + "/ln_1/b", L.ln1_b, E, false);
         ok = ok && vec(p + "/ln_2/g", L.ln2_g, E, true) && vec(p + "/ln_2/b", L.ln2_b, E, false);
-        ok = ok && need(p + "/attn/c_attn/w", L.attn_w, E, 3 * E) && need(p + "/attn/c_proj/w", L.proj_w, E, E);
-        ok = ok && need(p + "/mlp/c_fc/w", L.fc_w, E, 4 * E) && need(p + "/mlp/c_proj/w", L.mproj_w, 4 * E, E);
+        ok = ok && needw(p + "/attn/c_attn/w", L.attn_w, E, 3 * E) && needw(p + "/attn/c_proj/w", L.proj_w, E, E);
+        ok = ok && needw(p + "/mlp/c_fc/w", L.fc_w, E, 4 * E) && needw(p + "/mlp/c_proj/w", L.mproj_w, 4 * E, E);
         ok = ok && vec(p + "/attn/c_attn/b", L.attn_b, 3 * E, false) && vec(p + "/attn/c_proj/b", L.proj_b, E, false);
         ok = ok && vec(p + "/mlp/c_fc/b", L.fc_b, 4 * E, false) && vec(p + "/mlp/c_proj/b", L.mproj_b, E, false);
     }
@@ -208,7 +295,7 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
 // EnCodec decoder weights, all widened to f32 at load (exact)
 struct Conv { std::vector<float> w, b; int cout = 0, cin = 0, k = 0; };          // w[cout][cin][k]
 struct ConvT { std::vector<float> w, b; int cin = 0, cout = 0, k = 0, stride = 0; }; // w[cin][cout][k]
-struct Lstm { std::vector<float> w_ih, w_hh, b_ih, b_hh; };
+struct Lstm { CanonW w_ih, w_hh; std::vector<float> b_ih, b_hh; };
 struct Codec {
     int in_channels = 0, hidden_dim = 0, n_filters = 0, kernel = 0, res_kernel = 0, n_bins = 0, bandwidth = 0, sr = 0, ftype = 0;
     std::vector<std::vector<float>> codebooks;   // [q][n_bins][hidden_dim]
@@ -234,6 +321,11 @@ static bool load_codec(Reader & r, Codec & c) {
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s\n", n.c_str()); return false; }
         out = to_f32(it->second); return true;
     };
+    auto getw = [&](const std::string & n, CanonW & out) {
+        auto it = tens.find(n);
+        if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s\n", n.c_str()); return false; }
+        out.build(it->second.data, it->second.ttype == 1, (int) it->second.ne[1], (int) it->second.ne[0]); return true;
+    };
     auto conv = [&](const std::string & p, Conv & cv) {
         auto it = tens.find(p + ".weight");
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s.weight\n", p.c_str()); return false; }
@@ -249,7 +341,7 @@ static bool load_codec(Reader & r, Codec & c) {
     bool ok = conv("decoder.model.0.conv.conv", c.init);
     for (int l = 0; l < 2 && ok; l++) {
         std::string s = std::to_string(l);
-        ok = get("decoder.model.1.lstm.weight_ih_l" + s, c.lstm[l].w_ih) && get("decoder.model.1.lstm.weight_hh_l" + s, c.lstm[l].w_hh) &&
+        ok = getw("decoder.model.1.lstm.weight_ih_l" + s, c.lstm[l].w_ih) && getw("decoder.model.1.lstm.weight_hh_l" + s, c.lstm[l].w_hh) &&
              get("decoder.model.1.lstm.bias_ih_l" + s, c.lstm[l].b_ih) && get("decoder.model.1.lstm.bias_hh_l" + s, c.lstm[l].b_hh);
     }
     const int ratios[4] = {8, 5, 4, 2};    // EnCodec 24 kHz upsampling ratios (modeling_encodec.py:329-340)
@@ -286,7 +378,7 @@ struct Oracle {
     std::vector<uint16_t> gelu_table;
     std::mt19937 rng;
     // scratch
-    BigBuf x, xn, qkv, att, fc, tmp, scores, vt, logits;
+    BigBuf x, xn, qkv, att, fc, tmp, scores, vt, logits, ximg;
     ~Oracle() {
         for (Gpt * g : {&sem, &coarse, &fine}) {
             size_t n = (size_t) g->n_layer * g->block_size * g->n_embd * 4;
@@ -323,73 +415,6 @@ static inline float gelu_apply(const Oracle & o, float x) {
 }
 
 // ------------------------------------------------------------------------------------
-// dense kernels:  C[n][m] = sum_k A[m][k] * B[n][k]   (A: f16 or f32 rows, B: f32 rows)
-// ------------------------------------------------------------------------------------
-template <bool A16> static inline __m256 load_a8(const uint8_t * row, int k) {
-    if (A16) return _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *) (row + 2 * (size_t) k)));
-    return _mm256_loadu_ps((const float *) (row + 4 * (size_t) k));
-}
-template <bool A16> static inline float load_a1(const uint8_t * row, int k) {
-    return A16 ? h2f(ld_u16(row, k)) : ld_f32(row, k);
-}
-static inline float hsum8(__m256 v) {
-    __m128 lo = _mm256_castps256_ps128(v), hi = _mm256_extractf128_ps(v, 1);
-    lo = _mm_add_ps(lo, hi);
-    lo = _mm_add_ps(lo, _mm_movehl_ps(lo, lo));
-    lo = _mm_add_ss(lo, _mm_shuffle_ps(lo, lo, 1));
-    return _mm_cvtss_f32(lo);
-}
-
-template <bool A16, int MR, int NR>
-static inline void micro(const uint8_t * A, size_t lda, const float * B, size_t ldb, float * C, size_t ldc, int K) {
-    __m256 acc[MR][NR];
-    for (int i = 0; i < MR; i++) for (int j = 0; j < NR; j++) acc[i][j] = _mm256_setzero_ps();
-    const int K8 = K & ~7;
-    for (int k = 0; k < K8; k += 8) {
-        __m256 b[NR];
-        for (int j = 0; j < NR; j++) b[j] = _mm256_loadu_ps(B + j * ldb + k);
-        for (int i = 0; i < MR; i++) {
-            __m256 a = load_a8<A16>(A + i * lda, k);
-            for (int j = 0; j < NR; j++) acc[i][j] = _mm256_fmadd_ps(a, b[j], acc[i][j]);
-        }
-    }
-    for (int i = 0; i < MR; i++) for (int j = 0; j < NR; j++) {
-        float s = hsum8(acc[i][j]);
-        for (int k = K8; k < K; k++) s = fmaf(load_a1<A16>(A + i * lda, k), B[j * ldb + k], s);
-        C[j * ldc + i] = s;
-    }
-}
-
-// lda in BYTES (rows of A may be unaligned file data); ldb/ldc in floats.
-template <bool A16>
-static void gemm_nt_t(const uint8_t * A, size_t lda, const float * B, size_t ldb, float * C, size_t ldc,
-                      int M, int N, int K, int nth) {
-    const int MB = 4, NB = 3;
-    const int mblocks = (M + MB - 1) / MB;
-    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
-    for (int mb = 0; mb < mblocks; mb++) {
-        const int m0 = mb * MB, mr = std::min(MB, M - m0);
-        const uint8_t * a = A + (size_t) m0 * lda;
-        for (int n0 = 0; n0 < N; n0 += NB) {
-            const int nr = std::min(NB, N - n0);
-            const float * b = B + (size_t) n0 * ldb; float * c = C + (size_t) n0 * ldc + m0;
-            if (mr == 4 && nr == 3) micro<A16, 4, 3>(a, lda, b, ldb, c, ldc, K);
-            else {
-                for (int i = 0; i < mr; i++) for (int j = 0; j < nr; j++)
-                    micro<A16, 1, 1>(a + i * lda, lda, b + j * ldb, ldb, c + j * ldc + i, ldc, K);
-            }
-        }
-    }
-}
-static void gemm_w(const Tensor & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
-    if (W.ttype == 1) gemm_nt_t<true>(W.data, (size_t) K * 2, B, ldb, C, ldc, M, N, K, nth);
-    else              gemm_nt_t<false>(W.data, (size_t) K * 4, B, ldb, C, ldc, M, N, K, nth);
-}
-static void gemm_f32(const float * A, size_t lda, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K) {
-    gemm_nt_t<false>((const uint8_t *) A, lda * 4, B, ldb, C, ldc, M, N, K, 1);
-}
-
-// ------------------------------------------------------------------------------------
 // elementwise pieces with ggml-CPU rounding points
 // ------------------------------------------------------------------------------------
 // ggml_norm + ggml_mul(g) [+ ggml_add(b)]  (bark.cpp:1265-1274): sums in double, eps on the variance
@@ -412,43 +437,90 @@ static void round_rows(const Oracle & o, float * x, size_t n) {
     if (!o.num.act_round_f16) return;
     for (size_t i = 0; i < n; i++) x[i] = round_h(x[i]);
 }
-// ggml_soft_max over one row of `n` valid entries: max, expf, double sum, scale by (float)(1/sum)
+// ggml_soft_max over one row of `n` valid entries: max, exp, double sum, scale by (float)(1/sum).
+// Canonical exp: e = (float) exp((double)(s - max)) - a double-precision exp rounded once, so that
+// the CPU libm and the GPU's device libm (both < 1 ulp in double) agree on the float result.
 static void softmax_row(float * s, int n) {
     float mx = -INFINITY;
     for (int i = 0; i < n; i++) mx = std::max(mx, s[i]);
     double sum = 0.0;
-    for (int i = 0; i < n; i++) { float e = expf(s[i] - mx); s[i] = e; sum += (double) e; }
+    for (int i = 0; i < n; i++) { float e = (float) exp((double) (s[i] - mx)); s[i] = e; sum += (double) e; }
     const float inv = (float) (1.0 / sum);
     for (int i = 0; i < n; i++) s[i] *= inv;
+}
+
+// C[n*ldc + m] = C1-dot(W[m], B[n])   (B rows: f32, already holding f16-rounded values where ggml rounds)
+static void gemm_w(Oracle & o, const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
+    assert(M == W.M && K == W.K);
+    const int Kp = W.Kp;
+    o.ximg.ensure((size_t) N * Kp);
+    float * xi = o.ximg.p;
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
+    for (int n = 0; n < N; n++) canon_image_f32(B + (size_t) n * ldb, K, xi + (size_t) n * Kp);
+    const size_t rb = (size_t) Kp * (W.f16 ? 2 : 4);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
+    for (int m = 0; m < M; m++) {
+        const uint8_t * w = W.data + (size_t) m * rb;
+        int n = 0;
+        if (W.f16) {
+            for (; n + 4 <= N; n += 4) canon_dot<true, 4>(w, xi + (size_t) n * Kp, Kp, Kp, C + (size_t) n * ldc + m, ldc);
+            for (; n < N; n++)         canon_dot<true, 1>(w, xi + (size_t) n * Kp, Kp, Kp, C + (size_t) n * ldc + m, ldc);
+        } else {
+            for (; n + 4 <= N; n += 4) canon_dot<false, 4>(w, xi + (size_t) n * Kp, Kp, Kp, C + (size_t) n * ldc + m, ldc);
+            for (; n < N; n++)         canon_dot<false, 1>(w, xi + (size_t) n * Kp, Kp, Kp, C + (size_t) n * ldc + m, ldc);
+        }
+    }
 }
 
 // Multi-head attention for N query rows against `ctx_total` cached rows.
 //   q: rows at q[i*ldq + h*64 ...]; K/V rows at kc[j*E + h*64 ...]; out[i*E + h*64 ...]
 //   causal: query i sees keys j <= n_past + i (ggml_diag_mask_inf(n_past), bark.cpp:1320)
+// Summation orders: scores C2, mix C5 (see the dense-kernel header).  Masked keys carry p == 0 in
+// ggml and fmaf(v, 0, acc) == acc, so they are simply skipped here.
 static void attention(Oracle & o, const float * q, size_t ldq, const float * kc, const float * vc, float * out,
                       int N, int ctx_total, int n_past, bool causal, int E, int H, int nth) {
     const int D = E / H;
     const float scale = 1.0f / sqrtf((float) E / H);      // bark.cpp:1318
-    o.scores.ensure((size_t) nth * N * ctx_total);
-    o.vt.ensure((size_t) nth * D * ctx_total);
+    const int ctx8 = (ctx_total + 7) & ~7;
+    o.scores.ensure((size_t) nth * ctx8);
+    o.vt.ensure((size_t) nth * D * ctx8);
+    assert(D % 8 == 0);
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nth) if (nth > 1)
     for (int h = 0; h < H; h++) {
         const int tid = omp_get_thread_num();
-        float * S = o.scores.p + (size_t) tid * N * ctx_total;
-        float * Vt = o.vt.p + (size_t) tid * D * ctx_total;
-        // S[i][j] = K_j . Q_i   (f32 x f32, bark.cpp:1316)
-        gemm_f32(kc + h * D, E, q + h * D, ldq, S, ctx_total, ctx_total, N, D);
+        float * row = o.scores.p + (size_t) tid * ctx8;
+        float * Kt = o.vt.p + (size_t) tid * D * ctx8;                    // Kt[d][j]
+        for (int j = 0; j < ctx_total; j++) for (int d = 0; d < D; d++) Kt[(size_t) d * ctx8 + j] = kc[(size_t) j * E + h * D + d];
+        for (int j = ctx_total; j < ctx8; j++) for (int d = 0; d < D; d++) Kt[(size_t) d * ctx8 + j] = 0.0f;
         for (int i = 0; i < N; i++) {
-            float * row = S + (size_t) i * ctx_total;
+            const float * qi = q + (size_t) i * ldq + h * D;
             const int valid = causal ? std::min(ctx_total, n_past + i + 1) : ctx_total;
-            for (int j = 0; j < valid; j++) row[j] *= scale;
+            // C2: s[j] = chain over d of fmaf(K[j][d], Q[i][d], acc)   (f32 x f32, bark.cpp:1316)
+            for (int j0 = 0; j0 < valid; j0 += 8) {
+                __m256 acc = _mm256_setzero_ps();
+                for (int d = 0; d < D; d++) acc = _mm256_fmadd_ps(_mm256_loadu_ps(Kt + (size_t) d * ctx8 + j0), _mm256_set1_ps(qi[d]), acc);
+                _mm256_storeu_ps(row + j0, acc);
+            }
+            for (int j = 0; j < valid; j++) row[j] *= scale;                // ggml_scale_inplace, bark.cpp:1318
             softmax_row(row, valid);
-            for (int j = valid; j < ctx_total; j++) row[j] = 0.0f;   // exp(-inf - max) == 0
+            // C5: out[d] = 16 chains over j, tree-combined   (V_trans . P, bark.cpp:1324-1333)
+            float * oi = out + (size_t) i * E + h * D;
+            for (int d0 = 0; d0 < D; d0 += 8) {
+                __m256 acc[16];
+                for (int c = 0; c < 16; c++) acc[c] = _mm256_setzero_ps();
+                const float * vp = vc + h * D + d0;
+                int j = 0;
+                for (; j + 16 <= valid; j += 16)
+                    for (int c = 0; c < 16; c++)
+                        acc[c] = _mm256_fmadd_ps(_mm256_loadu_ps(vp + (size_t) (j + c) * E), _mm256_set1_ps(row[j + c]), acc[c]);
+                for (int c = 0; j + c < valid; c++)
+                    acc[c] = _mm256_fmadd_ps(_mm256_loadu_ps(vp + (size_t) (j + c) * E), _mm256_set1_ps(row[j + c]), acc[c]);
+                for (int c = 0; c < 16; c += 2) acc[c] = _mm256_add_ps(acc[c], acc[c + 1]);
+                for (int c = 0; c < 16; c += 4) acc[c] = _mm256_add_ps(acc[c], acc[c + 2]);
+                for (int c = 0; c < 16; c += 8) acc[c] = _mm256_add_ps(acc[c], acc[c + 4]);
+                _mm256_storeu_ps(oi + d0, _mm256_add_ps(acc[0], acc[8]));
+            }
         }
-        // V_trans (contiguous copy, bark.cpp:1324-1331), then KQV = V_trans . P
-        for (int j = 0; j < ctx_total; j++) for (int d = 0; d < D; d++) Vt[(size_t) d * ctx_total + j] = vc[(size_t) j * E + h * D + d];
-        // out[i][h*D + d] = sum_j Vt[d][j] * S[i][j]
-        gemm_f32(Vt, ctx_total, S, ctx_total, out + h * D, E, D, N, ctx_total);
     }
 }
 
@@ -468,7 +540,7 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln1_g.data(), L.ln1_b.empty() ? nullptr : L.ln1_b.data());
     round_rows(o, xn, (size_t) N * E);
-    gemm_w(L.attn_w, xn, E, qkv, 3 * E, 3 * E, N, E, nth);
+    gemm_w(o, L.attn_w, xn, E, qkv, 3 * E, 3 * E, N, E, nth);
     add_bias_rows(qkv, 3 * E, N, 3 * E, L.attn_b);
 
     if (causal_cached) {
@@ -490,17 +562,17 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
     }
 
     round_rows(o, att, (size_t) N * E);
-    gemm_w(L.proj_w, att, E, tmp, E, E, N, E, nth);
+    gemm_w(o, L.proj_w, att, E, tmp, E, E, N, E, nth);
     add_bias_rows(tmp, E, N, E, L.proj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpL  (bark.cpp:1352)
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln2_g.data(), L.ln2_b.empty() ? nullptr : L.ln2_b.data());
     round_rows(o, xn, (size_t) N * E);
-    gemm_w(L.fc_w, xn, E, fc, 4 * E, 4 * E, N, E, nth);
+    gemm_w(o, L.fc_w, xn, E, fc, 4 * E, 4 * E, N, E, nth);
     add_bias_rows(fc, 4 * E, N, 4 * E, L.fc_b);
     for (size_t i = 0; i < (size_t) N * 4 * E; i++) fc[i] = gelu_apply(o, fc[i]);
     round_rows(o, fc, (size_t) N * 4 * E);
-    gemm_w(L.mproj_w, fc, 4 * E, tmp, E, E, N, 4 * E, nth);
+    gemm_w(o, L.mproj_w, fc, 4 * E, tmp, E, E, N, 4 * E, nth);
     add_bias_rows(tmp, E, N, E, L.mproj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpFF (bark.cpp:1388)
 }
@@ -544,7 +616,7 @@ static bool gpt_eval(Oracle & o, Gpt & m, const int32_t * tokens, int n_tokens, 
     std::vector<float> last(E);
     layer_norm_row(x + (size_t) (N - 1) * E, last.data(), E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
     round_rows(o, last.data(), E);
-    gemm_w(m.lm_heads[0], last.data(), E, logits, m.n_out, m.n_out, 1, E, nth);
+    gemm_w(o, m.lm_heads[0], last.data(), E, logits, m.n_out, m.n_out, 1, E, nth);
     *n_past += N;
     m.t_predict_us += now_us() - t0;
     return true;
@@ -576,7 +648,7 @@ static bool fine_eval(Oracle & o, const int32_t * tokens, int nn, float * logits
     o.xn.ensure((size_t) N * E);
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, o.xn.p + (size_t) i * E, E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
     round_rows(o, o.xn.p, (size_t) N * E);
-    gemm_w(m.lm_heads[nn - 1], o.xn.p, E, logits, m.n_out, m.n_out, N, E, nth);   // lm_heads[codebook_idx - n_codes_given]
+    gemm_w(o, m.lm_heads[nn - 1], o.xn.p, E, logits, m.n_out, m.n_out, N, E, nth);   // lm_heads[codebook_idx - n_codes_given]
     m.t_predict_us += now_us() - t0;
     return true;
 }
@@ -891,8 +963,8 @@ static std::vector<float> lstm_layer(const Oracle & o, const Lstm & L, const std
     for (int t = 0; t < T; t++) {
         for (int d = 0; d < D; d++) { xt[d] = x[(size_t) d * T + t]; hr[d] = h[d]; }
         if (o.num.act_round_f16) { for (float & v : xt) v = round_h(v); for (float & v : hr) v = round_h(v); }
-        gemm_nt_t<false>((const uint8_t *) L.w_ih.data(), (size_t) D * 4, xt.data(), D, gi.data(), 4 * D, 4 * D, 1, D, nth);
-        gemm_nt_t<false>((const uint8_t *) L.w_hh.data(), (size_t) D * 4, hr.data(), D, gh.data(), 4 * D, 4 * D, 1, D, nth);
+        gemm_w(const_cast<Oracle &>(o), L.w_ih, xt.data(), D, gi.data(), 4 * D, 4 * D, 1, D, nth);     // C1 order
+        gemm_w(const_cast<Oracle &>(o), L.w_hh, hr.data(), D, gh.data(), 4 * D, 4 * D, 1, D, nth);
         for (int d = 0; d < D; d++) {
             auto gate = [&](int g) { return (gi[g * D + d] + L.b_ih[g * D + d]) + (gh[g * D + d] + L.b_hh[g * D + d]); };
             const float i_t = 1.f / (1.f + expf(-gate(0)));
