@@ -1,0 +1,301 @@
+"""ctypes mirror of libbark.so (include/bark.h + include/bark_mi355x.h).
+
+Names, argument meaning and error behaviour follow the reference C API
+(/root/reference/bark.h:148-240): `BarkContext.load_model` <-> bark_load_model,
+`generate_audio` <-> bark_generate_audio, `audio_data` <-> bark_get_audio_data[_size], ...
+There is NO fallback: if the HIP library is missing or no GPU is present, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+
+
+class BarkContextParams(C.Structure):
+    """struct bark_context_params (bark.h:81-141) - field order is ABI."""
+    _fields_ = [
+        ("verbosity", C.c_int), ("temp", C.c_float), ("fine_temp", C.c_float), ("min_eos_p", C.c_float),
+        ("sliding_window_size", C.c_int32), ("max_coarse_history", C.c_int32), ("sample_rate", C.c_int32),
+        ("target_bandwidth", C.c_int32), ("cls_token_id", C.c_int32), ("sep_token_id", C.c_int32),
+        ("n_steps_text_encoder", C.c_int32), ("text_pad_token", C.c_int32), ("text_encoding_offset", C.c_int32),
+        ("semantic_rate_hz", C.c_float), ("semantic_pad_token", C.c_int32), ("semantic_vocab_size", C.c_int32),
+        ("semantic_infer_token", C.c_int32), ("coarse_rate_hz", C.c_float), ("coarse_infer_token", C.c_int32),
+        ("coarse_semantic_pad_token", C.c_int32), ("n_coarse_codebooks", C.c_int32), ("n_fine_codebooks", C.c_int32),
+        ("codebook_size", C.c_int32), ("progress_callback", PROGRESS_CB), ("progress_callback_user_data", C.c_void_p),
+    ]
+
+
+class BarkHipStats(C.Structure):
+    _fields_ = [
+        ("t_load_us", C.c_int64), ("t_eval_us", C.c_int64), ("t_semantic_us", C.c_int64), ("t_coarse_us", C.c_int64),
+        ("t_fine_us", C.c_int64), ("t_codec_us", C.c_int64), ("n_sample_semantic", C.c_int64), ("n_sample_coarse", C.c_int64),
+        ("n_sample_fine", C.c_int64), ("n_semantic", C.c_int32), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
+        ("n_near_tie", C.c_int32), ("graph_replays", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "lib", "libbark.so")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["rm", "-rf", os.path.join(_HERE, "lib", "obj")])
+    subprocess.check_call([os.path.join(_HERE, "build.sh")])
+    return library_path()
+
+
+_LIB = None
+
+EXPORTS = [
+    # bark.h
+    "bark_context_default_params", "bark_load_model", "bark_generate_audio", "bark_get_audio_data", "bark_get_audio_data_size",
+    "bark_get_load_time", "bark_get_eval_time", "bark_reset_statistics", "bark_model_quantize", "bark_free",
+    # ggml.h shim
+    "ggml_time_init", "ggml_time_us", "ggml_time_ms", "ggml_init", "ggml_free",
+    # bark_mi355x.h
+    "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
+    "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode",
+    "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
+    "bark_hip_time_decode_step", "bark_hip_time_fine_pass", "bark_hip_describe",
+]
+
+
+def load_library() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing - run bark.cpp_amd/build.sh (there is no fallback path)")
+    lib = C.CDLL(path)
+    vp, ip, fp = C.c_void_p, C.c_void_p, C.c_void_p
+    lib.bark_context_default_params.restype = BarkContextParams
+    lib.bark_context_default_params.argtypes = []
+    lib.bark_load_model.restype = vp
+    lib.bark_load_model.argtypes = [C.c_char_p, BarkContextParams, C.c_uint32]
+    lib.bark_generate_audio.restype = C.c_bool
+    lib.bark_generate_audio.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.bark_get_audio_data.restype = C.POINTER(C.c_float)
+    lib.bark_get_audio_data.argtypes = [vp]
+    lib.bark_get_audio_data_size.restype = C.c_int
+    lib.bark_get_audio_data_size.argtypes = [vp]
+    lib.bark_get_load_time.restype = C.c_int64
+    lib.bark_get_load_time.argtypes = [vp]
+    lib.bark_get_eval_time.restype = C.c_int64
+    lib.bark_get_eval_time.argtypes = [vp]
+    lib.bark_reset_statistics.argtypes = [vp]
+    lib.bark_model_quantize.restype = C.c_bool
+    lib.bark_model_quantize.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    lib.bark_free.argtypes = [vp]
+    lib.ggml_time_us.restype = C.c_int64
+    lib.bark_hip_hparams.argtypes = [vp, C.c_int, ip]
+    lib.bark_hip_set_params.argtypes = [vp, BarkContextParams]
+    lib.bark_hip_tokenize.argtypes = [vp, C.c_char_p, ip]
+    lib.bark_hip_bert_tokenize.argtypes = [vp, C.c_char_p, ip, C.c_int]
+    lib.bark_hip_gpt_eval.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int, C.c_int, fp]
+    lib.bark_hip_fine_eval.argtypes = [vp, ip, C.c_int, fp]
+    lib.bark_hip_semantic.argtypes = [vp, ip, ip, fp]
+    lib.bark_hip_coarse.argtypes = [vp, ip, C.c_int, ip]
+    lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip]
+    lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
+    lib.bark_hip_get_semantic_tokens.argtypes = [vp, ip, C.c_int]
+    lib.bark_hip_get_coarse_tokens.argtypes = [vp, ip, C.c_int]
+    lib.bark_hip_get_fine_tokens.argtypes = [vp, ip, C.c_int]
+    lib.bark_hip_get_stats.argtypes = [vp, C.POINTER(BarkHipStats)]
+    lib.bark_hip_time_decode_step.restype = C.c_double
+    lib.bark_hip_time_decode_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.bark_hip_time_fine_pass.restype = C.c_double
+    lib.bark_hip_time_fine_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    lib.bark_hip_describe.restype = C.c_char_p
+    lib.bark_hip_describe.argtypes = [vp]
+    _LIB = lib
+    return lib
+
+
+def default_params(**overrides) -> BarkContextParams:
+    p = load_library().bark_context_default_params()
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class BarkContext:
+    """Owner of a `struct bark_context *`."""
+
+    def __init__(self, handle, lib):
+        self._h = handle
+        self._lib = lib
+        self._cb = None
+
+    # ---- bark.h ---------------------------------------------------------------------------------
+    @classmethod
+    def load_model(cls, model_path: str, params: BarkContextParams | None = None, seed: int = 0) -> "BarkContext":
+        lib = load_library()
+        params = params if params is not None else default_params()
+        h = lib.bark_load_model(os.fsencode(model_path), params, seed)
+        if not h:
+            raise RuntimeError(f"bark_load_model failed for {model_path}")
+        ctx = cls(h, lib)
+        ctx._cb = params.progress_callback      # keep the callback object alive
+        return ctx
+
+    def generate_audio(self, text: str, n_threads: int = 4) -> bool:
+        return bool(self._lib.bark_generate_audio(self._h, text.encode("utf-8"), n_threads))
+
+    def audio_data(self) -> np.ndarray:
+        n = self._lib.bark_get_audio_data_size(self._h)
+        p = self._lib.bark_get_audio_data(self._h)
+        if n <= 0 or not p:
+            return np.zeros(0, np.float32)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def load_time_us(self) -> int:
+        return int(self._lib.bark_get_load_time(self._h))
+
+    def eval_time_us(self) -> int:
+        return int(self._lib.bark_get_eval_time(self._h))
+
+    def reset_statistics(self):
+        self._lib.bark_reset_statistics(self._h)
+
+    def free(self):
+        if self._h:
+            self._lib.bark_free(self._h)
+            self._h = None
+
+    close = free
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # ---- bark_mi355x.h --------------------------------------------------------------------------
+    def describe(self) -> str:
+        return self._lib.bark_hip_describe(self._h).decode()
+
+    def hparams(self, which: int) -> dict:
+        out = np.zeros(10, np.int32)
+        if self._lib.bark_hip_hparams(self._h, which, out.ctypes.data) != 0:
+            raise RuntimeError("bark_hip_hparams failed")
+        keys = ["n_layer", "n_head", "n_embd", "block_size", "bias", "n_in", "n_out", "n_lm_heads", "n_wtes", "ftype"]
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def set_params(self, params: BarkContextParams):
+        self._cb = params.progress_callback
+        self._lib.bark_hip_set_params(self._h, params)
+
+    def tokenize(self, text: str) -> np.ndarray:
+        out = np.zeros(513, np.int32)
+        n = self._lib.bark_hip_tokenize(self._h, text.encode("utf-8"), out.ctypes.data)
+        if n != 513:
+            raise RuntimeError("bark_hip_tokenize failed")
+        return out
+
+    def bert_tokenize(self, text: str, n_max: int = 256) -> np.ndarray:
+        out = np.zeros(n_max, np.int32)
+        n = self._lib.bark_hip_bert_tokenize(self._h, text.encode("utf-8"), out.ctypes.data, n_max)
+        if n < 0:
+            raise RuntimeError("bark_hip_bert_tokenize failed")
+        return out[:n]
+
+    def gpt_eval(self, which: int, tokens, n_past: int, merge_ctx: bool):
+        tokens = _i32(tokens)
+        logits = np.zeros(self.hparams(which)["n_out"], np.float32)
+        r = self._lib.bark_hip_gpt_eval(self._h, which, tokens.ctypes.data, len(tokens), n_past, int(merge_ctx), logits.ctypes.data)
+        if r < 0:
+            raise RuntimeError("bark_hip_gpt_eval failed")
+        return logits, r
+
+    def fine_eval(self, tokens_8x1024, nn: int) -> np.ndarray:
+        tokens = _i32(tokens_8x1024).reshape(8, 1024)
+        logits = np.zeros((1024, self.hparams(2)["n_out"]), np.float32)
+        if self._lib.bark_hip_fine_eval(self._h, tokens.ctypes.data, nn, logits.ctypes.data) != 0:
+            raise RuntimeError("bark_hip_fine_eval failed")
+        return logits
+
+    def semantic(self, prompt513, want_eos_trace: bool = False):
+        prompt = _i32(prompt513)
+        assert prompt.shape == (513,)
+        out = np.zeros(1024, np.int32)
+        tr = np.zeros(1024, np.float32)
+        n = self._lib.bark_hip_semantic(self._h, prompt.ctypes.data, out.ctypes.data, tr.ctypes.data if want_eos_trace else None)
+        if n < 0:
+            raise RuntimeError("bark_hip_semantic failed")
+        return (out[:n].copy(), tr) if want_eos_trace else out[:n].copy()
+
+    def coarse(self, semantic) -> np.ndarray:
+        sem = _i32(semantic)
+        out = np.zeros((4096, 2), np.int32)
+        T = self._lib.bark_hip_coarse(self._h, sem.ctypes.data, len(sem), out.ctypes.data)
+        if T < 0:
+            raise RuntimeError("bark_hip_coarse failed")
+        return out[:T].copy()
+
+    def fine(self, coarse_Tx2) -> np.ndarray:
+        co = _i32(coarse_Tx2).reshape(-1, 2)
+        out = np.zeros((1024, 8), np.int32)
+        T = self._lib.bark_hip_fine(self._h, co.ctypes.data, len(co), out.ctypes.data)
+        if T < 0:
+            raise RuntimeError("bark_hip_fine failed")
+        return out[:T].copy()
+
+    def codec_decode(self, codes_qxT) -> np.ndarray:
+        codes = _i32(codes_qxT)
+        n_q, T = codes.shape
+        pcm = np.zeros(T * 320, np.float32)
+        n = self._lib.bark_hip_codec_decode(self._h, codes.ctypes.data, n_q, T, pcm.ctypes.data)
+        if n < 0:
+            raise RuntimeError("bark_hip_codec_decode failed")
+        return pcm[:n].copy()
+
+    def semantic_tokens(self) -> np.ndarray:
+        out = np.zeros(1024, np.int32)
+        n = self._lib.bark_hip_get_semantic_tokens(self._h, out.ctypes.data, 1024)
+        return out[:max(n, 0)].copy()
+
+    def coarse_tokens(self) -> np.ndarray:
+        out = np.zeros((2048, 2), np.int32)
+        n = self._lib.bark_hip_get_coarse_tokens(self._h, out.ctypes.data, 2048)
+        return out[:max(n, 0)].copy()
+
+    def fine_tokens(self) -> np.ndarray:
+        out = np.zeros((1024, 8), np.int32)
+        n = self._lib.bark_hip_get_fine_tokens(self._h, out.ctypes.data, 1024)
+        return out[:max(n, 0)].copy()
+
+    def stats(self) -> dict:
+        s = BarkHipStats()
+        self._lib.bark_hip_get_stats(self._h, C.byref(s))
+        return s.as_dict()
+
+    def time_decode_step(self, which: int, ctx: int, iters: int):
+        b = C.c_double(0)
+        us = self._lib.bark_hip_time_decode_step(self._h, which, ctx, iters, C.byref(b))
+        if us < 0:
+            raise RuntimeError("bark_hip_time_decode_step failed")
+        return us, b.value
+
+    def time_fine_pass(self, iters: int):
+        f = C.c_double(0)
+        us = self._lib.bark_hip_time_fine_pass(self._h, iters, C.byref(f))
+        if us < 0:
+            raise RuntimeError("bark_hip_time_fine_pass failed")
+        return us, f.value

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Builds bark.cpp_amd/lib/libbark.so for gfx950 (cross-compiles without a GPU).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$HERE/csrc"
+OUT="$HERE/lib"
+mkdir -p "$OUT" "$OUT/obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function -I$HERE/../include -I$SRC"
+pids=()
+for f in kernels.hip codec_kernels.hip engine.hip api.hip; do
+    o="$OUT/obj/${f%.*}.o"
+    if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h' -newer "$o" 2>/dev/null | head -1)" ]; then
+        $HIPCC $FLAGS -c "$SRC/$f" -o "$o" &
+        pids+=($!)
+    fi
+done
+for f in model_file.cpp tokenizer.cpp; do
+    o="$OUT/obj/${f%.*}.o"
+    if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" -name '*.h' -newer "$o" 2>/dev/null | head -1)" ]; then
+        g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -I"$SRC" -c "$SRC/$f" -o "$o" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbark.so" "$OUT"/obj/*.o
+echo "built $OUT/libbark.so"

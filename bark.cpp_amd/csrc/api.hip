@@ -1,0 +1,204 @@
+// api.hip - C ABI of libbark.so: the reference's bark.h surface (drop-in) plus bark_mi355x.h.
+// No exception crosses the boundary; failures are reported as nullptr / false / negative counts with
+// a diagnostic on stderr, like the reference (bark.cpp:1174-1177, 2379-2401).
+#include "engine.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+using namespace barkhip;
+
+namespace {
+int64_t wall_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+template <typename F> auto guarded(const char * what, decltype(std::declval<F>()()) fail, F && f) -> decltype(f()) {
+    try { return f(); }
+    catch (const std::exception & e) { fprintf(stderr, "%s: %s\n", what, e.what()); }
+    catch (...) { fprintf(stderr, "%s: unknown failure\n", what); }
+    return fail;
+}
+}  // namespace
+
+extern "C" {
+
+// defaults: /root/reference/bark.cpp:2202-2232
+struct bark_context_params bark_context_default_params(void) {
+    struct bark_context_params p;
+    memset(&p, 0, sizeof(p));
+    p.verbosity = LOW;
+    p.temp = 0.7f;
+    p.fine_temp = 0.5f;
+    p.min_eos_p = 0.2f;
+    p.sliding_window_size = 60;
+    p.max_coarse_history = 630;
+    p.sample_rate = 24000;
+    p.target_bandwidth = 6;
+    p.cls_token_id = 101;
+    p.sep_token_id = 102;
+    p.n_steps_text_encoder = 768;
+    p.text_pad_token = 129595;
+    p.text_encoding_offset = 10048;
+    p.semantic_rate_hz = 49.9f;
+    p.semantic_pad_token = 10000;
+    p.semantic_vocab_size = 10000;
+    p.semantic_infer_token = 129599;
+    p.coarse_rate_hz = 75.0f;
+    p.coarse_infer_token = 12050;
+    p.coarse_semantic_pad_token = 12048;
+    p.n_coarse_codebooks = 2;
+    p.n_fine_codebooks = 8;
+    p.codebook_size = 1024;
+    p.progress_callback = nullptr;
+    p.progress_callback_user_data = nullptr;
+    return p;
+}
+
+struct bark_context * bark_load_model(const char * model_path, struct bark_context_params params, uint32_t seed) {
+    const int64_t t0 = wall_us();
+    if (!model_path) { fprintf(stderr, "bark_load_model: null path\n"); return nullptr; }
+    bark_context * ctx = guarded("bark_load_model", (bark_context *) nullptr, [&] { return engine_load(model_path, params, seed); });
+    if (ctx) ctx->stats.t_load_us = wall_us() - t0;
+    return ctx;
+}
+
+bool bark_generate_audio(struct bark_context * bctx, const char * text, int n_threads) {
+    (void) n_threads;      // CPU-backend hint in the reference (bark.cpp:1623-1625); the HIP engine has no use for it
+    if (!bctx || !text) { fprintf(stderr, "bark_generate_audio: null argument\n"); return false; }
+    return guarded("bark_generate_audio", false, [&] { return engine_generate(bctx, text); });
+}
+
+float * bark_get_audio_data(struct bark_context * bctx) { return (bctx && !bctx->audio.empty()) ? bctx->audio.data() : nullptr; }
+int bark_get_audio_data_size(struct bark_context * bctx) { return bctx ? (int) bctx->audio.size() : 0; }
+int64_t bark_get_load_time(struct bark_context * bctx) { return bctx ? bctx->stats.t_load_us : 0; }
+int64_t bark_get_eval_time(struct bark_context * bctx) { return bctx ? bctx->stats.t_eval_us : 0; }
+
+void bark_reset_statistics(struct bark_context * bctx) {
+    if (!bctx) return;
+    const int64_t t_load = bctx->stats.t_load_us;
+    bctx->stats = bark_hip_stats{};
+    bctx->stats.t_load_us = t_load;
+}
+
+bool bark_model_quantize(const char * fname_inp, const char * fname_out, enum ggml_ftype ftype) {
+    (void) fname_inp; (void) fname_out; (void) ftype;
+    fprintf(stderr, "bark_model_quantize: the offline quantizer is outside this engine's scope (hot path only); use the reference tool\n");
+    return false;
+}
+
+void bark_free(struct bark_context * bctx) { delete bctx; }
+
+// ---- ggml.h shim --------------------------------------------------------------------------------------
+void ggml_time_init(void) {}
+int64_t ggml_time_us(void) { return wall_us(); }
+int64_t ggml_time_ms(void) { return wall_us() / 1000; }
+struct ggml_context * ggml_init(struct ggml_init_params params) { (void) params; return nullptr; }
+void ggml_free(struct ggml_context * ctx) { (void) ctx; }
+
+// ---- bark_mi355x.h -------------------------------------------------------------------------------------
+int bark_hip_hparams(struct bark_context * bctx, int which, int32_t * out10) {
+    if (!bctx || which < 0 || which > 2 || !out10) return -1;
+    const GptHparams & h = bctx->gpt[which].hp;
+    const int32_t v[10] = {h.n_layer, h.n_head, h.n_embd, h.block_size, h.bias, h.n_in_vocab, h.n_out_vocab, h.n_lm_heads, h.n_wtes, h.ftype};
+    memcpy(out10, v, sizeof(v));
+    return 0;
+}
+
+void bark_hip_set_params(struct bark_context * bctx, struct bark_context_params params) {
+    if (!bctx) return;
+    bctx->params = params;
+    guarded("bark_hip_set_params", 0, [&] { engine_invalidate_graphs(bctx); return 0; });   // sampling constants are baked into the graphs
+}
+
+int bark_hip_tokenize(struct bark_context * bctx, const char * text, int32_t * out513) {
+    if (!bctx || !text || !out513) return -1;
+    return guarded("bark_hip_tokenize", -1, [&] {
+        PromptParams pp;
+        pp.block_size = bctx->gpt[0].hp.block_size; pp.text_encoding_offset = bctx->params.text_encoding_offset;
+        pp.text_pad_token = bctx->params.text_pad_token; pp.semantic_pad_token = bctx->params.semantic_pad_token;
+        pp.semantic_infer_token = bctx->params.semantic_infer_token;
+        std::vector<int32_t> ids = build_semantic_prompt(bctx->vocab, pp, text, false);
+        memcpy(out513, ids.data(), ids.size() * 4);
+        return (int) ids.size();
+    });
+}
+
+int bark_hip_bert_tokenize(struct bark_context * bctx, const char * text, int32_t * out, int n_max) {
+    if (!bctx || !text || !out || n_max <= 0) return -1;
+    return guarded("bark_hip_bert_tokenize", -1, [&] { return wordpiece_encode(bctx->vocab, text, out, n_max, false); });
+}
+
+int bark_hip_gpt_eval(struct bark_context * bctx, int which, const int32_t * tokens, int n_tokens, int n_past, int merge_ctx, float * logits) {
+    if (!bctx || !tokens || !logits) return -1;
+    return guarded("bark_hip_gpt_eval", -1, [&] { return engine_gpt_eval(bctx, which, tokens, n_tokens, n_past, merge_ctx != 0, logits); });
+}
+
+int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * tokens_8x1024, int nn, float * logits) {
+    if (!bctx || !tokens_8x1024 || !logits) return -1;
+    return guarded("bark_hip_fine_eval", -1, [&] { engine_fine_eval(bctx, tokens_8x1024, nn, logits); return 0; });
+}
+
+int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, float * eos_trace) {
+    if (!bctx || !prompt513 || !out) return -1;
+    return guarded("bark_hip_semantic", -1, [&] {
+        std::vector<int32_t> prompt(prompt513, prompt513 + 513);
+        std::vector<float> tr;
+        std::vector<int32_t> r = engine_semantic(bctx, prompt, eos_trace ? &tr : nullptr);
+        if (!r.empty()) memcpy(out, r.data(), r.size() * 4);
+        if (eos_trace && !tr.empty()) memcpy(eos_trace, tr.data(), tr.size() * 4);
+        return (int) r.size();
+    });
+}
+
+int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2) {
+    if (!bctx || !semantic || n_semantic <= 0 || !out_Tx2) return -1;
+    return guarded("bark_hip_coarse", -1, [&] {
+        std::vector<int32_t> r = engine_coarse(bctx, std::vector<int32_t>(semantic, semantic + n_semantic));
+        memcpy(out_Tx2, r.data(), r.size() * 4);
+        return (int) r.size() / 2;
+    });
+}
+
+int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8) {
+    if (!bctx || !coarse_Tx2 || T <= 0 || !out_Tx8) return -1;
+    return guarded("bark_hip_fine", -1, [&] {
+        std::vector<int32_t> r = engine_fine(bctx, std::vector<int32_t>(coarse_Tx2, coarse_Tx2 + (size_t) T * 2));
+        memcpy(out_Tx8, r.data(), r.size() * 4);
+        return (int) r.size() / 8;
+    });
+}
+
+int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm) {
+    if (!bctx || !codes || !pcm) return -1;
+    return guarded("bark_hip_codec_decode", -1, [&] {
+        std::vector<float> r = engine_codec_decode(bctx, codes, n_q, T);
+        memcpy(pcm, r.data(), r.size() * 4);
+        return (int) r.size();
+    });
+}
+
+static int copy_out(const std::vector<int32_t> & v, int per_row, int32_t * out, int capacity_rows) {
+    const int rows = (int) v.size() / per_row;
+    if (!out || capacity_rows < rows) return -1;
+    if (rows) memcpy(out, v.data(), v.size() * 4);
+    return rows;
+}
+int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity) { return bctx ? copy_out(bctx->semantic_tokens, 1, out, capacity) : -1; }
+int bark_hip_get_coarse_tokens(struct bark_context * bctx, int32_t * out, int capacity_rows) { return bctx ? copy_out(bctx->coarse_tokens, 2, out, capacity_rows) : -1; }
+int bark_hip_get_fine_tokens(struct bark_context * bctx, int32_t * out, int capacity_rows) { return bctx ? copy_out(bctx->fine_tokens, 8, out, capacity_rows) : -1; }
+
+void bark_hip_get_stats(struct bark_context * bctx, struct bark_hip_stats * out) { if (bctx && out) *out = bctx->stats; }
+
+double bark_hip_time_decode_step(struct bark_context * bctx, int which, int ctx, int iters, double * bytes_per_step) {
+    if (!bctx) return -1.0;
+    return guarded("bark_hip_time_decode_step", -1.0, [&] { return engine_time_decode_step(bctx, which, ctx, iters, bytes_per_step); });
+}
+double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass) {
+    if (!bctx) return -1.0;
+    return guarded("bark_hip_time_fine_pass", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass); });
+}
+const char * bark_hip_describe(struct bark_context * bctx) { return bctx ? bctx->description.c_str() : "no context"; }
+
+}  // extern "C"

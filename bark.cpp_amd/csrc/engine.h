@@ -1,0 +1,110 @@
+// engine.h - the MI355X Bark engine behind bark.h / bark_mi355x.h.
+//
+// Pipeline (reference call stack /root/reference/bark.cpp:2125-2172): tokenise -> semantic GPT ->
+// coarse GPT (sliding windows) -> fine GPT (6 non-causal passes per window) -> EnCodec decoder.
+// Weights live in one device slab; activations, KV caches and the per-stage StepState are
+// device-resident; a decode step is a fixed kernel sequence captured once per model in a hipGraph
+// and replayed per token with no host-side parameter updates.
+#pragma once
+#include "bark.h"
+#include "bark_mi355x.h"
+#include "kernels.h"
+#include "model_file.h"
+#include "tokenizer.h"
+
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace barkhip {
+
+struct GptModel {
+    GptHparams hp;
+    const half_t * wte[8] = {};
+    const half_t * lm_head[8] = {};
+    const float * wpe = nullptr, * lnf_g = nullptr, * lnf_b = nullptr;
+    struct Layer {
+        const float * ln1_g = nullptr, * ln1_b = nullptr, * ln2_g = nullptr, * ln2_b = nullptr;
+        const half_t * attn_w = nullptr, * proj_w = nullptr, * fc_w = nullptr, * mproj_w = nullptr;
+        const float * attn_b = nullptr, * proj_b = nullptr, * fc_b = nullptr, * mproj_b = nullptr;
+    };
+    std::vector<Layer> layers;
+    float * kcache = nullptr, * vcache = nullptr;       // [L][H][16][P][4] / [L][H][P][64] f32; fine model: L = 1 scratch
+    size_t kv_layer_stride = 0;                         // floats per layer (0 for the fine model's shared scratch)
+    hipGraphExec_t decode_graph = nullptr;              // embed -> layers -> LM head -> greedy sample
+    hipGraphExec_t bench_graph = nullptr;               // same, without advancing n_past (timing hook)
+};
+
+struct CodecModel {
+    CodecHparams hp;
+    int n_q = 0, D = 0;
+    const float * codebooks = nullptr;                  // [n_q][n_bins][hidden_dim]
+    struct Conv { const half_t * w = nullptr; const float * b = nullptr; int cout = 0, cin = 0, k = 0; };
+    struct ConvT { const half_t * w = nullptr; const float * b = nullptr; int cin = 0, cout = 0, k = 0, stride = 0; };
+    struct Lstm { const half_t * w_ih = nullptr, * w_hh = nullptr; const float * b_ih = nullptr, * b_hh = nullptr; };
+    Conv init, fin;
+    Lstm lstm[2];
+    struct Block { ConvT up; Conv c1, c2, sc; } blocks[4];
+};
+
+}  // namespace barkhip
+
+// The opaque handle of bark.h.
+struct bark_context {
+    bark_context_params params;
+    std::mt19937 rng;
+
+    barkhip::Vocab vocab;
+    barkhip::GptModel gpt[3];
+    barkhip::CodecModel codec;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool use_graph = true;
+
+    // device memory
+    void * weight_slab = nullptr; size_t weight_bytes = 0;
+    std::vector<void *> allocs;                         // everything else (freed in destroy)
+    // GPT scratch
+    float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
+    barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
+    int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
+    float * d_eos_trace = nullptr;
+    barkhip::StepState * d_state = nullptr;
+    uint16_t * d_gelu_lut = nullptr;
+    int max_E = 0, max_H = 0, P = 1024;
+    // codec scratch (grown on demand)
+    float * cbuf[3] = {nullptr, nullptr, nullptr}; size_t cbuf_elems = 0;
+    barkhip::half_t * cbuf_h = nullptr; size_t cbuf_h_elems = 0;
+    float * c_gi = nullptr, * c_cell = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr; size_t c_T = 0;
+    int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
+
+    // results of the last generate call
+    std::vector<int32_t> tokens, semantic_tokens, coarse_tokens, fine_tokens;
+    std::vector<float> audio;
+    std::vector<float> eos_trace;
+    bark_hip_stats stats{};
+    std::string description;
+
+    ~bark_context();
+};
+
+namespace barkhip {
+
+// All functions throw std::runtime_error on failure; the C API catches at the boundary.
+bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed);
+void engine_invalidate_graphs(bark_context * ctx);
+
+int  engine_gpt_eval(bark_context * ctx, int which, const int32_t * tokens, int n_tokens, int n_past, bool merge_ctx, float * logits);
+void engine_fine_eval(bark_context * ctx, const int32_t * tokens_8x1024, int nn, float * logits);
+
+std::vector<int32_t> engine_semantic(bark_context * ctx, const std::vector<int32_t> & prompt, std::vector<float> * eos_trace);
+std::vector<int32_t> engine_coarse(bark_context * ctx, const std::vector<int32_t> & semantic);          // [T][2]
+std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> & coarse_Tx2);          // [T][8]
+std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T);
+bool engine_generate(bark_context * ctx, const char * text);
+
+double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
+double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass);
+
+}  // namespace barkhip

@@ -1,0 +1,952 @@
+// engine.hip - model upload, stage loops and orchestration of the MI355X Bark engine.
+// Control flow restates /root/reference/bark.cpp (cited per function); all tensor math runs in the
+// HIP kernels of kernels.hip / codec_kernels.hip.  No CPU fallback exists: without a HIP device
+// bark_load_model fails.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+using namespace barkhip;
+
+namespace {
+
+#define HIP_OK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);   \
+    } while (0)
+
+inline int64_t now_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
+    void * p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ctx->allocs.push_back(p);
+    return (T *) p;
+}
+
+// ---- weight slab ---------------------------------------------------------------------------------
+struct SlabPlan {
+    struct Item { const uint8_t * src; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    size_t add(const TensorRef & t) {
+        const size_t off = total;
+        items.push_back({t.data, t.nbytes(), off});
+        total = (total + t.nbytes() + 255) & ~(size_t) 255;
+        return off;
+    }
+};
+
+const TensorRef & need(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0, int64_t ne1) {
+    auto it = m.find(name);
+    if (it == m.end()) throw std::runtime_error("missing tensor '" + name + "'");
+    const TensorRef & t = it->second;
+    if (ne0 > 0 && (t.ne[0] != ne0 || (ne1 > 0 && t.ne[1] != ne1)))       // shape check on ne[0], ne[1] (bark.cpp:1034)
+        throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
+    if (t.ttype != ttype)
+        throw std::runtime_error("tensor '" + name + "' is " + (t.ttype ? "f16" : "f32") + "; this engine needs the f16 model file (convert.py --use-f16)");
+    return t;
+}
+const TensorRef * maybe(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0) {
+    auto it = m.find(name);
+    if (it == m.end()) return nullptr;
+    if (it->second.ne[0] != ne0 || it->second.ttype != ttype) throw std::runtime_error("tensor '" + name + "' has an unexpected shape/type");
+    return &it->second;
+}
+
+// ggml's GELU table: tanh approximation tabulated over every f16 input.
+// Written without fused multiply-adds (the file is built with -ffp-contract=off) so the table is the
+// same on every host compiler.
+float gelu_tanh_host(float x) {
+    const float a = 0.044715f, c = 0.79788456080286535587989211986876f;
+    const float x2 = x * x;
+    const float inner = 1.0f + a * x2;
+    const float arg = c * x * inner;
+    const float t = tanhf(arg);
+    return 0.5f * x * (1.0f + t);
+}
+
+}  // namespace
+
+bark_context::~bark_context() {
+    (void) hipSetDevice(device);
+    for (auto & g : gpt) {
+        if (g.decode_graph) (void) hipGraphExecDestroy(g.decode_graph);
+        if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
+    }
+    for (void * p : allocs) (void) hipFree(p);
+    if (weight_slab) (void) hipFree(weight_slab);
+    if (stream) (void) hipStreamDestroy(stream);
+}
+
+namespace barkhip {
+
+void engine_invalidate_graphs(bark_context * ctx) {
+    for (auto & g : ctx->gpt) {
+        if (g.decode_graph) { (void) hipGraphExecDestroy(g.decode_graph); g.decode_graph = nullptr; }
+        if (g.bench_graph) { (void) hipGraphExecDestroy(g.bench_graph); g.bench_graph = nullptr; }
+    }
+}
+
+// bark_load_model_from_file (bark.cpp:1080-1163): parse the container, upload every tensor of the hot path.
+bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        throw std::runtime_error("no HIP device available (this engine has no CPU path)");
+    std::unique_ptr<bark_context> ctx(new bark_context());
+    ctx->params = params;
+    ctx->rng = std::mt19937(seed);                       // bark.cpp:1179
+    if (const char * e = getenv("BARK_HIP_DEVICE")) ctx->device = atoi(e);
+    else (void) hipGetDevice(&ctx->device);
+    if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("BARK_HIP_DEVICE out of range");
+    HIP_OK(hipSetDevice(ctx->device));
+    if (const char * e = getenv("BARK_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
+    HIP_OK(hipStreamCreate(&ctx->stream));
+    init_kernel_attributes();
+
+    ModelFile mf;
+    std::string err;
+    if (!mf.open(path, err)) throw std::runtime_error(std::string("failed to read '") + path + "': " + err);
+    ctx->vocab.build(mf.vocab);
+
+    // ---- plan the slab -----------------------------------------------------------------------------
+    SlabPlan plan;
+    struct Fix { const void ** dst; size_t off; };
+    std::vector<Fix> fixes;
+    auto place = [&](const TensorRef & t, const void ** dst) { fixes.push_back({dst, plan.add(t)}); };
+
+    for (int g = 0; g < 3; g++) {
+        GptModel & m = ctx->gpt[g];
+        m.hp = mf.gpt[g].hp;
+        const auto & T = mf.gpt[g].tensors;
+        const int E = m.hp.n_embd;
+        if (E / m.hp.n_head != 64) throw std::runtime_error("head_dim must be 64");
+        if (E % 128 != 0 || E > 1024) throw std::runtime_error("n_embd must be a multiple of 128 and <= 1024");
+        if (m.hp.block_size != 1024) throw std::runtime_error("block_size must be 1024");
+        if (m.hp.n_wtes > 8 || m.hp.n_lm_heads > 8 || m.hp.n_layer > 64) throw std::runtime_error("unsupported GPT shape");
+        m.layers.resize((size_t) m.hp.n_layer);
+        for (int i = 0; i < m.hp.n_wtes; i++) place(need(T, "model/wte/" + std::to_string(i), 1, E, m.hp.n_in_vocab), (const void **) &m.wte[i]);
+        for (int i = 0; i < m.hp.n_lm_heads; i++) place(need(T, "model/lm_head/" + std::to_string(i), 1, E, m.hp.n_out_vocab), (const void **) &m.lm_head[i]);
+        place(need(T, "model/wpe", 0, E, m.hp.block_size), (const void **) &m.wpe);
+        place(need(T, "model/ln_f/g", 0, E, 0), (const void **) &m.lnf_g);
+        if (auto * t = maybe(T, "model/ln_f/b", 0, E)) place(*t, (const void **) &m.lnf_b);
+        for (int l = 0; l < m.hp.n_layer; l++) {
+            const std::string p = "model/h" + std::to_string(l);
+            GptModel::Layer & L = m.layers[(size_t) l];
+            place(need(T, p + "/ln_1/g", 0, E, 0), (const void **) &L.ln1_g);
+            place(need(T, p + "/ln_2/g", 0, E, 0), (const void **) &L.ln2_g);
+            if (auto * t = maybe(T, p + "/ln_1/b", 0, E)) place(*t, (const void **) &L.ln1_b);
+            if (auto * t = maybe(T, p + "/ln_2/b", 0, E)) place(*t, (const void **) &L.ln2_b);
+            place(need(T, p + "/attn/c_attn/w", 1, E, 3 * E), (const void **) &L.attn_w);
+            place(need(T, p + "/attn/c_proj/w", 1, E, E), (const void **) &L.proj_w);
+            place(need(T, p + "/mlp/c_fc/w", 1, E, 4 * E), (const void **) &L.fc_w);
+            place(need(T, p + "/mlp/c_proj/w", 1, 4 * E, E), (const void **) &L.mproj_w);
+            if (auto * t = maybe(T, p + "/attn/c_attn/b", 0, 3 * E)) place(*t, (const void **) &L.attn_b);
+            if (auto * t = maybe(T, p + "/attn/c_proj/b", 0, E)) place(*t, (const void **) &L.proj_b);
+            if (auto * t = maybe(T, p + "/mlp/c_fc/b", 0, 4 * E)) place(*t, (const void **) &L.fc_b);
+            if (auto * t = maybe(T, p + "/mlp/c_proj/b", 0, E)) place(*t, (const void **) &L.mproj_b);
+        }
+        ctx->max_E = std::max(ctx->max_E, E);
+        ctx->max_H = std::max(ctx->max_H, m.hp.n_head);
+    }
+    if (ctx->gpt[2].hp.n_wtes != 8 || ctx->gpt[2].hp.n_lm_heads < 6) throw std::runtime_error("fine model must have 8 embeddings and >= 6 heads");
+
+    // ---- codec -------------------------------------------------------------------------------------
+    CodecModel & cm = ctx->codec;
+    cm.hp = mf.codec_hp;
+    {
+        const auto & T = mf.codec;
+        auto conv = [&](const std::string & p, CodecModel::Conv & cv) {
+            const TensorRef & w = need(T, p + ".weight", 1, 0, 0);
+            cv.k = (int) w.ne[0]; cv.cin = (int) w.ne[1]; cv.cout = (int) w.ne[2];
+            place(w, (const void **) &cv.w);
+            const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
+            if (b.nelements() != cv.cout) throw std::runtime_error("codec bias size mismatch at " + p);
+            place(b, (const void **) &cv.b);
+        };
+        auto convt = [&](const std::string & p, CodecModel::ConvT & cv, int stride) {
+            const TensorRef & w = need(T, p + ".weight", 1, 0, 0);
+            cv.k = (int) w.ne[0]; cv.cout = (int) w.ne[1]; cv.cin = (int) w.ne[2]; cv.stride = stride;
+            place(w, (const void **) &cv.w);
+            const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
+            if (b.nelements() != cv.cout) throw std::runtime_error("codec bias size mismatch at " + p);
+            place(b, (const void **) &cv.b);
+        };
+        conv("decoder.model.0.conv.conv", cm.init);
+        cm.D = cm.init.cout;
+        if (cm.D % 128 != 0) throw std::runtime_error("codec LSTM width must be a multiple of 128");
+        for (int l = 0; l < 2; l++) {
+            const std::string s = std::to_string(l);
+            place(need(T, "decoder.model.1.lstm.weight_ih_l" + s, 1, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_ih);
+            place(need(T, "decoder.model.1.lstm.weight_hh_l" + s, 1, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_hh);
+            place(need(T, "decoder.model.1.lstm.bias_ih_l" + s, 0, 4 * cm.D, 0), (const void **) &cm.lstm[l].b_ih);
+            place(need(T, "decoder.model.1.lstm.bias_hh_l" + s, 0, 4 * cm.D, 0), (const void **) &cm.lstm[l].b_hh);
+        }
+        static const int ratios[4] = {8, 5, 4, 2};          // EnCodec 24 kHz upsampling ratios (modeling_encodec.py:329-340)
+        for (int i = 0; i < 4; i++) {
+            const int idx = 3 + 3 * i;
+            convt("decoder.model." + std::to_string(idx) + ".convtr.convtr", cm.blocks[i].up, ratios[i]);
+            conv("decoder.model." + std::to_string(idx + 1) + ".block.1.conv.conv", cm.blocks[i].c1);
+            conv("decoder.model." + std::to_string(idx + 1) + ".block.3.conv.conv", cm.blocks[i].c2);
+            conv("decoder.model." + std::to_string(idx + 1) + ".shortcut.conv.conv", cm.blocks[i].sc);
+        }
+        conv("decoder.model.15.conv.conv", cm.fin);
+        // codebooks are uploaded contiguously (separate allocation below)
+        while (T.count("quantizer.vq.layers." + std::to_string(cm.n_q) + "._codebook.embed")) cm.n_q++;
+        if (cm.n_q == 0) throw std::runtime_error("codec has no codebooks");
+    }
+
+    // ---- upload ------------------------------------------------------------------------------------
+    ctx->weight_bytes = plan.total;
+    HIP_OK(hipMalloc(&ctx->weight_slab, plan.total));
+    {
+        // stage through pinned memory in 32 MiB pieces (the mapping is pageable and possibly unaligned)
+        const size_t kStage = 32u << 20;
+        void * stage = nullptr;
+        HIP_OK(hipHostMalloc(&stage, kStage, hipHostMallocDefault));
+        for (const auto & it : plan.items) {
+            for (size_t done = 0; done < it.bytes; done += kStage) {
+                const size_t n = std::min(kStage, it.bytes - done);
+                memcpy(stage, it.src + done, n);
+                HIP_OK(hipMemcpy((uint8_t *) ctx->weight_slab + it.off + done, stage, n, hipMemcpyHostToDevice));
+            }
+        }
+        (void) hipHostFree(stage);
+    }
+    for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weight_slab + f.off;
+    {
+        const size_t per = (size_t) cm.hp.n_bins * cm.hp.hidden_dim;
+        float * cb = dev_alloc<float>(ctx.get(), per * cm.n_q);
+        for (int q = 0; q < cm.n_q; q++) {
+            const TensorRef & t = need(mf.codec, "quantizer.vq.layers." + std::to_string(q) + "._codebook.embed", 0, cm.hp.hidden_dim, cm.hp.n_bins);
+            HIP_OK(hipMemcpy(cb + per * q, t.data, per * 4, hipMemcpyHostToDevice));
+        }
+        cm.codebooks = cb;
+    }
+
+    // ---- KV caches, scratch ------------------------------------------------------------------------
+    const int P = ctx->P;
+    for (int g = 0; g < 2; g++) {
+        GptModel & m = ctx->gpt[g];
+        m.kv_layer_stride = (size_t) m.hp.n_embd * P;
+        m.kcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);     // bark.cpp:976-991
+        m.vcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);
+    }
+    {
+        GptModel & m = ctx->gpt[2];
+        m.kv_layer_stride = 0;
+        m.kcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
+        m.vcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
+    }
+    const size_t NE = (size_t) P * ctx->max_E;
+    ctx->x = dev_alloc<float>(ctx.get(), NE);
+    ctx->q = dev_alloc<float>(ctx.get(), NE);
+    ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
+    ctx->att = dev_alloc<half_t>(ctx.get(), NE);
+    ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
+    ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
+    size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
+    for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
+    ctx->logits = dev_alloc<float>(ctx.get(), n_logits);
+    ctx->d_tokens = dev_alloc<int32_t>(ctx.get(), 8 * 1024);
+    ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
+    ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
+    ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
+    {
+        std::vector<uint16_t> lut(65536);
+        for (uint32_t i = 0; i < 65536; i++) {
+            const uint16_t bits = (uint16_t) i;
+            const _Float16 h = __builtin_bit_cast(_Float16, bits);
+            const _Float16 r = (_Float16) gelu_tanh_host((float) h);
+            lut[i] = __builtin_bit_cast(uint16_t, r);
+        }
+        ctx->d_gelu_lut = dev_alloc<uint16_t>(ctx.get(), 65536);
+        HIP_OK(hipMemcpy(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice));
+    }
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, ctx->device));
+    char buf[512];
+    snprintf(buf, sizeof(buf), "bark-mi355x engine on %s (%s, %d CUs), weights %.1f MB, n_embd %d/%d/%d, layers %d/%d/%d, graph=%d",
+             prop.name, prop.gcnArchName, prop.multiProcessorCount, plan.total / 1e6, ctx->gpt[0].hp.n_embd, ctx->gpt[1].hp.n_embd,
+             ctx->gpt[2].hp.n_embd, ctx->gpt[0].hp.n_layer, ctx->gpt[1].hp.n_layer, ctx->gpt[2].hp.n_layer, (int) ctx->use_graph);
+    ctx->description = buf;
+    if (params.verbosity >= MEDIUM) fprintf(stderr, "%s\n", buf);
+    return ctx.release();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GPT building blocks
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride * (size_t) l; }
+float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
+
+// N > 1 rows through all layers (bark.cpp:1261-1389 causal, :1474-1562 fine); x holds the embeddings.
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal) {
+    const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
+    hipStream_t s = c->stream;
+    for (int l = 0; l < m.hp.n_layer; l++) {
+        const GptModel::Layer & L = m.layers[(size_t) l];
+        launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
+        LinArgs a;
+        a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0;
+        launch_linear(s, a);
+        AttnPrefillArgs at;
+        at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = 0;
+        at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E;
+        launch_attn_prefill(s, at);
+        LinArgs p;
+        p.W = L.proj_w; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        launch_linear(s, p);
+        launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
+        LinArgs f;
+        f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.bias = L.fc_b; f.epi = EPI_GELU; f.out_h = c->hbuf; f.lut = c->d_gelu_lut;
+        launch_linear(s, f);
+        LinArgs o;
+        o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        launch_linear(s, o);
+    }
+}
+
+// one token through all layers; position / token come from the device-resident StepState
+void run_layers_decode(bark_context * c, GptModel & m) {
+    const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
+    hipStream_t s = c->stream;
+    for (int l = 0; l < m.hp.n_layer; l++) {
+        const GptModel::Layer & L = m.layers[(size_t) l];
+        LinArgs a;
+        a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
+        a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
+        launch_linear(s, a);
+        AttnDecodeArgs at;
+        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att;
+        launch_attn_decode(s, at);
+        LinArgs p;
+        p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        launch_linear(s, p);
+        LinArgs f;
+        f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
+        f.epi = EPI_GELU; f.out_h = c->hbuf; f.lut = c->d_gelu_lut;
+        launch_linear(s, f);
+        LinArgs o;
+        o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = 1; o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        launch_linear(s, o);
+    }
+}
+
+// final LayerNorm + LM head on ONE row (bark.cpp:1391-1405): rows [row0, row0 + n_rows) of the head,
+// or the parity-selected codebook window of the coarse model.
+void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows) {
+    LinArgs a;
+    a.W = m.lm_head[0] + (size_t) row0 * m.hp.n_embd; a.M = n_rows; a.K = m.hp.n_embd; a.N = 1;
+    a.x_f32 = xrow; a.ln_g = m.lnf_g; a.ln_b = m.lnf_b; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.parity_rows = parity_rows; a.st = c->d_state;
+    launch_linear(c->stream, a);
+}
+
+void set_state(bark_context * c, const StepState & st) {
+    HIP_OK(hipMemcpyAsync(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));       // `st` is a stack object
+}
+StepState get_state(bark_context * c) {
+    StepState st;
+    HIP_OK(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return st;
+}
+StepState fresh_state() {
+    StepState st{};
+    st.eos_step = INT32_MAX;
+    return st;
+}
+
+void upload_tokens(bark_context * c, const int32_t * tok, size_t n) {
+    HIP_OK(hipMemcpyAsync(c->d_tokens, tok, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
+void check_ids(const int32_t * tok, size_t n, int n_in, const char * what) {
+    for (size_t i = 0; i < n; i++)
+        if (tok[i] < 0 || tok[i] >= n_in) throw std::runtime_error(std::string(what) + ": token id out of range");
+}
+
+// prompt rows -> x, all layers.  merge: the 513-id semantic prompt collapses to 257 rows (bark.cpp:1231-1248)
+int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge) {
+    const int N = merge ? n_tokens - 256 : n_tokens;
+    EmbedArgs e;
+    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.tokens = c->d_tokens; e.n_rows = N; e.merge = merge ? 1 : 0; e.pos0 = 0; e.x = c->x;
+    launch_embed_causal(c->stream, e);
+    run_layers_rows(c, m, N, true);
+    return N;
+}
+
+struct StageCfg {            // what differs between the semantic and the coarse decode step
+    int which; int mode; int lm_row0, lm_rows, parity_rows; int token_base; float min_eos_p; int eos_token;
+};
+StageCfg stage_cfg(bark_context * c, int which) {
+    const bark_context_params & p = c->params;
+    StageCfg s{};
+    s.which = which;
+    if (which == 0) {
+        // the reference samples over ALL n_out logits (bark.cpp:1682-1688)
+        s.mode = 0; s.lm_row0 = 0; s.lm_rows = c->gpt[0].hp.n_out_vocab; s.parity_rows = 0; s.token_base = 0;
+        s.min_eos_p = p.min_eos_p; s.eos_token = p.semantic_vocab_size;
+    } else {
+        // only the active codebook's window is sampled (bark.cpp:1829-1835) -> only its 1024 rows are evaluated
+        s.mode = 1; s.lm_row0 = p.semantic_vocab_size; s.lm_rows = p.codebook_size; s.parity_rows = p.codebook_size;
+        s.token_base = p.semantic_vocab_size; s.min_eos_p = 0.f; s.eos_token = -1;
+    }
+    return s;
+}
+
+void run_sample(bark_context * c, const StageCfg & s, int n_past_add) {
+    SampleArgs a;
+    a.logits = c->logits; a.n = s.lm_rows; a.mode = s.mode; a.min_eos_p = s.min_eos_p; a.eos_token = s.eos_token;
+    a.token_base = s.token_base; a.n_past_add = n_past_add; a.out_tokens = c->d_out_tokens;
+    a.eos_trace = s.mode == 0 ? c->d_eos_trace : nullptr; a.st = c->d_state;
+    launch_sample_greedy(c->stream, a);
+}
+
+// embed(state) -> layers -> LM head [-> greedy sample]
+void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add) {
+    GptModel & m = c->gpt[s.which];
+    EmbedArgs e;
+    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
+    launch_embed_causal(c->stream, e);
+    run_layers_decode(c, m);
+    run_lm_head(c, m, c->x, s.lm_row0, s.lm_rows, s.parity_rows);
+    if (sample) run_sample(c, s, n_past_add);
+}
+
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    try { enqueue_decode_step(c, s, true, n_past_add); }
+    catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+    HIP_OK(hipStreamEndCapture(c->stream, &graph));
+    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void) hipGraphDestroy(graph);
+    return exec;
+}
+
+void decode_step_greedy(bark_context * c, const StageCfg & s) {
+    GptModel & m = c->gpt[s.which];
+    if (c->use_graph) {
+        if (!m.decode_graph) m.decode_graph = capture_decode(c, s, 1);
+        HIP_OK(hipGraphLaunch(m.decode_graph, c->stream));
+        c->stats.graph_replays++;
+    } else {
+        enqueue_decode_step(c, s, true, 1);
+    }
+}
+
+// ---- host-side sampling (temp > 0, or settling a near tie): bark.cpp:184-270 -------------------------
+void softmax_host(std::vector<float> & l) {
+    float mx = -INFINITY;
+    for (float v : l) mx = std::max(mx, v);
+    float sum = 0.0f;
+    for (float & v : l) { v = (float) exp((double) (v - mx)); sum += v; }
+    for (float & v : l) v /= sum;
+}
+int sample_host(std::vector<float> & l, std::mt19937 & rng, float temp, float * eos_p) {
+    if (temp == 0.0f) {                                  // gpt_argmax_sample
+        for (float & v : l) v /= 0.7f;
+        softmax_host(l);
+        if (eos_p) *eos_p = l.back();
+        int best = 0; float mx = -INFINITY;
+        for (int i = 0; i < (int) l.size(); i++) if (l[(size_t) i] > mx) { mx = l[(size_t) i]; best = i; }
+        return best;
+    }
+    for (float & v : l) v /= temp;                       // gpt_multinomial_sample
+    softmax_host(l);
+    std::discrete_distribution<int32_t> dist(l.begin(), l.end());
+    const int next = dist(rng);
+    if (eos_p) *eos_p = l.back();
+    return next;
+}
+
+std::vector<float> fetch_logits(bark_context * c, size_t n) {
+    std::vector<float> l(n);
+    HIP_OK(hipMemcpyAsync(l.data(), c->logits, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return l;
+}
+
+void progress(bark_context * c, bark_encoding_step step, int pct) {
+    if (c->params.progress_callback) c->params.progress_callback(c, step, pct, c->params.progress_callback_user_data);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// test / binding hooks: one evaluation with full logits (bark_eval_encoder_internal, bark.cpp:1586-1643)
+// ---------------------------------------------------------------------------------------------------
+int engine_gpt_eval(bark_context * c, int which, const int32_t * tokens, int n_tokens, int n_past, bool merge_ctx, float * logits) {
+    if (which < 0 || which > 1) throw std::runtime_error("gpt_eval: which must be 0 or 1");
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    const bool merge = merge_ctx && n_past == 0;
+    if (n_tokens <= 0) throw std::runtime_error("gpt_eval: no tokens");
+    if (n_past > 0 && n_tokens != 1) throw std::runtime_error("gpt_eval: n_past > 0 needs exactly one token");   // bark.cpp:1227
+    if (merge && n_tokens != 513) throw std::runtime_error("gpt_eval: merged prompt must hold 513 ids");        // bark.cpp:1231
+    const int N = merge ? n_tokens - 256 : n_tokens;
+    if (n_past + N > m.hp.block_size) throw std::runtime_error("gpt_eval: context overflow");
+    check_ids(tokens, (size_t) n_tokens, m.hp.n_in_vocab, "gpt_eval");
+    const int n_out = m.hp.n_out_vocab;
+    if (N > 1) {
+        upload_tokens(c, tokens, (size_t) n_tokens);
+        run_prefill(c, m, n_tokens, merge);
+        StepState st = fresh_state();
+        set_state(c, st);
+        run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, 0, n_out, 0);
+    } else if (n_past == 0) {
+        // a single-token prompt: same kernels as a decode step at position 0
+        StepState st = fresh_state(); st.n_past = 0; st.cur_token = tokens[0];
+        set_state(c, st);
+        StageCfg s = stage_cfg(c, which); s.lm_row0 = 0; s.lm_rows = n_out; s.parity_rows = 0;
+        enqueue_decode_step(c, s, false, 1);
+    } else {
+        StepState st = fresh_state(); st.n_past = n_past; st.cur_token = tokens[0];
+        set_state(c, st);
+        StageCfg s = stage_cfg(c, which); s.lm_row0 = 0; s.lm_rows = n_out; s.parity_rows = 0;
+        enqueue_decode_step(c, s, false, 1);
+    }
+    HIP_OK(hipMemcpyAsync(logits, c->logits, (size_t) n_out * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return n_past + N;
+}
+
+namespace {
+// one fine forward (bark_build_fine_gpt_graph, bark.cpp:1416-1584): d_tokens holds [8][1024]; logits -> c->logits [1024][n_rows]
+void run_fine_forward(bark_context * c, int nn, int n_rows) {
+    GptModel & m = c->gpt[2];
+    const int E = m.hp.n_embd;
+    launch_embed_fine(c->stream, m.wte, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
+    run_layers_rows(c, m, 1024, false);
+    launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
+    LinArgs a;
+    a.W = m.lm_head[nn - 1]; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
+}
+}  // namespace
+
+void engine_fine_eval(bark_context * c, const int32_t * tokens_8x1024, int nn, float * logits) {
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[2];
+    if (nn < 1 || nn >= m.hp.n_wtes || nn - 1 >= m.hp.n_lm_heads) throw std::runtime_error("fine_eval: bad codebook index");
+    check_ids(tokens_8x1024, 8 * 1024, m.hp.n_in_vocab, "fine_eval");
+    upload_tokens(c, tokens_8x1024, 8 * 1024);
+    run_fine_forward(c, nn, m.hp.n_out_vocab);
+    HIP_OK(hipMemcpyAsync(logits, c->logits, (size_t) 1024 * m.hp.n_out_vocab * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// semantic stage: bark_eval_text_encoder (bark.cpp:1645-1701)
+// ---------------------------------------------------------------------------------------------------
+std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t> & prompt, std::vector<float> * eos_trace) {
+    HIP_OK(hipSetDevice(c->device));
+    const bark_context_params & p = c->params;
+    GptModel & m = c->gpt[0];
+    if (prompt.size() != 513) throw std::runtime_error("semantic: prompt must hold 513 ids");
+    check_ids(prompt.data(), prompt.size(), m.hp.n_in_vocab, "semantic");
+    // 257 prompt rows + one row per further step must fit the context (the reference would overrun it)
+    const int n_steps = std::max(0, std::min(p.n_steps_text_encoder, m.hp.block_size - 257 + 1));
+    const StageCfg s = stage_cfg(c, 0);
+    std::vector<int32_t> out;
+    if (n_steps == 0) return out;
+    upload_tokens(c, prompt.data(), prompt.size());
+    StepState st = fresh_state();
+    set_state(c, st);
+    const bool greedy = p.temp == 0.0f;
+    const int N = run_prefill(c, m, 513, true);
+    run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, s.lm_row0, s.lm_rows, 0);
+    if (greedy) {
+        run_sample(c, s, N);
+        progress(c, SEMANTIC, 100 * 1 / std::max(1, p.n_steps_text_encoder));
+        int issued = 1;
+        StepState cur{};
+        while (true) {
+            const int batch_end = std::min(n_steps, issued + 32);
+            for (; issued < batch_end; issued++) {
+                decode_step_greedy(c, s);
+                progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder));
+            }
+            cur = get_state(c);                                        // poll the stop rule every 32 steps
+            if (cur.eos_step != INT32_MAX || issued >= n_steps) break;
+        }
+        const int n_keep = std::min(cur.eos_step, issued);
+        out.resize((size_t) n_keep);
+        if (n_keep) HIP_OK(hipMemcpy(out.data(), c->d_out_tokens, (size_t) n_keep * 4, hipMemcpyDeviceToHost));
+        if (eos_trace) {
+            const int n_tr = std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
+            eos_trace->resize((size_t) n_tr);
+            if (n_tr) HIP_OK(hipMemcpy(eos_trace->data(), c->d_eos_trace, (size_t) n_tr * 4, hipMemcpyDeviceToHost));
+        }
+        c->stats.n_sample_semantic += std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
+        c->stats.n_near_tie += cur.near_tie;
+    } else {
+        int n_past = N;
+        for (int i = 0; i < n_steps; i++) {
+            if (i > 0) {
+                StepState h = fresh_state(); h.n_past = n_past; h.cur_token = out.back();
+                set_state(c, h);
+                enqueue_decode_step(c, s, false, 1);
+                n_past += 1;
+            }
+            std::vector<float> l = fetch_logits(c, (size_t) s.lm_rows);
+            float eos_p = 0.f;
+            const int next = sample_host(l, c->rng, p.temp, &eos_p);
+            c->stats.n_sample_semantic++;
+            if (eos_trace) eos_trace->push_back(eos_p);
+            progress(c, SEMANTIC, 100 * (i + 1) / std::max(1, p.n_steps_text_encoder));
+            if (next == p.semantic_vocab_size || eos_p >= p.min_eos_p) break;      // bark.cpp:1690
+            out.push_back(next);
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// coarse stage: bark_eval_coarse_encoder (bark.cpp:1745-1863)
+// ---------------------------------------------------------------------------------------------------
+std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> & semantic) {
+    HIP_OK(hipSetDevice(c->device));
+    const bark_context_params & p = c->params;
+    GptModel & m = c->gpt[1];
+    if (p.n_coarse_codebooks != 2 || p.codebook_size != 1024) throw std::runtime_error("coarse: only 2 codebooks of 1024 entries are supported");
+    if (p.sliding_window_size <= 0 || p.max_coarse_history < 0) throw std::runtime_error("coarse: bad window parameters");
+    check_ids(semantic.data(), semantic.size(), m.hp.n_in_vocab, "coarse");
+    const StageCfg s = stage_cfg(c, 1);
+    if (s.lm_row0 + 2 * s.lm_rows > m.hp.n_out_vocab) throw std::runtime_error("coarse: vocabulary too small");
+    const float stc_ratio = p.coarse_rate_hz / p.semantic_rate_hz * p.n_coarse_codebooks;                        // bark.cpp:1757
+    const int max_semantic_history = (int) floorf(p.max_coarse_history / stc_ratio);
+    const int n_steps = (int) (floorf(semantic.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);  // bark.cpp:1775-1779
+    if (n_steps <= 0) throw std::runtime_error("coarse: no steps to run");
+    const int n_windows = (int) ceilf((float) n_steps / p.sliding_window_size);
+    const bool greedy = p.temp == 0.0f;
+    std::vector<int32_t> out;            // offset ids, as fed back into the model
+    int step_idx = 0;
+    for (int w = 0; w < n_windows; w++) {
+        // window prompt (bark.cpp:1787-1807)
+        const int semantic_idx = (int) roundf(step_idx / stc_ratio);
+        std::vector<int32_t> in(semantic.begin() + std::max(semantic_idx - max_semantic_history, 0), semantic.end());
+        const size_t had = in.size();
+        in.resize(256);
+        for (size_t i = had; i < 256; i++) in[i] = p.coarse_semantic_pad_token;
+        in.push_back(p.coarse_infer_token);
+        const int nh = std::min(p.max_coarse_history, (int) out.size());
+        in.insert(in.end(), out.end() - nh, out.end());
+        const int N = (int) in.size();
+        const int steps_here = std::min(p.sliding_window_size, n_steps - step_idx);
+        if (N + steps_here - 1 > m.hp.block_size) throw std::runtime_error("coarse: window exceeds the context");
+        check_ids(in.data(), in.size(), m.hp.n_in_vocab, "coarse");
+        upload_tokens(c, in.data(), in.size());
+        StepState st = fresh_state(); st.step = step_idx;
+        set_state(c, st);
+        run_prefill(c, m, N, false);
+        if (greedy) {
+            run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, s.lm_row0, s.lm_rows, s.parity_rows);
+            run_sample(c, s, N);
+            progress(c, COARSE, 100 * (step_idx + 1) / n_steps);
+            for (int j = 1; j < steps_here; j++) {
+                decode_step_greedy(c, s);
+                progress(c, COARSE, 100 * (step_idx + j + 1) / n_steps);
+            }
+            const StepState cur = get_state(c);
+            std::vector<int32_t> got((size_t) steps_here);
+            HIP_OK(hipMemcpy(got.data(), c->d_out_tokens, (size_t) steps_here * 4, hipMemcpyDeviceToHost));
+            out.insert(out.end(), got.begin(), got.end());
+            step_idx += steps_here;
+            c->stats.n_sample_coarse += steps_here;
+            c->stats.n_near_tie += cur.near_tie;
+        } else {
+            int n_past = N;
+            for (int j = 0; j < steps_here; j++) {
+                const int parity = step_idx % 2;
+                if (j == 0) {
+                    run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, s.lm_row0 + parity * s.lm_rows, s.lm_rows, 0);
+                } else {
+                    StepState h = fresh_state(); h.n_past = n_past; h.cur_token = out.back(); h.step = step_idx;
+                    set_state(c, h);
+                    StageCfg s2 = s; s2.lm_row0 = s.lm_row0 + parity * s.lm_rows; s2.parity_rows = 0;
+                    enqueue_decode_step(c, s2, false, 1);
+                    n_past += 1;
+                }
+                std::vector<float> l = fetch_logits(c, (size_t) s.lm_rows);
+                int next = sample_host(l, c->rng, p.temp, nullptr);
+                next += s.lm_row0 + parity * s.lm_rows;
+                out.push_back(next);
+                step_idx += 1;
+                c->stats.n_sample_coarse++;
+                progress(c, COARSE, 100 * step_idx / n_steps);
+            }
+        }
+    }
+    // de-offset into [T][2] (bark.cpp:1851-1857)
+    std::vector<int32_t> res;
+    for (size_t i = 0; i + 1 < out.size(); i += 2) {
+        res.push_back(out[i] - p.semantic_vocab_size);
+        res.push_back(out[i + 1] - p.semantic_vocab_size - p.codebook_size);
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fine stage: bark_eval_fine_encoder (bark.cpp:1961-2059).  T > 1024 is rejected: the reference's
+// windowing is undefined there.
+// ---------------------------------------------------------------------------------------------------
+std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & coarse) {
+    HIP_OK(hipSetDevice(c->device));
+    const bark_context_params & p = c->params;
+    GptModel & m = c->gpt[2];
+    const int nc = p.n_coarse_codebooks, nf = p.n_fine_codebooks, cs = p.codebook_size;
+    if (nc != 2 || nf != 8 || cs != 1024) throw std::runtime_error("fine: only 2 -> 8 codebooks of 1024 entries are supported");
+    const int T = (int) coarse.size() / nc;
+    if (T <= 0 || T > 1024) throw std::runtime_error("fine: number of frames must be in 1..1024");
+    for (int32_t v : coarse) if (v < 0 || v >= cs) throw std::runtime_error("fine: coarse code out of range");
+    // codebook-major window [8][1024]: coarse rows, channels 2..7 and the time padding filled with `cs` (bark.cpp:1983-2013)
+    std::vector<int32_t> buf((size_t) 8 * 1024, cs);
+    for (int t = 0; t < T; t++) for (int ch = 0; ch < nc; ch++) buf[(size_t) ch * 1024 + t] = coarse[(size_t) t * nc + ch];
+    upload_tokens(c, buf.data(), buf.size());
+    const bool greedy = p.fine_temp == 0.0f;
+    StepState st = fresh_state();
+    set_state(c, st);
+    // one window (T <= 1024  =>  n_loops == 1, start_idx == 0, rel_start_fill_idx == 0)
+    for (int nn = nc; nn < nf; nn++) {
+        progress(c, FINE, 100 * (nn - nc + 1) / (nf - nc));
+        if (greedy) {
+            run_fine_forward(c, nn, cs);                   // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
+            launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, c->d_tokens + (size_t) nn * 1024, 1, c->d_state);
+        } else {
+            const int n_out = m.hp.n_out_vocab;
+            run_fine_forward(c, nn, n_out);
+            std::vector<float> l = fetch_logits(c, (size_t) 1024 * n_out);
+            std::vector<int32_t> ch(1024);
+            for (int i = 0; i < 1024; i++) {
+                std::vector<float> rel(l.begin() + (size_t) i * n_out, l.begin() + (size_t) i * n_out + cs);
+                ch[(size_t) i] = sample_host(rel, c->rng, p.fine_temp, nullptr);
+            }
+            HIP_OK(hipMemcpyAsync(c->d_tokens + (size_t) nn * 1024, ch.data(), 1024 * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+        }
+        c->stats.n_sample_fine += 1024;
+    }
+    HIP_OK(hipMemcpyAsync(buf.data(), c->d_tokens, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    const StepState cur = get_state(c);
+    c->stats.n_near_tie += cur.near_tie;
+    std::vector<int32_t> res((size_t) T * 8);
+    for (int t = 0; t < T; t++) for (int ch = 0; ch < 8; ch++) res[(size_t) t * 8 + ch] = buf[(size_t) ch * 1024 + t];
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// EnCodec decode (encodec_decompress_audio call site, bark.cpp:2143-2167)
+// ---------------------------------------------------------------------------------------------------
+std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, int n_q, int T) {
+    HIP_OK(hipSetDevice(c->device));
+    CodecModel & cm = c->codec;
+    if (n_q <= 0 || n_q > cm.n_q || T <= 0 || T > 4096) throw std::runtime_error("codec: bad code matrix shape");
+    for (size_t i = 0; i < (size_t) n_q * T; i++) if (codes[i] < 0 || codes[i] >= cm.hp.n_bins) throw std::runtime_error("codec: code out of range");
+    hipStream_t s = c->stream;
+    const int D = cm.D;
+    int hop = 1; for (auto & b : cm.blocks) hop *= b.up.stride;
+    // largest activation: channels x time at every stage
+    size_t need = (size_t) std::max(cm.hp.hidden_dim, D) * T;
+    { int ch = D, tt = T; for (auto & b : cm.blocks) { ch = b.up.cout; tt *= b.up.stride; need = std::max(need, (size_t) ch * tt); } }
+    if (need > c->cbuf_elems) {
+        for (auto & b : c->cbuf) b = dev_alloc<float>(c, need);
+        c->cbuf_h = dev_alloc<half_t>(c, need);
+        c->cbuf_elems = need;
+    }
+    if ((size_t) T > c->c_T) {
+        c->c_gi = dev_alloc<float>(c, (size_t) T * 4 * D);
+        c->c_cell = dev_alloc<float>(c, (size_t) D);
+        c->c_hseq_h = dev_alloc<half_t>(c, (size_t) T * D);
+        c->c_xt_h = dev_alloc<half_t>(c, (size_t) T * D);
+        c->c_T = (size_t) T;
+    }
+    if ((size_t) n_q * T > c->d_codes_elems) { c->d_codes = dev_alloc<int32_t>(c, (size_t) n_q * T); c->d_codes_elems = (size_t) n_q * T; }
+    HIP_OK(hipMemcpyAsync(c->d_codes, codes, (size_t) n_q * T * 4, hipMemcpyHostToDevice, s));
+    float * A = c->cbuf[0], * B = c->cbuf[1], * R = c->cbuf[2];
+    half_t * Hh = c->cbuf_h;
+
+    auto conv = [&](const CodecModel::Conv & cv, const float * in, bool elu, int Tc, const float * add, float * out) {
+        launch_act_round(s, in, (size_t) cv.cin * Tc, elu ? 1 : 0, Hh);
+        launch_conv1d(s, cv.w, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
+    };
+    // RVQ de-embedding, first conv
+    launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, T, A);
+    conv(cm.init, A, false, T, nullptr, B);                            // B = x [D][T]
+    // 2-layer LSTM + skip (modeling_encodec.py:236-249)
+    const float * lin = B;
+    for (int l = 0; l < 2; l++) {
+        const half_t * seq_h;
+        if (l == 0) { launch_transpose_round(s, lin, D, T, c->c_xt_h); seq_h = c->c_xt_h; }
+        else { HIP_OK(hipMemcpyAsync(c->c_xt_h, c->c_hseq_h, (size_t) T * D * sizeof(half_t), hipMemcpyDeviceToDevice, s)); seq_h = c->c_xt_h; }
+        LinArgs g;
+        g.W = cm.lstm[l].w_ih; g.M = 4 * D; g.K = D; g.N = T; g.x_f16 = seq_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
+        launch_linear(s, g);
+        HIP_OK(hipMemsetAsync(c->c_cell, 0, (size_t) D * 4, s));
+        float * hseq = (l == 0) ? A : R;                                // layer outputs [D][T]
+        for (int t = 0; t < T; t++) {
+            LstmStepArgs a;
+            a.w_hh = cm.lstm[l].w_hh; a.b_ih = cm.lstm[l].b_ih; a.b_hh = cm.lstm[l].b_hh; a.gi = c->c_gi + (size_t) t * 4 * D;
+            a.hprev_h = t ? c->c_hseq_h + (size_t) (t - 1) * D : nullptr; a.c = c->c_cell; a.hout_h = c->c_hseq_h + (size_t) t * D;
+            a.hseq = hseq; a.T = T; a.t = t; a.D = D;
+            launch_lstm_step(s, a);
+        }
+    }
+    launch_add(s, R, B, (size_t) D * T, A);                            // y + x ; A = x
+    float * cur = A, * other = B;
+    int Tc = T;
+    for (int b = 0; b < 4; b++) {
+        const CodecModel::Block & bl = cm.blocks[b];
+        launch_act_round(s, cur, (size_t) bl.up.cin * Tc, 1, Hh);
+        launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
+        Tc *= bl.up.stride;
+        std::swap(cur, other);                                          // cur = upsampled x
+        // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)
+        conv(bl.c1, cur, true, Tc, nullptr, R);
+        conv(bl.c2, R, true, Tc, nullptr, other);                       // other = r
+        conv(bl.sc, cur, false, Tc, other, R);                          // R = shortcut(x) + r
+        std::swap(cur, R);
+        // keep three distinct buffers: cur (result), other, R (old x)
+    }
+    conv(cm.fin, cur, true, Tc, nullptr, other);
+    std::vector<float> pcm((size_t) Tc);
+    HIP_OK(hipMemcpyAsync(pcm.data(), other, (size_t) Tc * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    (void) hop;
+    return pcm;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bark_generate_audio (bark.cpp:2125-2172)
+// ---------------------------------------------------------------------------------------------------
+bool engine_generate(bark_context * c, const char * text) {
+    HIP_OK(hipSetDevice(c->device));
+    const int64_t t0 = now_us();
+    const int64_t t_load = c->stats.t_load_us;
+    c->stats = bark_hip_stats{};
+    c->stats.t_load_us = t_load;
+    c->audio.clear(); c->semantic_tokens.clear(); c->coarse_tokens.clear(); c->fine_tokens.clear();
+    PromptParams pp;
+    pp.block_size = c->gpt[0].hp.block_size; pp.text_encoding_offset = c->params.text_encoding_offset; pp.text_pad_token = c->params.text_pad_token;
+    pp.semantic_pad_token = c->params.semantic_pad_token; pp.semantic_infer_token = c->params.semantic_infer_token;
+    c->tokens = build_semantic_prompt(c->vocab, pp, text, true);
+    if (c->params.verbosity >= MEDIUM) {
+        fprintf(stderr, "bark_tokenize_input: prompt: '%s'\nbark_tokenize_input: number of tokens in prompt = %zu, first 8 tokens:", text, c->tokens.size());
+        for (int i = 0; i < 8 && i < (int) c->tokens.size(); i++) fprintf(stderr, " %d", c->tokens[(size_t) i]);
+        fprintf(stderr, "\n");
+    }
+    int64_t t = now_us();
+    c->semantic_tokens = engine_semantic(c, c->tokens, nullptr);
+    c->stats.t_semantic_us = now_us() - t;
+    c->stats.n_semantic = (int32_t) c->semantic_tokens.size();
+    if (c->semantic_tokens.empty()) { fprintf(stderr, "bark_generate_audio: the semantic stage produced no tokens\n"); return false; }
+    t = now_us();
+    c->coarse_tokens = engine_coarse(c, c->semantic_tokens);
+    c->stats.t_coarse_us = now_us() - t;
+    t = now_us();
+    c->fine_tokens = engine_fine(c, c->coarse_tokens);
+    c->stats.t_fine_us = now_us() - t;
+    const int T = (int) c->fine_tokens.size() / 8;
+    c->stats.n_frames = T;
+    std::vector<int32_t> codes((size_t) 8 * T);
+    for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) codes[(size_t) ch * T + i] = c->fine_tokens[(size_t) i * 8 + ch];   // bark.cpp:2153-2159
+    t = now_us();
+    c->audio = engine_codec_decode(c, codes.data(), 8, T);
+    c->stats.t_codec_us = now_us() - t;
+    c->stats.n_samples = (int32_t) c->audio.size();
+    c->stats.t_eval_us = now_us() - t0;
+    if (c->params.verbosity >= MEDIUM) {
+        auto line = [](const char * name, int64_t n, int64_t us) {
+            fprintf(stderr, "%s: %8.2f ms / %lld samples (%.3f ms per sample)\n", name, us / 1000.0, (long long) n, n ? us / 1000.0 / n : 0.0);
+        };
+        line("semantic", c->stats.n_sample_semantic, c->stats.t_semantic_us);
+        line("coarse  ", c->stats.n_sample_coarse, c->stats.t_coarse_us);
+        line("fine    ", c->stats.n_sample_fine, c->stats.t_fine_us);
+        fprintf(stderr, "codec   : %8.2f ms / %d frames ; total %8.2f ms for %.2f s of audio\n", c->stats.t_codec_us / 1000.0, T,
+                c->stats.t_eval_us / 1000.0, c->audio.size() / (double) c->params.sample_rate);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// timing hooks for bench.py (hipEvents on the engine's own stream)
+// ---------------------------------------------------------------------------------------------------
+double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iters, double * bytes_per_step) {
+    if (which < 0 || which > 1) throw std::runtime_error("time_decode_step: which must be 0 or 1");
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    ctxlen = std::max(1, std::min(ctxlen, m.hp.block_size));
+    const StageCfg s = stage_cfg(c, which);
+    StepState st = fresh_state(); st.n_past = ctxlen - 1; st.cur_token = 1;
+    set_state(c, st);
+    // the cache rows below ctxlen hold whatever the last run left; timing does not depend on the values,
+    // but keep them finite: zero them once
+    HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    if (!m.bench_graph) m.bench_graph = capture_decode(c, s, 0);       // n_past does not advance
+    for (int i = 0; i < 3; i++) HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
+    set_state(c, st);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) {
+        HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
+        if ((i & 1023) == 1023) set_state(c, st);                        // out_tokens holds 2048 entries
+    }
+    HIP_OK(hipEventRecord(e1, c->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (bytes_per_step) {
+        const double E = m.hp.n_embd, L = m.hp.n_layer;
+        // f16 weights of all layers + evaluated LM-head rows + f32 K and V rows read
+        *bytes_per_step = L * 12.0 * E * E * 2.0 + (double) s.lm_rows * E * 2.0 + 2.0 * ctxlen * E * L * 4.0;
+    }
+    return (double) ms * 1000.0 / std::max(1, iters);
+}
+
+double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pass) {
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[2];
+    std::vector<int32_t> buf((size_t) 8 * 1024);
+    for (size_t i = 0; i < buf.size(); i++) buf[i] = (int32_t) ((i * 2654435761u) >> 22) & 1023;
+    upload_tokens(c, buf.data(), buf.size());
+    run_fine_forward(c, 4, 1024);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) run_fine_forward(c, 2 + i % 6, 1024);
+    HIP_OK(hipEventRecord(e1, c->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (flops_per_pass) {
+        const double E = m.hp.n_embd, L = m.hp.n_layer, N = 1024;
+        *flops_per_pass = 2.0 * N * (L * 12.0 * E * E + 1024.0 * E) + 4.0 * N * N * E * L;
+    }
+    return (double) ms * 1000.0 / std::max(1, iters);
+}
+
+}  // namespace barkhip

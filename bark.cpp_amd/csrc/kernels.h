@@ -1,0 +1,129 @@
+// kernels.h - launch interface of the HIP kernels (kernels.hip, codec_kernels.hip).
+//
+// Numerics contract ("canonical numerics"): every kernel reproduces, with IEEE fp32
+// fma/add and the summation orders C1/C2/C5, exactly what the CPU oracle computes, so that greedy
+// token ids are bit-identical.  All code is built with -ffp-contract=off; fused multiply-adds are
+// written explicitly (fmaf / MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace barkhip {
+
+typedef _Float16 half_t;
+
+// Device-resident state of one autoregressive stage; kernels read/advance it so that a captured
+// hipGraph of one decode step can be replayed without host-side parameter updates.
+struct StepState {
+    int32_t n_past;        // rows already in the KV cache == position of the next token
+    int32_t cur_token;     // token embedded by the next decode step
+    int32_t step;          // stage step counter (coarse: parity selects the logit slice)
+    int32_t eos_step;      // first step whose sample met the stop rule (INT32_MAX if none)
+    int32_t near_tie;      // samples whose runner-up was within kNearTie of the winner
+    int32_t n_out;         // sampled ids written to out_tokens so far
+    float   last_eos_p;
+    float   pad1;
+};
+
+enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
+
+// One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
+struct LinArgs {
+    const half_t * W = nullptr; int M = 0, K = 0;     // [M][K] f16, row-major ([out][in])
+    int N = 1;
+    // input rows: either f16 [N][K] ...
+    const half_t * x_f16 = nullptr;
+    // ... or (decode GEMV only) one f32 row normalised in the kernel prologue (LayerNorm fused)
+    const float * x_f32 = nullptr; const float * ln_g = nullptr; const float * ln_b = nullptr;
+    const float * bias = nullptr;
+    int epi = EPI_LOGITS;
+    // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
+    float * q = nullptr; float * kc = nullptr; float * vc = nullptr; int E = 0, P = 0; int pos0 = 0;
+    const StepState * st = nullptr;
+    // EPI_RESID: res[n][m] = (dot + bias) + res[n][m]
+    float * res = nullptr;
+    // EPI_GELU: out_h[n][m] = f16(gelu_lut(dot + bias))
+    half_t * out_h = nullptr; const uint16_t * lut = nullptr;
+    // EPI_LOGITS: out[n*ld_out + m] = dot (+ bias)
+    float * out = nullptr; int ld_out = 0;
+    // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
+    // the row window starts at parity_rows * (st->step & 1) rows into W (and bias)
+    int parity_rows = 0;
+};
+void launch_linear(hipStream_t s, const LinArgs & a);
+
+// x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
+struct EmbedArgs {
+    const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024;
+    const int32_t * tokens = nullptr;      // n_tokens ids (prefill) - ignored when st != nullptr
+    int n_rows = 1; int merge = 0;         // merge: 513 ids -> 257 rows
+    int pos0 = 0;
+    const StepState * st = nullptr;        // decode: token = st->cur_token, pos = st->n_past
+    float * x = nullptr;
+};
+void launch_embed_causal(hipStream_t s, const EmbedArgs & a);
+// fine: x[i] = sum_{c<=nn} wte_c[tok[c][i]] + wpe[i]                   (bark.cpp:1450-1472)
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const float * wpe, int E, int n_in,
+                       const int32_t * tokens_8x1024, int nn, float * x);
+
+void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
+
+// Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.
+struct AttnDecodeArgs {
+    const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
+    int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
+};
+void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
+
+// Multi-query attention (prefill / fine): N queries at positions n_past.., keys 0..n_past+N-1.
+struct AttnPrefillArgs {
+    const float * q = nullptr; int ldq = 0; const float * kc = nullptr; const float * vc = nullptr;
+    int H = 0, P = 0, N = 0, n_past = 0; int causal = 1;
+    float * scores = nullptr;              // scratch [H][N][P]
+    half_t * att = nullptr; int ld_att = 0;
+};
+void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
+
+// Greedy pick (gpt_argmax_sample, bark.cpp:223-247) over logits[0..n); advances *st.
+struct SampleArgs {
+    const float * logits = nullptr; int n = 0;
+    int mode = 0;                          // 0 semantic (stop rule on eos token / eos_p), 1 coarse
+    float min_eos_p = 0.2f; int eos_token = 10000;
+    int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
+    int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
+    int32_t * out_tokens = nullptr; float * eos_trace = nullptr; StepState * st = nullptr;
+};
+void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
+// fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]
+void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
+                        int out_stride, StepState * st);
+
+void init_kernel_attributes();
+
+// ---- EnCodec decoder (codec_kernels.hip) ---------------------------------------------------------
+// Activations are channel-major [C][T] f32; every conv / LSTM matmul consumes them rounded to f16
+// (ggml im2col / mul_mat) and accumulates in f32 as ONE fmaf chain in
+// (ci, k) order, bias added last - the order the oracle uses.
+void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, float * z);
+// out_h = f16(elu ? ELU(x) : x), n elements
+void launch_act_round(hipStream_t s, const float * x, size_t n, int elu, half_t * out_h);
+// causal stride-1 conv with reflect padding on the left (k-1): y[co][t] = b[co] + chain(w[co][ci][k] * xh[ci][t+k-(K-1)]) (+ add[co][t])
+void launch_conv1d(hipStream_t s, const half_t * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
+                   const float * add, float * y);
+// causal transposed conv, stride s, output trimmed to T*s: y[co][to] = b[co] + chain over (ci, t) of w[ci][co][to - t*s] * xh[ci][t]
+void launch_convtr1d(hipStream_t s, const half_t * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
+                     int T, float * y);
+// xt[t][c] = f16(x[c][t])
+void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt);
+// one LSTM time step for all D units (PyTorch gate order i,f,g,o); hprev_h: f16 h_{t-1} [D] or nullptr at t = 0
+struct LstmStepArgs {
+    const half_t * w_hh = nullptr; const float * b_ih = nullptr; const float * b_hh = nullptr;
+    const float * gi = nullptr;          // W_ih x_t for this t: [4D]
+    const half_t * hprev_h = nullptr; float * c = nullptr;   // cell state [D], updated in place
+    half_t * hout_h = nullptr;           // f16(h_t) [D]  (row t of the time-major sequence)
+    float * hseq = nullptr; int T = 0, t = 0; int D = 0;     // hseq[d*T + t] = h_t
+};
+void launch_lstm_step(hipStream_t s, const LstmStepArgs & a);
+void launch_add(hipStream_t s, const float * a, const float * b, size_t n, float * out);
+
+}  // namespace barkhip

@@ -1,0 +1,630 @@
+// kernels.hip - GPT kernels of the MI355X-native Bark engine (gfx950 / CDNA4, wave64).
+//
+// Every kernel follows the canonical numerics of DESIGN.md (orders C1/C2/C5, explicit fmaf, double
+// accumulated LayerNorm / softmax sums, f16 rounding points of ggml's CPU backend) so that the CPU
+// oracle reproduces its results bit for bit.  Built with -ffp-contract=off.
+//
+//   decode (N = 1)      : gemv_kernel (16 lanes per output row = the 16 chains of C1, coalesced
+//                         16-byte weight loads, LayerNorm fused as prologue, bias / residual /
+//                         GELU-LUT / KV-append fused as epilogue), attn_decode_kernel (one
+//                         workgroup per head, thread per key for C2, wave per chain for C5).
+//   prefill / fine (N>1): gemm_kernel (v_mfma_f32_32x32x2_f32: exact f32 fma chains; the 16 chains
+//                         of C1 live in 8 waves x 2 accumulator sets and meet in LDS),
+//                         attn_qk_kernel / softmax_rows_kernel / attn_pv_kernel.
+#include "kernels.h"
+
+#include <cfloat>
+#include <cstdio>
+
+namespace barkhip {
+
+typedef float  floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float wave_xor_add16(float v) {       // C1/C5 tree over 16 adjacent lanes: xor 1, 2, 4, 8
+    v = v + __shfl_xor(v, 1, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 4, 64);
+    v = v + __shfl_xor(v, 8, 64);
+    return v;
+}
+DEVINL double group16_sum(double v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+DEVINL double wave_sum(double v) {
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+DEVINL float wave_max(float v) {
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+DEVINL half8 ld_half8(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
+
+// ggml_gelu on the CPU backend: f16 lookup table, pass-through outside (-10, 10)
+DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
+    if (v <= -10.0f) return (half_t) 0.0f;
+    if (v >= 10.0f) return (half_t) v;
+    const half_t hv = (half_t) v;                         // round to nearest even
+    const uint16_t bits = __builtin_bit_cast(uint16_t, hv);
+    return __builtin_bit_cast(half_t, lut[bits]);
+}
+
+// K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
+DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
+DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
+
+DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_off) {
+    float v = dot;
+    if (a.bias) v = v + a.bias[row_off + m];
+    switch (a.epi) {
+        case EPI_QKV: {
+            const int E = a.E;
+            if (m < E) { a.q[(size_t) n * E + m] = v; break; }
+            const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
+            const int mm = m < 2 * E ? m - E : m - 2 * E;
+            const int h = mm >> 6, d = mm & 63;
+            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else a.vc[vc_index(h, d, pos, a.P)] = v;
+            break;
+        }
+        case EPI_RESID: { float * r = a.res + (size_t) n * a.M + m; *r = v + *r; break; }       // cur + inpL (bark.cpp:1352,1388)
+        case EPI_GELU:  a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v, a.lut); break;
+        default:        a.out[(size_t) n * a.ld_out + m] = v; break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode GEMV.  One wave = 4 output rows x 16 lanes; lane c of a row owns chain c of C1, i.e. the
+// 16-byte chunks c, c+16, c+32, ... of that weight row: the wave's loads are four fully used
+// 256-byte row segments per instruction.  x is either an f16 vector or (LN = true) an f32 row that
+// every 16-lane group normalises redundantly in registers (no LDS, no barrier).
+// ------------------------------------------------------------------------------------------------
+template <bool LN>
+__global__ __launch_bounds__(256) void gemv_kernel(const LinArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = (blockIdx.x * 4 + wave) * 4 + rg;
+    const int K = a.K, nblk = K >> 7;                      // K is a multiple of 128
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;                              // whole 16-lane groups are live or dead together
+    const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    float acc = 0.0f;
+
+    if (LN) {
+        constexpr int MAXB = 8;                             // n_embd <= 1024
+        half8 wv[MAXB];
+        #pragma unroll
+        for (int b = 0; b < MAXB; b++) if (b < nblk) wv[b] = ld_half8(wrow + (b << 7));   // weights first: longest latency
+        // ggml_norm (+mul, +add): double sums, eps on the variance (bark.cpp:1265-1274)
+        float xr[MAXB][8];
+        double s1 = 0.0;
+        #pragma unroll
+        for (int b = 0; b < MAXB; b++) if (b < nblk) {
+            const float4 * p = reinterpret_cast<const float4 *>(a.x_f32 + ((b * 16 + c) << 3));
+            const float4 u = p[0], w = p[1];
+            xr[b][0] = u.x; xr[b][1] = u.y; xr[b][2] = u.z; xr[b][3] = u.w; xr[b][4] = w.x; xr[b][5] = w.y; xr[b][6] = w.z; xr[b][7] = w.w;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) s1 += (double) xr[b][e];
+        }
+        s1 = group16_sum(s1);
+        const float mean = (float) (s1 / (double) K);
+        double s2 = 0.0;
+        #pragma unroll
+        for (int b = 0; b < MAXB; b++) if (b < nblk) {
+            #pragma unroll
+            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; s2 += (double) (v * v); }
+        }
+        s2 = group16_sum(s2);
+        const float var = (float) (s2 / (double) K);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int b = 0; b < MAXB; b++) if (b < nblk) {
+            const int k0 = (b * 16 + c) << 3;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float v = xr[b][e] * scale;
+                v = v * a.ln_g[k0 + e];
+                if (a.ln_b) v = v + a.ln_b[k0 + e];
+                // mul_mat converts the activation to f16 first
+                acc = fmaf((float) wv[b][e], (float) (half_t) v, acc);
+            }
+        }
+    } else {
+        const half_t * xrow = a.x_f16 + (c << 3);
+        for (int b0 = 0; b0 < nblk; b0 += 8) {
+            half8 wv[8], xv[8];
+            #pragma unroll
+            for (int i = 0; i < 8; i++) if (b0 + i < nblk) { wv[i] = ld_half8(wrow + ((b0 + i) << 7)); xv[i] = ld_half8(xrow + ((b0 + i) << 7)); }
+            #pragma unroll
+            for (int i = 0; i < 8; i++) if (b0 + i < nblk) {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
+            }
+        }
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue(a, 0, m, acc, row_off);
+}
+
+// Same operator for several input rows at once (N small, or as a cross-check of gemm_kernel):
+// grid.y indexes the input row; no LayerNorm prologue.
+template <int MAXB>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const LinArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = (blockIdx.x * 4 + wave) * 4 + rg;
+    const int n = blockIdx.y;
+    const int K = a.K, nblk = K >> 7;
+    if (m >= a.M) return;
+    const half_t * wrow = a.W + (size_t) m * K + (c << 3);
+    const half_t * xrow = a.x_f16 + (size_t) n * K + (c << 3);
+    float acc = 0.0f;
+    #pragma unroll 4
+    for (int b = 0; b < nblk; b++) {
+        const half8 wv = ld_half8(wrow + (b << 7)), xv = ld_half8(xrow + (b << 7));
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[e], (float) xv[e], acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (c == 0) linear_epilogue(a, n, m, acc, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact GEMM on the f32 matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain
+// (cdna_hip_programming.md section 3), so one accumulator register == one chain of C1.
+// Workgroup: 8 waves, output tile 64 (rows n) x 64 (cols m).  Wave w owns chains 2w and 2w+1 for the
+// whole tile (2 x 2 MFMA tiles x 2 chains = 8 accumulators); per 128-element K block it loads one
+// 16-byte chunk per operand row and chain and issues 4 MFMAs (k pairs) per tile.  The 16 chains meet
+// in LDS and are added in the C1 tree order.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEMM_TM = 64, GEMM_TN = 64;
+__global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * GEMM_TN, m0 = blockIdx.x * GEMM_TM;
+    const int K = a.K, nblk = K >> 7;
+    int nrow[2], mrow[2];
+    #pragma unroll
+    for (int t = 0; t < 2; t++) {
+        nrow[t] = min(n0 + t * 32 + l31, a.N - 1);
+        mrow[t] = min(m0 + t * 32 + l31, a.M - 1);
+    }
+    floatx16 acc[2][2][2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++)
+        for (int r = 0; r < 16; r++) acc[s][i][j][r] = 0.0f;
+
+    for (int b = 0; b < nblk; b++) {
+        #pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int koff = ((b * 16 + 2 * w + s) << 3);
+            half8 xa[2], wb[2];
+            #pragma unroll
+            for (int t = 0; t < 2; t++) {
+                xa[t] = ld_half8(a.x_f16 + (size_t) nrow[t] * K + koff);
+                wb[t] = ld_half8(a.W + (size_t) mrow[t] * K + koff);
+            }
+            #pragma unroll
+            for (int kp = 0; kp < 4; kp++) {
+                float av[2], bv[2];
+                #pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    av[t] = half ? (float) xa[t][2 * kp + 1] : (float) xa[t][2 * kp];
+                    bv[t] = half ? (float) wb[t][2 * kp + 1] : (float) wb[t][2 * kp];
+                }
+                #pragma unroll
+                for (int i = 0; i < 2; i++)
+                    #pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[s][i][j], 0, 0, 0);
+            }
+        }
+    }
+    // chain pair (2w, 2w+1) -> LDS; accumulator register r of lane l holds row (r&3)+8(r>>2)+4*half, col l31
+    float * mine = lds + (size_t) w * (GEMM_TN * GEMM_TM);
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+        #pragma unroll
+        for (int j = 0; j < 2; j++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, col = j * 32 + l31;
+                mine[row * GEMM_TM + col] = acc[0][i][j][r] + acc[1][i][j][r];
+            }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < GEMM_TN * GEMM_TM; idx += 512) {
+        const int row = idx >> 6, col = idx & 63;
+        const int n = n0 + row, m = m0 + col;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = lds[q * (GEMM_TN * GEMM_TM) + idx];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (n < a.N && m < a.M) linear_epilogue(a, n, m, v, 0);
+    }
+}
+
+void launch_linear(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
+    const int nblk = a.K >> 7;
+    if (a.N == 1) {
+        dim3 grid((a.M + 15) / 16), block(256);
+        if (a.x_f32) {
+            if (nblk <= 8) hipLaunchKernelGGL((gemv_kernel<true>), grid, block, 0, s, a);
+            else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
+        } else {
+            hipLaunchKernelGGL((gemv_kernel<false>), grid, block, 0, s, a);
+        }
+        return;
+    }
+    if (a.x_f32 || a.parity_rows) { fprintf(stderr, "bark-hip: batched linear op needs f16 rows\n"); abort(); }
+    static const bool force_rows = getenv("BARK_HIP_GEMM_ROWS") != nullptr;      // cross-check path
+    if (force_rows) {
+        dim3 grid((a.M + 15) / 16, a.N), block(256);
+        hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
+        return;
+    }
+    dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);
+    hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_causal_kernel(const EmbedArgs a) {
+    const int i = blockIdx.x;
+    int tok, tok2 = -1, pos;
+    if (a.st) { tok = a.st->cur_token; pos = min(a.st->n_past, a.P - 1); }
+    else {
+        pos = a.pos0 + i;
+        if (a.merge) { if (i < 256) { tok = a.tokens[i]; tok2 = a.tokens[256 + i]; } else tok = a.tokens[512]; }
+        else tok = a.tokens[i];
+    }
+    tok = min(max(tok, 0), a.n_in - 1);
+    if (tok2 >= 0) tok2 = min(tok2, a.n_in - 1);
+    const half_t * r1 = a.wte + (size_t) tok * a.E;
+    const half_t * r2 = tok2 >= 0 ? a.wte + (size_t) tok2 * a.E : nullptr;
+    const float * pe = a.wpe + (size_t) pos * a.E;
+    float * out = a.x + (size_t) i * a.E;
+    for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
+        float v = (float) r1[e];
+        if (r2) v = v + (float) r2[e];                      // wte[text] + wte[history]  (bark.cpp:1237-1248)
+        out[e] = v + pe[e];
+    }
+}
+void launch_embed_causal(hipStream_t s, const EmbedArgs & a) {
+    hipLaunchKernelGGL(embed_causal_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
+}
+
+struct FineEmbedArgs { const half_t * wte[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
+__global__ void embed_fine_kernel(const FineEmbedArgs a) {
+    const int i = blockIdx.x;
+    float * out = a.x + (size_t) i * a.E;
+    const float * pe = a.wpe + (size_t) i * a.E;
+    for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
+        float v = 0.0f;                                     // ggml_set_zero(tok_emb), bark.cpp:1936-1937
+        for (int cb = 0; cb <= a.nn; cb++) {
+            int id = a.tok[cb * 1024 + i];
+            id = min(max(id, 0), a.n_in - 1);
+            v = v + (float) a.wte[cb][(size_t) id * a.E + e];
+        }
+        out[e] = v + pe[e];
+    }
+}
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const float * wpe, int E, int n_in,
+                       const int32_t * tokens_8x1024, int nn, float * x) {
+    FineEmbedArgs a; for (int i = 0; i < 8; i++) a.wte[i] = wte[i];
+    a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens_8x1024; a.nn = nn; a.x = x;
+    hipLaunchKernelGGL(embed_fine_kernel, dim3(1024), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows -> f16 (one wave per row)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float * x, int N, int E, const float * g, const float * b, half_t * out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    half_t * o = out + (size_t) row * E;
+    for (int e = lane; e < E; e += 64) {
+        float v = (xr[e] - mean) * scale;
+        v = v * g[e];
+        if (b) v = v + b[e];
+        o[e] = (half_t) v;
+    }
+}
+void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention: one workgroup (1024 threads) per head.
+//   scores : thread j owns key j  (C2: one fmaf chain over d = 0..63; K cache is d-quad major so the
+//            wave's 16-byte loads are contiguous over keys)
+//   softmax: block max, e = (float) exp((double)(s - max)), double sum, p = e * (float)(1/sum)
+//   mix    : wave c owns chain c of C5 (keys j = c, c+16, ...), lane = d; chains meet in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs a) {
+    __shared__ float qs[64];
+    __shared__ float ps[1024];
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ float part[16][64];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = a.H * 64, P = a.P;
+    const int ctx = a.st->n_past + 1;
+    if (tid < 64) qs[tid] = a.q[h * 64 + tid];
+    __syncthreads();
+    float s = -INFINITY;
+    if (tid < ctx) {
+        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+        float acc = 0.0f;
+        #pragma unroll
+        for (int dq = 0; dq < 16; dq++) {
+            const float4 kv = kp[(size_t) dq * P];
+            acc = fmaf(kv.x, qs[4 * dq + 0], acc);
+            acc = fmaf(kv.y, qs[4 * dq + 1], acc);
+            acc = fmaf(kv.z, qs[4 * dq + 2], acc);
+            acc = fmaf(kv.w, qs[4 * dq + 3], acc);
+        }
+        s = acc * 0.125f;                                   // 1/sqrt(64), bark.cpp:1318
+    }
+    float mx = wave_max(s);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    float e = 0.0f;
+    if (tid < ctx) e = (float) exp((double) (s - mx));
+    double sum = wave_sum((double) e);
+    if (lane == 0) red_d[wave] = sum;
+    __syncthreads();
+    sum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) sum += red_d[i];
+    const float inv = (float) (1.0 / sum);
+    ps[tid] = e * inv;
+    __syncthreads();
+    {
+        const float * vp = a.vc + (size_t) h * P * 64 + lane;
+        float acc = 0.0f;
+        for (int j = wave; j < ctx; j += 16) acc = fmaf(vp[(size_t) j * 64], ps[j], acc);
+        part[wave][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        a.att[h * 64 + tid] = (half_t) p[0];
+    }
+    (void) E;
+}
+void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.H), dim3(1024), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefill / fine attention (materialised scores): S = scale * Q K^T on the f32 matrix cores (C2 = one
+// MFMA accumulator chain over d), row softmax, O = P V on the f32 matrix cores (C5: 16 chains in
+// 8 waves x 2 accumulator sets, LDS tree).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_qk_kernel(const AttnPrefillArgs a) {
+    const int h = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int ctx = a.n_past + a.N;
+    if (j0 >= ctx) return;
+    if (a.causal && j0 > a.n_past + i0 + 63) return;        // tile entirely masked
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int it = w >> 1, jt = w & 1;
+    const int irow = min(i0 + it * 32 + l31, a.N - 1);
+    const int jrow = min(j0 + jt * 32 + l31, ctx - 1);
+    const float4 * qp = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
+    floatx16 acc;
+    #pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) {
+        const float4 qv = qp[dq], kv = kp[(size_t) dq * a.P];
+        // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv.y : qv.x, half ? kv.y : kv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv.w : qv.z, half ? kv.w : kv.z, acc, 0, 0, 0);
+    }
+    // A operand = Q (accumulator rows = queries i), B operand = K (accumulator cols = keys j: coalesced stores)
+    #pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = i0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int j = j0 + jt * 32 + l31;
+        if (i < a.N && j < ctx) a.scores[((size_t) h * a.N + i) * a.P + j] = acc[r] * 0.125f;    // 1/sqrt(64), bark.cpp:1318
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const AttnPrefillArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);     // row = h * N + i
+    if (row >= a.H * a.N) return;
+    const int i = row % a.N;
+    const int ctx = a.n_past + a.N;
+    const int valid = a.causal ? min(ctx, a.n_past + i + 1) : ctx;
+    float * s = a.scores + (size_t) row * a.P;
+    float mx = -INFINITY;
+    for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
+    mx = wave_max(mx);
+    double sum = 0.0;
+    for (int j = lane; j < valid; j += 64) { const float e = (float) exp((double) (s[j] - mx)); s[j] = e; sum += (double) e; }
+    sum = wave_sum(sum);
+    const float inv = (float) (1.0 / sum);
+    for (int j = lane; j < valid; j += 64) s[j] = s[j] * inv;
+    const int ctx32 = min((ctx + 31) & ~31, a.P);
+    for (int j = valid + lane; j < ctx32; j += 64) s[j] = 0.0f;          // masked keys: p == 0
+}
+
+__global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
+    __shared__ float part[8][32][64];
+    const int h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctx = a.n_past + a.N;
+    const int irow = min(i0 + l31, a.N - 1);
+    // causal: rows of this tile see keys <= n_past + i0 + 31
+    const int jend = a.causal ? min(ctx, a.n_past + i0 + 32) : ctx;
+    const float * prow = a.scores + ((size_t) h * a.N + irow) * a.P;
+    const float * vbase = a.vc + (size_t) h * a.P * 64;
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
+    for (int jb = 0; jb < jend; jb += 32) {
+        #pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int j = jb + 2 * w + s + 16 * half;           // chain 2w+s: keys jb+c, jb+16+c
+            const bool ok = j < jend;
+            const float pv = ok ? prow[j] : 0.0f;
+            #pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float vv = ok ? vbase[(size_t) j * 64 + t * 32 + l31] : 0.0f;
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, vv, acc[s][t], 0, 0, 0);
+            }
+        }
+    }
+    #pragma unroll
+    for (int t = 0; t < 2; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            part[w][row][t * 32 + l31] = acc[0][t][r] + acc[1][t][r];
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 512) {
+        const int row = idx >> 6, d = idx & 63;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = part[q][row][d];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        const int i = i0 + row;
+        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = (half_t) v;
+    }
+}
+
+void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
+    const int ctx = a.n_past + a.N;
+    hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 63) / 64, (a.N + 63) / 64, a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.H * a.N + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_pv_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy sampling (gpt_argmax_sample, bark.cpp:223-247): l /= 0.7; softmax; first index of the
+// largest probability.  p_i = e_i / sum is monotone in e_i = (float) exp((double)(l_i/0.7 - max)), so
+// the winner is the first index whose e_i rounds to 1.0f, i.e. l_i/0.7 - max >= -2^-25.
+// Picks whose runner-up is within kNearTie are counted in st->near_tie (the float division can
+// merge neighbouring probabilities; the host re-checks those).
+// ------------------------------------------------------------------------------------------------
+constexpr float kTieCut = -2.98023223876953125e-08f;     // -2^-25
+constexpr float kNearTie = -4.0e-7f;
+
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a) {
+    __shared__ float red_f[16];
+    __shared__ int red_i[16];
+    __shared__ int red_c[16];
+    __shared__ float red_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < a.n; i += 1024) mx = fmaxf(mx, a.logits[i] / 0.7f);
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    int best = INT32_MAX, close = 0;
+    float sum = 0.0f;
+    for (int i = tid; i < a.n; i += 1024) {
+        const float d = a.logits[i] / 0.7f - mx;
+        if (d >= kTieCut && i < best) best = i;
+        if (d >= kNearTie) close++;
+        if (a.mode == 0) sum += (float) exp((double) d);
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        best = min(best, __shfl_xor(best, m, 64));
+        close += __shfl_xor(close, m, 64);
+        sum += __shfl_xor(sum, m, 64);
+    }
+    if (lane == 0) { red_i[wave] = best; red_c[wave] = close; red_s[wave] = sum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; i++) { best = min(best, red_i[i]); close += red_c[i]; sum += red_s[i]; }
+        StepState * st = a.st;
+        const int step = st->step;
+        int tok = best;
+        float eos_p = 0.0f;
+        if (a.mode == 0) {
+            // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
+            eos_p = (float) exp((double) (a.logits[a.n - 1] / 0.7f - mx)) / sum;
+            if ((tok == a.eos_token || eos_p >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if (a.eos_trace) a.eos_trace[step] = eos_p;
+        } else {
+            tok += a.token_base + ((step & 1) ? 1024 : 0);   // slice start (bark.cpp:1829-1841)
+        }
+        if (close > 1) st->near_tie += 1;
+        a.out_tokens[st->n_out] = tok;
+        st->n_out += 1;
+        st->cur_token = tok;
+        st->step = step + 1;
+        st->n_past += a.n_past_add;
+        st->last_eos_p = eos_p;
+    }
+}
+void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
+    hipLaunchKernelGGL(sample_greedy_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
+                                                         int out_stride, StepState * st) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float * l = logits + (size_t) row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < n_cols; i += 64) mx = fmaxf(mx, l[i] / 0.7f);
+    mx = wave_max(mx);
+    int best = INT32_MAX, close = 0;
+    for (int i = lane; i < n_cols; i += 64) {
+        const float d = l[i] / 0.7f - mx;
+        if (d >= kTieCut && i < best) best = i;
+        if (d >= kNearTie) close++;
+    }
+    for (int m = 1; m < 64; m <<= 1) { best = min(best, __shfl_xor(best, m, 64)); close += __shfl_xor(close, m, 64); }
+    if (lane == 0) {
+        out[(size_t) row * out_stride] = best;
+        if (close > 1 && st) atomicAdd(&st->near_tie, 1);
+    }
+}
+void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out, int out_stride,
+                        StepState * st) {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, out, out_stride, st);
+}
+
+void init_kernel_attributes() {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
+}
+
+}  // namespace barkhip

@@ -1,0 +1,98 @@
+/*
+ * bark_mi355x.h - engine extensions of the MI355X-native Bark library (libbark.so).
+ *
+ * bark.h stays byte-compatible with the reference; everything the reference API cannot express
+ * (device selection, stage-level entry points that the parity tests and benchmarks drive,
+ * statistics beyond load/eval time) is declared here with plain C types.
+ *
+ * Each stage-level entry point replaces one internal function of the reference and is what a
+ * maintainer would bind if the reference exposed it (file:line cites /root/reference/bark.cpp):
+ *
+ *   bark_hip_tokenize        bark_tokenize_input                 bark.cpp:622-662
+ *   bark_hip_bert_tokenize   bert_tokenize                       bark.cpp:558-620
+ *   bark_hip_gpt_eval        bark_eval_encoder_internal          bark.cpp:1586-1643
+ *   bark_hip_fine_eval       bark_eval_fine_encoder_internal     bark.cpp:1907-1959
+ *   bark_hip_semantic        bark_forward_text_encoder           bark.cpp:1645-1743
+ *   bark_hip_coarse          bark_forward_coarse_encoder         bark.cpp:1745-1905
+ *   bark_hip_fine            bark_forward_fine_encoder           bark.cpp:1961-2104
+ *   bark_hip_codec_decode    encodec_decompress_audio call site  bark.cpp:2143-2167
+ *
+ * All of them run on the context's HIP stream and block until their result is on the host.
+ * Environment (read at bark_load_model):
+ *   BARK_HIP_DEVICE=<n>   HIP device ordinal (default: current device)
+ *   BARK_HIP_GRAPH=0|1    replay decode steps from a captured hipGraph (default 1)
+ */
+#pragma once
+#include "bark.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* which GPT: 0 semantic, 1 coarse, 2 fine */
+enum bark_hip_model { BARK_HIP_SEMANTIC = 0, BARK_HIP_COARSE = 1, BARK_HIP_FINE = 2 };
+
+/* out[10] = n_layer, n_head, n_embd, block_size, bias, n_in_vocab, n_out_vocab, n_lm_heads, n_wtes, ftype */
+BARK_API int bark_hip_hparams(struct bark_context * bctx, int which, int32_t * out10);
+
+/* Replace the generation parameters of a live context (same struct as bark_load_model takes). */
+BARK_API void bark_hip_set_params(struct bark_context * bctx, struct bark_context_params params);
+
+/* 513-id semantic prompt for `text`; returns 513 or <0. */
+BARK_API int bark_hip_tokenize(struct bark_context * bctx, const char * text, int32_t * out513);
+/* raw WordPiece ids (no offset / padding); returns the count. */
+BARK_API int bark_hip_bert_tokenize(struct bark_context * bctx, const char * text, int32_t * out, int n_max);
+
+/* One causal-model evaluation (which = 0|1).  n_tokens ids at positions n_past..; with merge_ctx
+ * and n_past == 0 the 513-id prompt collapses to 257 rows.  Writes n_out logits of the last row.
+ * Returns the new n_past, or -1. */
+BARK_API int bark_hip_gpt_eval(struct bark_context * bctx, int which, const int32_t * tokens, int n_tokens,
+                               int n_past, int merge_ctx, float * logits);
+
+/* One fine-model forward: tokens [8][1024] codebook-major, codebook nn in 2..7.
+ * logits [1024][n_out].  Returns 0 or -1. */
+BARK_API int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * tokens_8x1024, int nn, float * logits);
+
+/* Stage loops (greedy on device when temp == 0; host sampling otherwise).
+ * semantic: prompt513 -> out (capacity >= n_steps_text_encoder); returns count or -1.
+ * coarse  : semantic ids -> out [T][2]; returns T or -1.
+ * fine    : coarse [T][2] -> out [T][8]; returns T or -1 (T <= 1024). */
+BARK_API int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, float * eos_trace);
+BARK_API int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2);
+BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8);
+
+/* EnCodec decode: codes [n_q][T] (time contiguous) -> pcm (capacity 320*T floats). Returns samples or -1. */
+BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm);
+
+/* Token streams of the last bark_generate_audio call (copied out; returns counts). */
+BARK_API int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity);
+BARK_API int bark_hip_get_coarse_tokens(struct bark_context * bctx, int32_t * out_Tx2, int capacity_rows);
+BARK_API int bark_hip_get_fine_tokens(struct bark_context * bctx, int32_t * out_Tx8, int capacity_rows);
+
+/* Detailed statistics of the last bark_generate_audio call. */
+struct bark_hip_stats {
+    int64_t t_load_us, t_eval_us;
+    int64_t t_semantic_us, t_coarse_us, t_fine_us, t_codec_us;   /* host wall clock per stage        */
+    int64_t n_sample_semantic, n_sample_coarse, n_sample_fine;   /* same quotient as bark.cpp:176-182 */
+    int32_t n_semantic, n_frames, n_samples;
+    int32_t n_near_tie;                                          /* greedy picks settled on the host  */
+    int32_t graph_replays;                                       /* hipGraph launches issued          */
+};
+BARK_API void bark_hip_get_stats(struct bark_context * bctx, struct bark_hip_stats * out);
+
+/* Micro-benchmark hook used by bench.py for the roofline line: runs `iters` decode steps of model
+ * `which` at context length `ctx` on the context's stream and returns the average device time of
+ * one step in microseconds (hipEvents on that stream); *bytes_per_step receives the algorithmic
+ * bytes of one step (weights + KV rows read).  Returns <0 on error. */
+BARK_API double bark_hip_time_decode_step(struct bark_context * bctx, int which, int ctx, int iters,
+                                          double * bytes_per_step);
+
+/* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
+BARK_API double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass);
+
+/* Library / device description (static string). */
+BARK_API const char * bark_hip_describe(struct bark_context * bctx);
+
+#ifdef __cplusplus
+}
+#endif

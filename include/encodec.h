@@ -1,0 +1,4 @@
+/* encodec.h - SHIM (reference bark.h:20 includes it; callers of bark.h use nothing from it).
+ * The EnCodec decoder itself is part of the HIP engine (bark.cpp_amd/csrc/codec.hip). */
+#pragma once
+#include "ggml.h"

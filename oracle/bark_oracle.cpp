@@ -881,7 +881,9 @@ static bool fine_stage(Oracle & o, const Params & p, const std::vector<int32_t> 
 // EnCodec decoder (HF modeling_encodec.py; numerics: ggml conv/LSTM matmuls take f16-rounded
 // activations against f16 weights with f32 accumulation, everything else f32)
 // ------------------------------------------------------------------------------------
-static float elu(float x) { return x > 0.f ? x : expm1f(x); }
+// Canonical transcendental: evaluated in double and rounded once to float, so that the host libm and
+// the GPU's device libm (both < 1 ulp in double) produce the same float.
+static float elu(float x) { return x > 0.f ? x : (float) expm1((double) x); }
 
 // EncodecConv1d._pad1d with mode="reflect" (modeling_encodec.py:140-157), causal: (left = k - stride, right = extra)
 static std::vector<float> reflect_pad(const std::vector<float> & x, int C, int T, int left, int right, int & Tp) {
@@ -967,12 +969,12 @@ static std::vector<float> lstm_layer(const Oracle & o, const Lstm & L, const std
         gemm_w(const_cast<Oracle &>(o), L.w_hh, hr.data(), D, gh.data(), 4 * D, 4 * D, 1, D, nth);
         for (int d = 0; d < D; d++) {
             auto gate = [&](int g) { return (gi[g * D + d] + L.b_ih[g * D + d]) + (gh[g * D + d] + L.b_hh[g * D + d]); };
-            const float i_t = 1.f / (1.f + expf(-gate(0)));
-            const float f_t = 1.f / (1.f + expf(-gate(1)));
-            const float g_t = tanhf(gate(2));
-            const float o_t = 1.f / (1.f + expf(-gate(3)));
+            const float i_t = 1.f / (1.f + (float) exp((double) (-gate(0))));
+            const float f_t = 1.f / (1.f + (float) exp((double) (-gate(1))));
+            const float g_t = (float) tanh((double) gate(2));
+            const float o_t = 1.f / (1.f + (float) exp((double) (-gate(3))));
             c[d] = f_t * c[d] + i_t * g_t;
-            h[d] = o_t * tanhf(c[d]);
+            h[d] = o_t * (float) tanh((double) c[d]);
             hs[(size_t) d * T + t] = h[d];
         }
     }
