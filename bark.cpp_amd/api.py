@@ -66,7 +66,7 @@ EXPORTS = [
     "ggml_time_init", "ggml_time_us", "ggml_time_ms", "ggml_init", "ggml_free",
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
-    "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode",
+    "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
     lib.bark_hip_coarse.argtypes = [vp, ip, C.c_int, ip]
     lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip]
     lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
+    lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_get_semantic_tokens.argtypes = [vp, ip, C.c_int]
     lib.bark_hip_get_coarse_tokens.argtypes = [vp, ip, C.c_int]
     lib.bark_hip_get_fine_tokens.argtypes = [vp, ip, C.c_int]
@@ -265,6 +266,15 @@ class BarkContext:
         if n < 0:
             raise RuntimeError("bark_hip_codec_decode failed")
         return pcm[:n].copy()
+
+    def codec_tap(self, codes_qxT, stage: int) -> np.ndarray:
+        codes = _i32(codes_qxT)
+        n_q, T = codes.shape
+        out = np.zeros(T * 320 * 64, np.float32)
+        n = self._lib.bark_hip_codec_tap(self._h, codes.ctypes.data, n_q, T, stage, out.ctypes.data, out.size)
+        if n < 0:
+            raise RuntimeError("bark_hip_codec_tap failed")
+        return out[:n].copy()
 
     def semantic_tokens(self) -> np.ndarray:
         out = np.zeros(1024, np.int32)

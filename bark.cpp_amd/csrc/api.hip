@@ -173,9 +173,20 @@ int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T,
 int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm) {
     if (!bctx || !codes || !pcm) return -1;
     return guarded("bark_hip_codec_decode", -1, [&] {
-        std::vector<float> r = engine_codec_decode(bctx, codes, n_q, T);
+        std::vector<float> r = engine_codec_decode(bctx, codes, n_q, T, -1, nullptr);
         memcpy(pcm, r.data(), r.size() * 4);
         return (int) r.size();
+    });
+}
+
+int bark_hip_codec_tap(struct bark_context * bctx, const int32_t * codes, int n_q, int T, int stage, float * out, int capacity) {
+    if (!bctx || !codes || !out) return -1;
+    return guarded("bark_hip_codec_tap", -1, [&] {
+        std::vector<float> tap;
+        engine_codec_decode(bctx, codes, n_q, T, stage, &tap);
+        if ((int) tap.size() > capacity) return -1;
+        memcpy(out, tap.data(), tap.size() * 4);
+        return (int) tap.size();
     });
 }
 

@@ -27,13 +27,15 @@ void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int H
     hipLaunchKernelGGL(rvq_gather_kernel, dim3((T + 127) / 128, Hd), dim3(128), 0, s, codebooks, n_bins, Hd, codes, n_q, T, z);
 }
 
+// see kernels.hip: keeps the compiler from fusing the producing multiply into the f16 conversion
+__device__ __forceinline__ half_t to_half(float v) { asm("" : "+v"(v)); return (half_t) v; }
 __device__ __forceinline__ float elu_canon(float x) { return x > 0.0f ? x : (float) expm1((double) x); }
 
 __global__ void act_round_kernel(const float * x, size_t n, int elu, half_t * out) {
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
         float v = x[i];
         if (elu) v = elu_canon(v);
-        out[i] = (half_t) v;
+        out[i] = to_half(v);
     }
 }
 void launch_act_round(hipStream_t s, const float * x, size_t n, int elu, half_t * out_h) {
@@ -101,7 +103,7 @@ __global__ void transpose_round_kernel(const float * x, int C, int T, half_t * x
     __syncthreads();
     for (int r = threadIdx.y; r < 32; r += blockDim.y) {
         const int t = t0 + r, c = c0 + threadIdx.x;
-        if (t < T && c < C) xt[(size_t) t * C + c] = (half_t) tile[threadIdx.x][r];
+        if (t < T && c < C) xt[(size_t) t * C + c] = to_half(tile[threadIdx.x][r]);
     }
 }
 void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmStepArgs a) {
         const float cn = f_t * a.c[d] + i_t * g_t;
         const float hn = o_t * (float) tanh((double) cn);
         a.c[d] = cn;
-        a.hout_h[d] = (half_t) hn;
+        a.hout_h[d] = to_half(hn);
         a.hseq[(size_t) d * a.T + a.t] = hn;
     }
 }

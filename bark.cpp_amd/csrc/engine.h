@@ -101,7 +101,8 @@ void engine_fine_eval(bark_context * ctx, const int32_t * tokens_8x1024, int nn,
 std::vector<int32_t> engine_semantic(bark_context * ctx, const std::vector<int32_t> & prompt, std::vector<float> * eos_trace);
 std::vector<int32_t> engine_coarse(bark_context * ctx, const std::vector<int32_t> & semantic);          // [T][2]
 std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> & coarse_Tx2);          // [T][8]
-std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T);
+// tap_stage >= 0: *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
+std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap);
 bool engine_generate(bark_context * ctx, const char * text);
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);

@@ -757,7 +757,7 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
 // ---------------------------------------------------------------------------------------------------
 // EnCodec decode (encodec_decompress_audio call site, bark.cpp:2143-2167)
 // ---------------------------------------------------------------------------------------------------
-std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, int n_q, int T) {
+std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap) {
     HIP_OK(hipSetDevice(c->device));
     CodecModel & cm = c->codec;
     if (n_q <= 0 || n_q > cm.n_q || T <= 0 || T > 4096) throw std::runtime_error("codec: bad code matrix shape");
@@ -811,7 +811,15 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
             launch_lstm_step(s, a);
         }
     }
+    auto grab = [&](int stage, const float * buf, size_t n) {
+        if (tap_stage != stage || !tap) return;
+        tap->resize(n);
+        HIP_OK(hipMemcpyAsync(tap->data(), buf, n * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    };
+    grab(0, B, (size_t) D * T);
     launch_add(s, R, B, (size_t) D * T, A);                            // y + x ; A = x
+    grab(1, A, (size_t) D * T);
     float * cur = A, * other = B;
     int Tc = T;
     for (int b = 0; b < 4; b++) {
@@ -826,6 +834,7 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
         conv(bl.sc, cur, false, Tc, other, R);                          // R = shortcut(x) + r
         std::swap(cur, R);
         // keep three distinct buffers: cur (result), other, R (old x)
+        grab(2 + b, cur, (size_t) bl.up.cout * Tc);
     }
     conv(cm.fin, cur, true, Tc, nullptr, other);
     std::vector<float> pcm((size_t) Tc);
@@ -870,7 +879,7 @@ bool engine_generate(bark_context * c, const char * text) {
     std::vector<int32_t> codes((size_t) 8 * T);
     for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) codes[(size_t) ch * T + i] = c->fine_tokens[(size_t) i * 8 + ch];   // bark.cpp:2153-2159
     t = now_us();
-    c->audio = engine_codec_decode(c, codes.data(), 8, T);
+    c->audio = engine_codec_decode(c, codes.data(), 8, T, -1, nullptr);
     c->stats.t_codec_us = now_us() - t;
     c->stats.n_samples = (int32_t) c->audio.size();
     c->stats.t_eval_us = now_us() - t0;

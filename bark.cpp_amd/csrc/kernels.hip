@@ -43,12 +43,16 @@ DEVINL float wave_max(float v) {
     return v;
 }
 DEVINL half8 ld_half8(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
+// f32 -> f16, round to nearest even, of an ALREADY ROUNDED f32 value.  The empty asm keeps hipcc from
+// folding the producing multiply/add into v_fma_mixlo_f16, which rounds the exact result once and
+// differs from the CPU's two roundings in about one of 2^13 cases.
+DEVINL half_t to_half(float v) { asm("" : "+v"(v)); return (half_t) v; }
 
 // ggml_gelu on the CPU backend: f16 lookup table, pass-through outside (-10, 10)
 DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
     if (v <= -10.0f) return (half_t) 0.0f;
-    if (v >= 10.0f) return (half_t) v;
-    const half_t hv = (half_t) v;                         // round to nearest even
+    if (v >= 10.0f) return to_half(v);
+    const half_t hv = to_half(v);                         // round to nearest even
     const uint16_t bits = __builtin_bit_cast(uint16_t, hv);
     return __builtin_bit_cast(half_t, lut[bits]);
 }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const LinArgs a) {
                 v = v * a.ln_g[k0 + e];
                 if (a.ln_b) v = v + a.ln_b[k0 + e];
                 // mul_mat converts the activation to f16 first
-                acc = fmaf((float) wv[b][e], (float) (half_t) v, acc);
+                acc = fmaf((float) wv[b][e], (float) to_half(v), acc);
             }
         }
     } else {
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float * x, int N, in
         float v = (xr[e] - mean) * scale;
         v = v * g[e];
         if (b) v = v + b[e];
-        o[e] = (half_t) v;
+        o[e] = to_half(v);
     }
 }
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
         for (int st = 1; st < 16; st <<= 1)
             #pragma unroll
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        a.att[h * 64 + tid] = (half_t) p[0];
+        a.att[h * 64 + tid] = to_half(p[0]);
     }
     (void) E;
 }
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
         for (int q = 0; q < 8; q++) p[q] = part[q][row][d];
         const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         const int i = i0 + row;
-        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = (half_t) v;
+        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v);
     }
 }
 

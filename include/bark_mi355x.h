@@ -64,6 +64,10 @@ BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx
 /* EnCodec decode: codes [n_q][T] (time contiguous) -> pcm (capacity 320*T floats). Returns samples or -1. */
 BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm);
 
+/* Per-layer parity tap of the codec: activation [C][T'] after stage 0 (first conv), 1 (LSTM + skip),
+ * 2..5 (the four upsampling blocks).  Returns the element count or -1. */
+BARK_API int bark_hip_codec_tap(struct bark_context * bctx, const int32_t * codes, int n_q, int T, int stage, float * out, int capacity);
+
 /* Token streams of the last bark_generate_audio call (copied out; returns counts). */
 BARK_API int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity);
 BARK_API int bark_hip_get_coarse_tokens(struct bark_context * bctx, int32_t * out_Tx2, int capacity_rows);

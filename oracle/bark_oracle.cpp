@@ -982,7 +982,8 @@ static std::vector<float> lstm_layer(const Oracle & o, const Lstm & L, const std
 }
 
 // codes: [n_q][T] (time contiguous, bark.cpp:2153-2161).  pcm: 320*T samples (for the 24 kHz ratios).
-static bool codec_decode(Oracle & o, const int32_t * codes, int n_q, int T, std::vector<float> & pcm, int nth) {
+// tap: if tap_stage >= 0, *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
+static bool codec_decode(Oracle & o, const int32_t * codes, int n_q, int T, std::vector<float> & pcm, int nth, int tap_stage = -1, std::vector<float> * tap = nullptr) {
     Codec & c = o.codec;
     const int H = c.hidden_dim;
     if (n_q <= 0 || n_q > (int) c.codebooks.size() || T <= 0) return false;
@@ -996,11 +997,13 @@ static bool codec_decode(Oracle & o, const int32_t * codes, int n_q, int T, std:
     }
     std::vector<float> x = conv1d(o, c.init, z, T, nth);
     const int D = c.init.cout;
+    if (tap_stage == 0) *tap = x;
     {   // 2-layer LSTM with skip connection
         std::vector<float> y = lstm_layer(o, c.lstm[0], x, D, T, nth);
         y = lstm_layer(o, c.lstm[1], y, D, T, nth);
         for (size_t i = 0; i < x.size(); i++) x[i] = y[i] + x[i];
     }
+    if (tap_stage == 1) *tap = x;
     int Tc = T;
     for (int b = 0; b < 4; b++) {
         auto & B = c.blocks[b];
@@ -1016,6 +1019,7 @@ static bool codec_decode(Oracle & o, const int32_t * codes, int n_q, int T, std:
         std::vector<float> s = conv1d(o, B.sc, x, Tc, nth);
         for (size_t i = 0; i < s.size(); i++) s[i] = s[i] + r[i];
         x.swap(s);
+        if (tap_stage == 2 + b) *tap = x;
     }
     for (float & v : x) v = elu(v);
     pcm = conv1d(o, c.fin, x, Tc, nth);
@@ -1114,6 +1118,14 @@ int orc_fine(void * h, const orc_params * q, const int32_t * coarse_Tx2, int T, 
     if (!fine_stage(*o, p, c, res, nth)) return -1;
     memcpy(out_Tx8, res.data(), res.size() * 4);
     return (int) res.size() / 8;
+}
+// activation after codec stage `stage` (see codec_decode); returns the element count or -1
+int orc_codec_tap(void * h, const int32_t * codes, int n_q, int T, int stage, float * out, int capacity, int nth) {
+    std::vector<float> pcm, tap;
+    if (!codec_decode(*(Oracle *) h, codes, n_q, T, pcm, nth, stage, &tap)) return -1;
+    if ((int) tap.size() > capacity) return -1;
+    memcpy(out, tap.data(), tap.size() * 4);
+    return (int) tap.size();
 }
 // codes: [n_q][T]; pcm must hold 320*T floats for the 24 kHz ratios; returns sample count
 int orc_codec_decode(void * h, const int32_t * codes, int n_q, int T, float * pcm, int nth) {

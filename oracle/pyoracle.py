@@ -58,6 +58,7 @@ class Oracle:
         lib.orc_coarse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         lib.orc_fine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         lib.orc_codec_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.orc_codec_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         lib.orc_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.h = lib.orc_open(model_path.encode())
         if not self.h:
@@ -161,6 +162,15 @@ class Oracle:
         if n < 0:
             raise RuntimeError("oracle codec decode failed")
         return pcm[:n].copy()
+
+    def codec_tap(self, codes_qxT, stage: int) -> np.ndarray:
+        codes = _i32(codes_qxT)
+        n_q, T = codes.shape
+        out = np.zeros(T * 320 * 64, np.float32)
+        n = self.lib.orc_codec_tap(self.h, codes.ctypes.data, n_q, T, stage, out.ctypes.data, out.size, self.n_threads)
+        if n < 0:
+            raise RuntimeError("oracle codec tap failed")
+        return out[:n].copy()
 
     def generate(self, text: str, p: OrcParams) -> dict:
         sem = np.zeros(1024, np.int32)
