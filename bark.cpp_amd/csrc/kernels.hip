@@ -86,30 +86,39 @@ DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_
 // 256-byte row segments per instruction.  x is either an f16 vector or (LN = true) an f32 row that
 // every 16-lane group normalises redundantly in registers (no LDS, no barrier).
 // ------------------------------------------------------------------------------------------------
-template <bool LN>
-__global__ __launch_bounds__(256) void gemv_kernel(const LinArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// NBLK = K / 128 is a compile-time constant so that every load of a lane (weights, x, LayerNorm
+// parameters) is issued up front with no control flow in between: the kernel is one memory round
+// trip deep.  One wave per workgroup (4 output rows) spreads the rows over as many CUs as possible.
+template <int NBLK, bool LN, bool LNB>
+__global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
+    const int lane = threadIdx.x;
     const int c = lane & 15, rg = lane >> 4;
-    const int m = (blockIdx.x * 4 + wave) * 4 + rg;
-    const int K = a.K, nblk = K >> 7;                      // K is a multiple of 128
+    const int m = blockIdx.x * 4 + rg;
+    constexpr int K = NBLK * 128;
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;                              // whole 16-lane groups are live or dead together
     const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
     float acc = 0.0f;
 
-    if (LN) {
-        constexpr int MAXB = 8;                             // n_embd <= 1024
-        half8 wv[MAXB];
+    if constexpr (LN) {
+        static_assert(NBLK <= 8, "LayerNorm-fused GEMV keeps the row in registers (n_embd <= 1024)");
+        half8 wv[NBLK];
+        float4 xa[NBLK][2], ga[NBLK][2], ba[NBLK][2];
         #pragma unroll
-        for (int b = 0; b < MAXB; b++) if (b < nblk) wv[b] = ld_half8(wrow + (b << 7));   // weights first: longest latency
+        for (int b = 0; b < NBLK; b++) {
+            const int k0 = (b * 16 + c) << 3;
+            wv[b] = ld_half8(wrow + (b << 7));
+            xa[b][0] = *reinterpret_cast<const float4 *>(a.x_f32 + k0); xa[b][1] = *reinterpret_cast<const float4 *>(a.x_f32 + k0 + 4);
+            ga[b][0] = *reinterpret_cast<const float4 *>(a.ln_g + k0);  ga[b][1] = *reinterpret_cast<const float4 *>(a.ln_g + k0 + 4);
+            if constexpr (LNB) { ba[b][0] = *reinterpret_cast<const float4 *>(a.ln_b + k0); ba[b][1] = *reinterpret_cast<const float4 *>(a.ln_b + k0 + 4); }
+        }
         // ggml_norm (+mul, +add): double sums, eps on the variance (bark.cpp:1265-1274)
-        float xr[MAXB][8];
+        float xr[NBLK][8];
         double s1 = 0.0;
         #pragma unroll
-        for (int b = 0; b < MAXB; b++) if (b < nblk) {
-            const float4 * p = reinterpret_cast<const float4 *>(a.x_f32 + ((b * 16 + c) << 3));
-            const float4 u = p[0], w = p[1];
-            xr[b][0] = u.x; xr[b][1] = u.y; xr[b][2] = u.z; xr[b][3] = u.w; xr[b][4] = w.x; xr[b][5] = w.y; xr[b][6] = w.z; xr[b][7] = w.w;
+        for (int b = 0; b < NBLK; b++) {
+            xr[b][0] = xa[b][0].x; xr[b][1] = xa[b][0].y; xr[b][2] = xa[b][0].z; xr[b][3] = xa[b][0].w;
+            xr[b][4] = xa[b][1].x; xr[b][5] = xa[b][1].y; xr[b][6] = xa[b][1].z; xr[b][7] = xa[b][1].w;
             #pragma unroll
             for (int e = 0; e < 8; e++) s1 += (double) xr[b][e];
         }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const LinArgs a) {
         const float mean = (float) (s1 / (double) K);
         double s2 = 0.0;
         #pragma unroll
-        for (int b = 0; b < MAXB; b++) if (b < nblk) {
+        for (int b = 0; b < NBLK; b++) {
             #pragma unroll
             for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; s2 += (double) (v * v); }
         }
@@ -125,32 +134,57 @@ __global__ __launch_bounds__(256) void gemv_kernel(const LinArgs a) {
         const float var = (float) (s2 / (double) K);
         const float scale = 1.0f / sqrtf(var + 1e-5f);
         #pragma unroll
-        for (int b = 0; b < MAXB; b++) if (b < nblk) {
-            const int k0 = (b * 16 + c) << 3;
+        for (int b = 0; b < NBLK; b++) {
+            const float gg[8] = {ga[b][0].x, ga[b][0].y, ga[b][0].z, ga[b][0].w, ga[b][1].x, ga[b][1].y, ga[b][1].z, ga[b][1].w};
+            float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (LNB) { bb[0] = ba[b][0].x; bb[1] = ba[b][0].y; bb[2] = ba[b][0].z; bb[3] = ba[b][0].w; bb[4] = ba[b][1].x; bb[5] = ba[b][1].y; bb[6] = ba[b][1].z; bb[7] = ba[b][1].w; }
             #pragma unroll
             for (int e = 0; e < 8; e++) {
                 float v = xr[b][e] * scale;
-                v = v * a.ln_g[k0 + e];
-                if (a.ln_b) v = v + a.ln_b[k0 + e];
+                v = v * gg[e];
+                if constexpr (LNB) v = v + bb[e];
                 // mul_mat converts the activation to f16 first
                 acc = fmaf((float) wv[b][e], (float) to_half(v), acc);
             }
         }
     } else {
         const half_t * xrow = a.x_f16 + (c << 3);
-        for (int b0 = 0; b0 < nblk; b0 += 8) {
-            half8 wv[8], xv[8];
-            #pragma unroll
-            for (int i = 0; i < 8; i++) if (b0 + i < nblk) { wv[i] = ld_half8(wrow + ((b0 + i) << 7)); xv[i] = ld_half8(xrow + ((b0 + i) << 7)); }
-            #pragma unroll
-            for (int i = 0; i < 8; i++) if (b0 + i < nblk) {
+        constexpr int G = NBLK < 8 ? NBLK : 8;                // loads in flight per lane and operand
+        static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+        half8 wv[2][G], xv[2][G];
+        #pragma unroll
+        for (int i = 0; i < G; i++) { wv[0][i] = ld_half8(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
+        #pragma unroll
+        for (int g = 0; g < NBLK / G; g++) {
+            if (g + 1 < NBLK / G) {
                 #pragma unroll
-                for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
+                for (int i = 0; i < G; i++) {
+                    wv[(g + 1) & 1][i] = ld_half8(wrow + (((g + 1) * G + i) << 7));
+                    xv[(g + 1) & 1][i] = ld_half8(xrow + (((g + 1) * G + i) << 7));
+                }
+            }
+            #pragma unroll
+            for (int i = 0; i < G; i++) {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) acc = fmaf((float) wv[g & 1][i][e], (float) xv[g & 1][i][e], acc);
             }
         }
     }
     acc = wave_xor_add16(acc);
     if (live && c == 0) linear_epilogue(a, 0, m, acc, row_off);
+}
+
+template <int NBLK>
+static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
+    dim3 grid((a.M + 3) / 4), block(64);
+    if (a.x_f32) {
+        if constexpr (NBLK <= 8) {
+            if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);
+        } else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a);
+    }
 }
 
 // Same operator for several input rows at once (N small, or as a cross-check of gemm_kernel):
@@ -255,12 +289,16 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
     const int nblk = a.K >> 7;
     if (a.N == 1) {
-        dim3 grid((a.M + 15) / 16), block(256);
-        if (a.x_f32) {
-            if (nblk <= 8) hipLaunchKernelGGL((gemv_kernel<true>), grid, block, 0, s, a);
-            else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
-        } else {
-            hipLaunchKernelGGL((gemv_kernel<false>), grid, block, 0, s, a);
+        switch (nblk) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
+            case 1:  launch_gemv_n<1>(s, a); break;
+            case 2:  launch_gemv_n<2>(s, a); break;
+            case 4:  launch_gemv_n<4>(s, a); break;
+            case 6:  launch_gemv_n<6>(s, a); break;
+            case 8:  launch_gemv_n<8>(s, a); break;
+            case 16: launch_gemv_n<16>(s, a); break;
+            case 24: launch_gemv_n<24>(s, a); break;
+            case 32: launch_gemv_n<32>(s, a); break;
+            default: fprintf(stderr, "bark-hip: unsupported K=%d in decode GEMV\n", a.K); abort();
         }
         return;
     }
@@ -362,30 +400,45 @@ void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * 
 //   mix    : wave c owns chain c of C5 (keys j = c, c+16, ...), lane = d; chains meet in LDS
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs a) {
-    __shared__ float qs[64];
     __shared__ float ps[1024];
     __shared__ float red_f[16];
     __shared__ double red_d[16];
     __shared__ float part[16][64];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int E = a.H * 64, P = a.P;
+    const int P = a.P;
     const int ctx = a.st->n_past + 1;
-    if (tid < 64) qs[tid] = a.q[h * 64 + tid];
-    __syncthreads();
+    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: served by scalar loads
+    // ---- issue every load of this thread's first two roles before any arithmetic ------------------
+    // role 1: key `tid` for the scores (16 x 16 bytes);  role 2: chain `wave`, dim `lane` of the mix
+    const int jk = min(tid, ctx - 1);
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + jk;
+    float4 kv[16];
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    const float * vp = a.vc + (size_t) h * P * 64 + lane;
+    float vv[32];
+    #pragma unroll
+    for (int i = 0; i < 32; i++) vv[i] = vp[(size_t) min(wave + 16 * i, ctx - 1) * 64];
+    // ---- scores: C2, one fmaf chain over d ----------------------------------------------------------
     float s = -INFINITY;
-    if (tid < ctx) {
-        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+    {
         float acc = 0.0f;
         #pragma unroll
         for (int dq = 0; dq < 16; dq++) {
-            const float4 kv = kp[(size_t) dq * P];
-            acc = fmaf(kv.x, qs[4 * dq + 0], acc);
-            acc = fmaf(kv.y, qs[4 * dq + 1], acc);
-            acc = fmaf(kv.z, qs[4 * dq + 2], acc);
-            acc = fmaf(kv.w, qs[4 * dq + 3], acc);
+            acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
+            acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
+            acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
+            acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
         }
-        s = acc * 0.125f;                                   // 1/sqrt(64), bark.cpp:1318
+        if (tid < ctx) s = acc * 0.125f;                     // 1/sqrt(64), bark.cpp:1318
     }
+    // second half of the value rows (only contexts beyond 512 keys need them); overlaps the softmax
+    float vw[32];
+    if (ctx > 512) {
+        #pragma unroll
+        for (int i = 0; i < 32; i++) vw[i] = vp[(size_t) min(wave + 16 * (32 + i), ctx - 1) * 64];
+    }
+    // ---- softmax --------------------------------------------------------------------------------------
     float mx = wave_max(s);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
@@ -403,10 +456,15 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
     const float inv = (float) (1.0 / sum);
     ps[tid] = e * inv;
     __syncthreads();
+    // ---- mix: C5, wave = chain, keys wave, wave+16, ... ---------------------------------------------
     {
-        const float * vp = a.vc + (size_t) h * P * 64 + lane;
         float acc = 0.0f;
-        for (int j = wave; j < ctx; j += 16) acc = fmaf(vp[(size_t) j * 64], ps[j], acc);
+        #pragma unroll
+        for (int i = 0; i < 32; i++) { const int j = wave + 16 * i; if (j < ctx) acc = fmaf(vv[i], ps[j], acc); }
+        if (ctx > 512) {
+            #pragma unroll
+            for (int i = 0; i < 32; i++) { const int j = wave + 16 * (32 + i); if (j < ctx) acc = fmaf(vw[i], ps[j], acc); }
+        }
         part[wave][lane] = acc;
     }
     __syncthreads();
@@ -420,7 +478,6 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
         a.att[h * 64 + tid] = to_half(p[0]);
     }
-    (void) E;
 }
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     hipLaunchKernelGGL(attn_decode_kernel, dim3(a.H), dim3(1024), 0, s, a);
