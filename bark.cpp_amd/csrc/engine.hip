@@ -332,7 +332,7 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         launch_linear(s, a);
         AttnDecodeArgs at;
-        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att;
+        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores;
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
@@ -417,15 +417,20 @@ void run_sample(bark_context * c, const StageCfg & s, int n_past_add) {
     a.logits = c->logits; a.n = s.lm_rows; a.mode = s.mode; a.min_eos_p = s.min_eos_p; a.eos_token = s.eos_token;
     a.token_base = s.token_base; a.n_past_add = n_past_add; a.out_tokens = c->d_out_tokens;
     a.eos_trace = s.mode == 0 ? c->d_eos_trace : nullptr; a.st = c->d_state;
+    const GptModel & m = c->gpt[s.which];
+    a.wte = m.wte[0]; a.wpe = m.wpe; a.E = m.hp.n_embd; a.n_in = m.hp.n_in_vocab; a.P = c->P; a.x = c->x;
     launch_sample_greedy(c->stream, a);
 }
 
-// embed(state) -> layers -> LM head [-> greedy sample]
-void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add) {
+// [embed(state) ->] layers -> LM head [-> greedy sample + embedding of the sampled token]
+// In the greedy loop the previous sample kernel has already written x, so the step starts at the layers.
+void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add, bool embed = true) {
     GptModel & m = c->gpt[s.which];
-    EmbedArgs e;
-    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
-    launch_embed_causal(c->stream, e);
+    if (embed) {
+        EmbedArgs e;
+        e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
+        launch_embed_causal(c->stream, e);
+    }
     run_layers_decode(c, m);
     run_lm_head(c, m, c->x, s.lm_row0, s.lm_rows, s.parity_rows);
     if (sample) run_sample(c, s, n_past_add);
@@ -435,7 +440,7 @@ hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_a
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    try { enqueue_decode_step(c, s, true, n_past_add); }
+    try { enqueue_decode_step(c, s, true, n_past_add, false); }
     catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
     HIP_OK(hipStreamEndCapture(c->stream, &graph));
     HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -450,7 +455,7 @@ void decode_step_greedy(bark_context * c, const StageCfg & s) {
         HIP_OK(hipGraphLaunch(m.decode_graph, c->stream));
         c->stats.graph_replays++;
     } else {
-        enqueue_decode_step(c, s, true, 1);
+        enqueue_decode_step(c, s, true, 1, false);
     }
 }
 

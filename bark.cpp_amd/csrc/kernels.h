@@ -72,6 +72,7 @@ void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * 
 struct AttnDecodeArgs {
     const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
+    float * scores = nullptr;             // scratch [H][P]
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
 
@@ -92,6 +93,8 @@ struct SampleArgs {
     int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
     int32_t * out_tokens = nullptr; float * eos_trace = nullptr; StepState * st = nullptr;
+    // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
+    const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
 };
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]

@@ -23,15 +23,30 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #define DEVINL __device__ __forceinline__
 
-DEVINL float wave_xor_add16(float v) {       // C1/C5 tree over 16 adjacent lanes: xor 1, 2, 4, 8
-    v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    v = v + __shfl_xor(v, 4, 64);
-    v = v + __shfl_xor(v, 8, 64);
+// Sums over the 16 lanes of a DPP row in the C1/C5 tree order (partner xor 1, 2, 4, 8).  After the
+// xor-1 / xor-2 quad permutes every lane of a quad holds the quad sum, so the half-row mirror (lane i
+// <- 7-i) and the row mirror (lane i <- 15-i) deliver exactly the xor-4 / xor-8 partner sums; fp add is
+// commutative, so every lane ends with the same bits as the butterfly.  DPP moves cost one VALU op,
+// ds_bpermute-based __shfl_xor costs an LDS round trip per stage.
+template <int CTRL> DEVINL float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> DEVINL double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) u, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (u >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+DEVINL float wave_xor_add16(float v) {
+    v = v + dpp_f32<DPP_XOR1>(v);
+    v = v + dpp_f32<DPP_XOR2>(v);
+    v = v + dpp_f32<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f32<DPP_MIRROR>(v);
     return v;
 }
 DEVINL double group16_sum(double v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    v += dpp_f64<DPP_XOR1>(v); v += dpp_f64<DPP_XOR2>(v); v += dpp_f64<DPP_HALF_MIRROR>(v); v += dpp_f64<DPP_MIRROR>(v);
     return v;
 }
 DEVINL double wave_sum(double v) {
@@ -61,6 +76,33 @@ DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
 DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
 DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
 
+// Operands the epilogue reads, fetched at kernel entry so that their latency overlaps the weight stream.
+struct EpiPre { float bias; float res; int n_past; };
+DEVINL EpiPre epilogue_prefetch(const LinArgs & a, int n, int m, int row_off) {
+    EpiPre p;
+    p.bias = a.bias ? a.bias[row_off + m] : 0.0f;
+    p.res = a.epi == EPI_RESID ? a.res[(size_t) n * a.M + m] : 0.0f;
+    p.n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
+    return p;
+}
+DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, const EpiPre & p) {
+    float v = dot;
+    if (a.bias) v = v + p.bias;
+    switch (a.epi) {
+        case EPI_QKV: {
+            const int E = a.E;
+            if (m < E) { a.q[(size_t) n * E + m] = v; break; }
+            const int pos = a.pos0 + p.n_past + n;
+            const int mm = m < 2 * E ? m - E : m - 2 * E;
+            const int h = mm >> 6, d = mm & 63;
+            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else a.vc[vc_index(h, d, pos, a.P)] = v;
+            break;
+        }
+        case EPI_RESID: a.res[(size_t) n * a.M + m] = v + p.res; break;                          // cur + inpL (bark.cpp:1352,1388)
+        case EPI_GELU:  a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v, a.lut); break;
+        default:        a.out[(size_t) n * a.ld_out + m] = v; break;
+    }
+}
 DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_off) {
     float v = dot;
     if (a.bias) v = v + a.bias[row_off + m];
@@ -98,6 +140,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;                              // whole 16-lane groups are live or dead together
     const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     float acc = 0.0f;
 
     if constexpr (LN) {
@@ -171,7 +214,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
         }
     }
     acc = wave_xor_add16(acc);
-    if (live && c == 0) linear_epilogue(a, 0, m, acc, row_off);
+    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
 }
 
 template <int NBLK>
@@ -393,13 +436,35 @@ void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * 
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode attention: one workgroup (1024 threads) per head.
-//   scores : thread j owns key j  (C2: one fmaf chain over d = 0..63; K cache is d-quad major so the
-//            wave's 16-byte loads are contiguous over keys)
-//   softmax: block max, e = (float) exp((double)(s - max)), double sum, p = e * (float)(1/sum)
-//   mix    : wave c owns chain c of C5 (keys j = c, c+16, ...), lane = d; chains meet in LDS
+// decode attention, two launches so that the key stream is spread over the whole chip:
+//   attn_scores_kernel : one wave per 64 keys and head (grid P/64 x H); lane = key, C2 = one fmaf chain
+//                        over d; the K cache is d-quad major, so a wave's 16-byte loads are contiguous.
+//   attn_mix_kernel    : one workgroup (16 waves) per head: softmax statistics over the score row
+//                        (max, e = (float) exp((double)(s - max)), double sum), then wave c owns chain c
+//                        of C5 (keys c, c+16, ...), lane = d; the 16 chains meet in LDS (tree order).
+// Every load is issued before the arithmetic that needs the previous one.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs a) {
+__global__ __launch_bounds__(64) void attn_scores_kernel(const AttnDecodeArgs a) {
+    const int h = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    const int P = a.P;
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + j;     // j < P: always inside the cache
+    float4 kv[16];
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    const int ctx = a.st->n_past + 1;
+    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
+    float acc = 0.0f;
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) {
+        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
+        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
+        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
+        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
+    }
+    if (j < ctx) a.scores[(size_t) h * P + j] = acc * 0.125f;          // 1/sqrt(64), bark.cpp:1318
+}
+
+__global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) {
     __shared__ float ps[1024];
     __shared__ float red_f[16];
     __shared__ double red_d[16];
@@ -407,38 +472,17 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
     const int ctx = a.st->n_past + 1;
-    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: served by scalar loads
-    // ---- issue every load of this thread's first two roles before any arithmetic ------------------
-    // role 1: key `tid` for the scores (16 x 16 bytes);  role 2: chain `wave`, dim `lane` of the mix
-    const int jk = min(tid, ctx - 1);
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + jk;
-    float4 kv[16];
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    const float sraw = a.scores[(size_t) h * P + tid];                // tid < P; garbage beyond ctx is masked below
     const float * vp = a.vc + (size_t) h * P * 64 + lane;
-    float vv[32];
+    float vv[64];
     #pragma unroll
-    for (int i = 0; i < 32; i++) vv[i] = vp[(size_t) min(wave + 16 * i, ctx - 1) * 64];
-    // ---- scores: C2, one fmaf chain over d ----------------------------------------------------------
-    float s = -INFINITY;
-    {
-        float acc = 0.0f;
-        #pragma unroll
-        for (int dq = 0; dq < 16; dq++) {
-            acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
-            acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
-            acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
-            acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (wave + 16 * (16 * g + i)) * 64];   // row < P
         }
-        if (tid < ctx) s = acc * 0.125f;                     // 1/sqrt(64), bark.cpp:1318
     }
-    // second half of the value rows (only contexts beyond 512 keys need them); overlaps the softmax
-    float vw[32];
-    if (ctx > 512) {
-        #pragma unroll
-        for (int i = 0; i < 32; i++) vw[i] = vp[(size_t) min(wave + 16 * (32 + i), ctx - 1) * 64];
-    }
-    // ---- softmax --------------------------------------------------------------------------------------
+    const float s = tid < ctx ? sraw : -INFINITY;
     float mx = wave_max(s);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
@@ -456,17 +500,15 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
     const float inv = (float) (1.0 / sum);
     ps[tid] = e * inv;
     __syncthreads();
-    // ---- mix: C5, wave = chain, keys wave, wave+16, ... ---------------------------------------------
-    {
-        float acc = 0.0f;
-        #pragma unroll
-        for (int i = 0; i < 32; i++) { const int j = wave + 16 * i; if (j < ctx) acc = fmaf(vv[i], ps[j], acc); }
-        if (ctx > 512) {
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
             #pragma unroll
-            for (int i = 0; i < 32; i++) { const int j = wave + 16 * (32 + i); if (j < ctx) acc = fmaf(vw[i], ps[j], acc); }
+            for (int i = 0; i < 16; i++) { const int j = wave + 16 * (16 * g + i); if (j < ctx) acc = fmaf(vv[16 * g + i], ps[j], acc); }
         }
-        part[wave][lane] = acc;
     }
+    part[wave][lane] = acc;
     __syncthreads();
     if (tid < 64) {
         float p[16];
@@ -480,7 +522,8 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const AttnDecodeArgs 
     }
 }
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.H), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,21 +650,35 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     __shared__ int red_i[16];
     __shared__ int red_c[16];
     __shared__ float red_s[16];
+    __shared__ int next_tok, next_pos;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int MAXV = 12;                                   // up to 12288 logits
+    float sv[MAXV];
     float mx = -INFINITY;
-    for (int i = tid; i < a.n; i += 1024) mx = fmaxf(mx, a.logits[i] / 0.7f);
+    #pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = tid + 1024 * k;
+        sv[k] = i < a.n ? a.logits[i] / 0.7f : -INFINITY;      // gpt_argmax_sample divides by 0.7 whatever the temperature
+        mx = fmaxf(mx, sv[k]);
+    }
+    const float last_logit = a.logits[a.n - 1];
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
     mx = red_f[0];
+    #pragma unroll
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
     int best = INT32_MAX, close = 0;
     float sum = 0.0f;
-    for (int i = tid; i < a.n; i += 1024) {
-        const float d = a.logits[i] / 0.7f - mx;
-        if (d >= kTieCut && i < best) best = i;
-        if (d >= kNearTie) close++;
-        if (a.mode == 0) sum += (float) exp((double) d);
+    #pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = tid + 1024 * k;
+        if (i < a.n) {
+            const float d = sv[k] - mx;
+            if (d >= kTieCut && i < best) best = i;
+            if (d >= kNearTie) close++;
+            if (a.mode == 0) sum += (float) exp((double) d);
+        }
     }
     for (int m = 1; m < 64; m <<= 1) {
         best = min(best, __shfl_xor(best, m, 64));
@@ -638,7 +695,7 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
         float eos_p = 0.0f;
         if (a.mode == 0) {
             // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
-            eos_p = (float) exp((double) (a.logits[a.n - 1] / 0.7f - mx)) / sum;
+            eos_p = (float) exp((double) (last_logit / 0.7f - mx)) / sum;
             if ((tok == a.eos_token || eos_p >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
             if (a.eos_trace) a.eos_trace[step] = eos_p;
         } else {
@@ -649,8 +706,18 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
         st->n_out += 1;
         st->cur_token = tok;
         st->step = step + 1;
-        st->n_past += a.n_past_add;
+        const int np = st->n_past + a.n_past_add;
+        st->n_past = np;
         st->last_eos_p = eos_p;
+        next_tok = tok; next_pos = np;
+    }
+    __syncthreads();
+    // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
+    if (a.x && next_pos < a.P) {
+        const int tok = min(max(next_tok, 0), a.n_in - 1);
+        const half_t * r = a.wte + (size_t) tok * a.E;
+        const float * pe = a.wpe + (size_t) next_pos * a.E;
+        for (int e = tid; e < a.E; e += 1024) a.x[e] = (float) r[e] + pe[e];
     }
 }
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
