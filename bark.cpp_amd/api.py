@@ -68,7 +68,7 @@ EXPORTS = [
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
-    "bark_hip_time_decode_step", "bark_hip_time_fine_pass", "bark_hip_describe",
+    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
 
 
@@ -117,6 +117,8 @@ def load_library() -> C.CDLL:
     lib.bark_hip_get_stats.argtypes = [vp, C.POINTER(BarkHipStats)]
     lib.bark_hip_time_decode_step.restype = C.c_double
     lib.bark_hip_time_decode_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.bark_hip_time_gemv.restype = C.c_double
+    lib.bark_hip_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_time_fine_pass.restype = C.c_double
     lib.bark_hip_time_fine_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_describe.restype = C.c_char_p
@@ -301,6 +303,13 @@ class BarkContext:
         us = self._lib.bark_hip_time_decode_step(self._h, which, ctx, iters, C.byref(b))
         if us < 0:
             raise RuntimeError("bark_hip_time_decode_step failed")
+        return us, b.value
+
+    def time_gemv(self, which: int, op: int, iters: int):
+        b = C.c_double(0)
+        us = self._lib.bark_hip_time_gemv(self._h, which, op, iters, C.byref(b))
+        if us < 0:
+            raise RuntimeError("bark_hip_time_gemv failed")
         return us, b.value
 
     def time_fine_pass(self, iters: int):

@@ -206,6 +206,10 @@ double bark_hip_time_decode_step(struct bark_context * bctx, int which, int ctx,
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_decode_step", -1.0, [&] { return engine_time_decode_step(bctx, which, ctx, iters, bytes_per_step); });
 }
+double bark_hip_time_gemv(struct bark_context * bctx, int which, int op, int iters, double * bytes_per_launch) {
+    if (!bctx) return -1.0;
+    return guarded("bark_hip_time_gemv", -1.0, [&] { return engine_time_gemv(bctx, which, op, iters, bytes_per_launch); });
+}
 double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass) {
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_fine_pass", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass); });

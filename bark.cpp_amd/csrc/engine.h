@@ -106,6 +106,7 @@ std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * cod
 bool engine_generate(bark_context * ctx, const char * text);
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
+double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);
 double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass);
 
 }  // namespace barkhip

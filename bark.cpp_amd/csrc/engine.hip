@@ -939,6 +939,51 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     return (double) ms * 1000.0 / std::max(1, iters);
 }
 
+// One decode GEMV, launched `iters` times back to back while rotating through the layers' weights (so that the
+// stream comes from HBM / Infinity Cache like in a real step, not from a hot L2).  op: 0 LN+QKV, 1 proj,
+// 2 LN+FC+GELU, 3 mlp proj.  Returns the average device time per launch in microseconds.
+double engine_time_gemv(bark_context * c, int which, int op, int iters, double * bytes_per_launch) {
+    if (which < 0 || which > 1 || op < 0 || op > 3) throw std::runtime_error("time_gemv: bad arguments");
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    const int E = m.hp.n_embd, P = c->P;
+    StepState st = fresh_state(); st.n_past = 100; st.cur_token = 1;
+    set_state(c, st);
+    HIP_OK(hipMemsetAsync(c->x, 0, (size_t) E * 4, c->stream));
+    HIP_OK(hipMemsetAsync(c->att, 0, (size_t) E * 2, c->stream));
+    HIP_OK(hipMemsetAsync(c->hbuf, 0, (size_t) 4 * E * 2, c->stream));
+    auto launch = [&](int l) {
+        const GptModel::Layer & L = m.layers[(size_t) l];
+        LinArgs a;
+        a.N = 1;
+        switch (op) {
+            case 0: a.W = L.attn_w; a.M = 3 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b; a.epi = EPI_QKV;
+                    a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.st = c->d_state; break;
+            case 1: a.W = L.proj_w; a.M = E; a.K = E; a.x_f16 = c->att; a.bias = L.proj_b; a.epi = EPI_RESID; a.res = c->x; break;
+            case 2: a.W = L.fc_w; a.M = 4 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.bias = L.fc_b; a.epi = EPI_GELU;
+                    a.out_h = c->hbuf; a.lut = c->d_gelu_lut; break;
+            default: a.W = L.mproj_w; a.M = E; a.K = 4 * E; a.x_f16 = c->hbuf; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = c->x; break;
+        }
+        launch_linear(c->stream, a);
+    };
+    for (int i = 0; i < m.hp.n_layer; i++) launch(i);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) launch(i % m.hp.n_layer);
+    HIP_OK(hipEventRecord(e1, c->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (bytes_per_launch) {
+        const double Ed = E;
+        const double w = op == 0 ? 3 * Ed * Ed : op == 1 ? Ed * Ed : 4 * Ed * Ed;
+        *bytes_per_launch = w * 2.0;          // f16 weight matrix; vectors are < 1 % of it
+    }
+    return (double) ms * 1000.0 / std::max(1, iters);
+}
+
 double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pass) {
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[2];

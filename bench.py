@@ -126,12 +126,26 @@ def main():
             "near_ties": agg["n_near_tie"],
             "prompts_per_s": world * a.steps / dt,
         }
-        # roofline of the dominant unit of work: one semantic decode step (graph of GEMV/attention kernels), HBM-bound
+        # roofline.  Dominant kernel by time: gemv_kernel (decode GEMV, ~45 % of a generate call, profiles/);
+        # its largest instance is the LayerNorm-fused FC GEMV (4 E^2 f16 weights = 4.72 MB per launch).
         try:
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_gemv_fc.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            us, nbytes = ctx.time_gemv(0, 2, 2400)
+            out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<6,LN> (LayerNorm + FC 3072x768 f16 + GELU, decode)",
+                               "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12,
+                               "traffic": traffic, "us_per_launch": us, "bytes_per_launch": nbytes}
+            gem = {}
+            for op, name in enumerate(("ln_qkv", "attn_proj", "ln_fc_gelu", "mlp_proj")):
+                u, nb = ctx.time_gemv(0, op, 1200)
+                gem[name] = {"us": u, "GB/s": nb / (u * 1e-6) / 1e9}
+            out["roofline_gemv_variants"] = gem
             us, nbytes = ctx.time_decode_step(0, 640, 300)
-            out["roofline"] = {"bound": "hbm", "kernel": "semantic decode step @ctx 640 (hipGraph of 63 kernels; dominant: gemv_kernel)",
-                               "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                               "frac": nbytes / (us * 1e-6) / 8e12, "traffic": None, "us_per_launch": us, "bytes_per_launch": nbytes}
+            out["roofline_decode_step"] = {"bound": "hbm", "unit_of_work": "one semantic decode step @ctx 640 (hipGraph: 74 kernels)",
+                                           "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": nbytes / (us * 1e-6) / 8e12, "us_per_step": us, "bytes_per_step": nbytes}
             fus, flops = ctx.time_fine_pass(6)
             out["roofline_fine_pass"] = {"bound": "mfma-f32", "achieved": flops / (fus * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                          "frac": flops / (fus * 1e-6) / 157.3e12, "us_per_pass": fus,
