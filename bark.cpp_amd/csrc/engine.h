@@ -71,6 +71,7 @@ struct bark_context {
     int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;
+    unsigned * d_hmax = nullptr;
     uint16_t * d_gelu_lut = nullptr;
     int max_E = 0, max_H = 0, P = 1024;
     // codec scratch (grown on demand)

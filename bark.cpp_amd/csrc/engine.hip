@@ -263,6 +263,8 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
     ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
     ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
+    ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
+    HIP_OK(hipMemset(ctx->d_hmax, 0, 64 * sizeof(unsigned)));
     {
         std::vector<uint16_t> lut(65536);
         for (uint32_t i = 0; i < 65536; i++) {
@@ -332,7 +334,7 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         launch_linear(s, a);
         AttnDecodeArgs at;
-        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores;
+        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
@@ -358,6 +360,7 @@ void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, i
 }
 
 void set_state(bark_context * c, const StepState & st) {
+    HIP_OK(hipMemsetAsync(c->d_hmax, 0, 64 * sizeof(unsigned), c->stream));     // decode-attention row maxima (kernels.hip)
     HIP_OK(hipMemcpyAsync(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));       // `st` is a stack object
 }
@@ -943,17 +946,33 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
 // stream comes from HBM / Infinity Cache like in a real step, not from a hot L2).  op: 0 LN+QKV, 1 proj,
 // 2 LN+FC+GELU, 3 mlp proj.  Returns the average device time per launch in microseconds.
 double engine_time_gemv(bark_context * c, int which, int op, int iters, double * bytes_per_launch) {
-    if (which < 0 || which > 1 || op < 0 || op > 3) throw std::runtime_error("time_gemv: bad arguments");
+    if (which < 0 || which > 1 || op < 0 || op > 11) throw std::runtime_error("time_gemv: bad arguments");
+    const bool attn = op >= 8;            // 8: attn_scores_kernel, 9: attn_mix_kernel, 10: both (context = n_past + 1 = 641)
+    const int attn_op = op;
+    const bool hot = op >= 4 && !attn;
+    op &= 3;
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[which];
     const int E = m.hp.n_embd, P = c->P;
-    StepState st = fresh_state(); st.n_past = 100; st.cur_token = 1;
+    StepState st = fresh_state(); st.n_past = attn ? 640 : 100; st.cur_token = 1;
     set_state(c, st);
+    if (attn) {
+        HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+        HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+        HIP_OK(hipMemsetAsync(c->q, 0, (size_t) E * 4, c->stream));
+    }
     HIP_OK(hipMemsetAsync(c->x, 0, (size_t) E * 4, c->stream));
     HIP_OK(hipMemsetAsync(c->att, 0, (size_t) E * 2, c->stream));
     HIP_OK(hipMemsetAsync(c->hbuf, 0, (size_t) 4 * E * 2, c->stream));
     auto launch = [&](int l) {
         const GptModel::Layer & L = m.layers[(size_t) l];
+        if (attn) {
+            AttnDecodeArgs at;
+            at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = m.hp.n_head; at.P = P; at.st = c->d_state; at.att = c->att;
+            at.scores = c->scores; at.hmax = c->d_hmax;
+            launch_attn_decode_part(c->stream, at, attn_op == 8 ? 1 : attn_op == 9 ? 2 : attn_op == 10 ? 3 : 4);
+            return;
+        }
         LinArgs a;
         a.N = 1;
         switch (op) {
@@ -966,16 +985,28 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
         }
         launch_linear(c->stream, a);
     };
-    for (int i = 0; i < m.hp.n_layer; i++) launch(i);
+    // op >= 4 ("hot"): always layer 0, so the weights stay in L2; otherwise rotate through the layers.
+    // The launches are captured into one hipGraph (48 nodes) so that the host launch rate does not bound the result.
+    const int per_graph = 48;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < per_graph; i++) launch(hot ? 0 : i % m.hp.n_layer);
+    HIP_OK(hipStreamEndCapture(c->stream, &graph));
+    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void) hipGraphDestroy(graph);
+    HIP_OK(hipGraphLaunch(exec, c->stream));
+    const int reps = std::max(1, iters / per_graph);
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; i++) launch(i % m.hp.n_layer);
+    for (int i = 0; i < reps; i++) HIP_OK(hipGraphLaunch(exec, c->stream));
     HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    (void) hipGraphExecDestroy(exec);
+    iters = reps * per_graph;
     if (bytes_per_launch) {
         const double Ed = E;
         const double w = op == 0 ? 3 * Ed * Ed : op == 1 ? Ed * Ed : 4 * Ed * Ed;

@@ -73,8 +73,10 @@ struct AttnDecodeArgs {
     const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
     float * scores = nullptr;             // scratch [H][P]
+    unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
+void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts);   // 1 scores, 2 mix, 3 both (timing hook)
 
 // Multi-query attention (prefill / fine): N queries at positions n_past.., keys 0..n_past+N-1.
 struct AttnPrefillArgs {

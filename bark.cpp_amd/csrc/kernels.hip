@@ -49,14 +49,26 @@ DEVINL double group16_sum(double v) {
     v += dpp_f64<DPP_XOR1>(v); v += dpp_f64<DPP_XOR2>(v); v += dpp_f64<DPP_HALF_MIRROR>(v); v += dpp_f64<DPP_MIRROR>(v);
     return v;
 }
+DEVINL float readlane_f32(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+DEVINL double readlane_f64(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, lane);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+// whole-wave reductions: DPP inside each 16-lane row, then the four row results through SGPRs
 DEVINL double wave_sum(double v) {
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = group16_sum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 DEVINL float wave_max(float v) {
-    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
+// order-preserving float <-> unsigned map, so that the row maximum can be kept with an integer atomicMax
+DEVINL unsigned f32_ordered(float f) { const unsigned b = __builtin_bit_cast(unsigned, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+DEVINL float f32_unordered(unsigned u) { const unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; return __builtin_bit_cast(float, b); }
 DEVINL half8 ld_half8(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
 // f32 -> f16, round to nearest even, of an ALREADY ROUNDED f32 value.  The empty asm keeps hipcc from
 // folding the producing multiply/add into v_fma_mixlo_f16, which rounds the exact result once and
@@ -156,24 +168,26 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
             if constexpr (LNB) { ba[b][0] = *reinterpret_cast<const float4 *>(a.ln_b + k0); ba[b][1] = *reinterpret_cast<const float4 *>(a.ln_b + k0 + 4); }
         }
         // ggml_norm (+mul, +add): double sums, eps on the variance (bark.cpp:1265-1274)
+        // (four partial sums per lane keep the fp64 add chains short; the order of a double sum of floats
+        // changes the rounded float mean / variance with probability ~2^-29)
         float xr[NBLK][8];
-        double s1 = 0.0;
+        double p1[4] = {0.0, 0.0, 0.0, 0.0};
         #pragma unroll
         for (int b = 0; b < NBLK; b++) {
             xr[b][0] = xa[b][0].x; xr[b][1] = xa[b][0].y; xr[b][2] = xa[b][0].z; xr[b][3] = xa[b][0].w;
             xr[b][4] = xa[b][1].x; xr[b][5] = xa[b][1].y; xr[b][6] = xa[b][1].z; xr[b][7] = xa[b][1].w;
             #pragma unroll
-            for (int e = 0; e < 8; e++) s1 += (double) xr[b][e];
+            for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
         }
-        s1 = group16_sum(s1);
+        const double s1 = group16_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
         const float mean = (float) (s1 / (double) K);
-        double s2 = 0.0;
+        double p2[4] = {0.0, 0.0, 0.0, 0.0};
         #pragma unroll
         for (int b = 0; b < NBLK; b++) {
             #pragma unroll
-            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; s2 += (double) (v * v); }
+            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; p2[e & 3] += (double) (v * v); }
         }
-        s2 = group16_sum(s2);
+        const double s2 = group16_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
         const float var = (float) (s2 / (double) K);
         const float scale = 1.0f / sqrtf(var + 1e-5f);
         #pragma unroll
@@ -279,32 +293,42 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     for (int s = 0; s < 2; s++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++)
         for (int r = 0; r < 16; r++) acc[s][i][j][r] = 0.0f;
 
-    for (int b = 0; b < nblk; b++) {
-        #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int koff = ((b * 16 + 2 * w + s) << 3);
-            half8 xa[2], wb[2];
-            #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                xa[t] = ld_half8(a.x_f16 + (size_t) nrow[t] * K + koff);
-                wb[t] = ld_half8(a.W + (size_t) mrow[t] * K + koff);
-            }
-            #pragma unroll
-            for (int kp = 0; kp < 4; kp++) {
-                float av[2], bv[2];
-                #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    av[t] = half ? (float) xa[t][2 * kp + 1] : (float) xa[t][2 * kp];
-                    bv[t] = half ? (float) wb[t][2 * kp + 1] : (float) wb[t][2 * kp];
-                }
-                #pragma unroll
-                for (int i = 0; i < 2; i++)
-                    #pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[s][i][j], 0, 0, 0);
-            }
-        }
+    // operands of one K block (both chains of this wave): [chain][row tile]; double buffered so that the
+    // loads of block b+1 are in flight while the 32 MFMAs of block b issue
+    // (buffer indices are compile-time constants: runtime-indexed register arrays would go to scratch)
+    half8 xa0[2][2], wb0[2][2], xa1[2][2], wb1[2][2];
+#define GEMM_LOAD_BLOCK(XA, WB, B)                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
+        const int koff = (((B) * 16 + 2 * w + s) << 3);                                                  \
+        _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                  \
+            XA[s][t] = ld_half8(a.x_f16 + (size_t) nrow[t] * K + koff);                                  \
+            WB[s][t] = ld_half8(a.W + (size_t) mrow[t] * K + koff);                                      \
+        }                                                                                                \
     }
+#define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
+        _Pragma("unroll") for (int kp = 0; kp < 4; kp++) {                                               \
+            float av[2], bv[2];                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) {                                              \
+                av[t] = half ? (float) XA[s][t][2 * kp + 1] : (float) XA[s][t][2 * kp];                  \
+                bv[t] = half ? (float) WB[s][t][2 * kp + 1] : (float) WB[s][t][2 * kp];                  \
+            }                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 2; i++)                                                \
+                _Pragma("unroll") for (int j = 0; j < 2; j++)                                            \
+                    acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[s][i][j], 0, 0, 0); \
+        }                                                                                                \
+    }
+    GEMM_LOAD_BLOCK(xa0, wb0, 0)
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+        GEMM_LOAD_BLOCK(xa1, wb1, b + 1)
+        GEMM_MFMA_BLOCK(xa0, wb0)
+        if (b + 2 < nblk) { GEMM_LOAD_BLOCK(xa0, wb0, b + 2) }
+        GEMM_MFMA_BLOCK(xa1, wb1)
+    }
+    if (b < nblk) { GEMM_MFMA_BLOCK(xa0, wb0) }
+#undef GEMM_LOAD_BLOCK
+#undef GEMM_MFMA_BLOCK
     // chain pair (2w, 2w+1) -> LDS; accumulator register r of lane l holds row (r&3)+8(r>>2)+4*half, col l31
     float * mine = lds + (size_t) w * (GEMM_TN * GEMM_TM);
     #pragma unroll
@@ -461,18 +485,22 @@ __global__ __launch_bounds__(64) void attn_scores_kernel(const AttnDecodeArgs a)
         acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
         acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
     }
-    if (j < ctx) a.scores[(size_t) h * P + j] = acc * 0.125f;          // 1/sqrt(64), bark.cpp:1318
+    const float sc = acc * 0.125f;                                       // 1/sqrt(64), bark.cpp:1318
+    if (j < ctx) a.scores[(size_t) h * P + j] = sc;
+    // row maximum for the softmax, kept exactly with an integer atomic (a.hmax[h] is reset by attn_mix_kernel)
+    const float wmax = wave_max(j < ctx ? sc : -INFINITY);
+    if (threadIdx.x == 0 && blockIdx.x * 64 < ctx) atomicMax(a.hmax + h, f32_ordered(wmax));
 }
 
 __global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) {
-    __shared__ float ps[1024];
-    __shared__ float red_f[16];
+    __shared__ float es[1024];
     __shared__ double red_d[16];
     __shared__ float part[16][64];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
     const int ctx = a.st->n_past + 1;
     const float sraw = a.scores[(size_t) h * P + tid];                // tid < P; garbage beyond ctx is masked below
+    const float mx = f32_unordered(a.hmax[h]);
     const float * vp = a.vc + (size_t) h * P * 64 + lane;
     float vv[64];
     #pragma unroll
@@ -482,30 +510,23 @@ __global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) 
             for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (wave + 16 * (16 * g + i)) * 64];   // row < P
         }
     }
-    const float s = tid < ctx ? sraw : -INFINITY;
-    float mx = wave_max(s);
-    if (lane == 0) red_f[wave] = mx;
-    __syncthreads();
-    mx = red_f[0];
-    #pragma unroll
-    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
     float e = 0.0f;
-    if (tid < ctx) e = (float) exp((double) (s - mx));
-    double sum = wave_sum((double) e);
-    if (lane == 0) red_d[wave] = sum;
+    if (tid < ctx) e = (float) exp((double) (sraw - mx));
+    es[tid] = e;
+    const double wsum = wave_sum((double) e);
+    if (lane == 0) red_d[wave] = wsum;
     __syncthreads();
-    sum = 0.0;
+    if (tid == 0) a.hmax[h] = 0u;                                      // below every encoded float: ready for the next layer
+    double sum = 0.0;
     #pragma unroll
     for (int i = 0; i < 16; i++) sum += red_d[i];
     const float inv = (float) (1.0 / sum);
-    ps[tid] = e * inv;
-    __syncthreads();
     float acc = 0.0f;
     #pragma unroll
     for (int g = 0; g < 4; g++) {
         if (g == 0 || ctx > 256 * g) {
             #pragma unroll
-            for (int i = 0; i < 16; i++) { const int j = wave + 16 * (16 * g + i); if (j < ctx) acc = fmaf(vv[16 * g + i], ps[j], acc); }
+            for (int i = 0; i < 16; i++) { const int j = wave + 16 * (16 * g + i); if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc); }
         }
     }
     part[wave][lane] = acc;
@@ -521,9 +542,116 @@ __global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) 
         a.att[h * 64 + tid] = to_half(p[0]);
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Fused decode attention: ONE launch, one 256-thread workgroup (4 waves, one per SIMD, up to 512
+// registers each) per head.  With a 1.7 us launch floor a second launch costs more than pulling the
+// head's K rows through the same CU, so scores, softmax and mix share a kernel:
+//   scores : thread t owns keys t, t+256, t+512, t+768 (C2: one fmaf chain over d per key)
+//   softmax: row max / double sum through LDS (two barriers)
+//   mix    : wave w, 16-lane group g own chain c = 4w+g of C5; lane&15 owns 4 adjacent dims (float4 V
+//            loads, so one instruction covers four keys); the 16 chains meet in LDS (tree order)
+// K is loaded two 256-key groups ahead, every V row group of the live context is requested before the
+// first arithmetic instruction.
+// ------------------------------------------------------------------------------------------------
+template <int G> DEVINL void load_k_group(float4 (&kv)[16], const float4 * kp, int P) {
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P + 256 * G];
+}
+DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) {
+    float acc = 0.0f;
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) {
+        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
+        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
+        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
+        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
+    }
+    return acc * 0.125f;                                      // 1/sqrt(64), bark.cpp:1318
+}
+__global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    __shared__ float part[16][64];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+    const int chain = 4 * wave + (lane >> 4), d4 = lane & 15;
+    const float4 * vp = reinterpret_cast<const float4 *>(a.vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;   // row `chain`, dims 4*d4..
+    float4 k0[16], k1[16];
+    load_k_group<0>(k0, kp, P);                                // keys 0..255: always inside the cache
+    const int ctx = a.st->n_past + 1;
+    if (ctx > 256) load_k_group<1>(k1, kp, P);
+    float4 vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 256];     // key chain + 16*(16g+i): 16 rows = 256 float4
+        }
+    }
+    float s[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    { const float v = score_chain(k0, qh); if (tid < ctx) s[0] = v; }
+    if (ctx > 512) load_k_group<2>(k0, kp, P);
+    if (ctx > 256) { const float v = score_chain(k1, qh); if (tid + 256 < ctx) s[1] = v; }
+    if (ctx > 768) load_k_group<3>(k1, kp, P);
+    if (ctx > 512) { const float v = score_chain(k0, qh); if (tid + 512 < ctx) s[2] = v; }
+    if (ctx > 768) { const float v = score_chain(k1, qh); if (tid + 768 < ctx) s[3] = v; }
+    float mx = wave_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = tid + 256 * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    const float inv = (float) (1.0 / sum);
+    float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int j = chain + 16 * (16 * g + i);
+                if (j < ctx) {
+                    const float p = es[j] * inv;               // p = e * (float)(1/sum), as ggml_soft_max scales in place
+                    const float4 v = vv[16 * g + i];
+                    acc.x = fmaf(v.x, p, acc.x); acc.y = fmaf(v.y, p, acc.y); acc.z = fmaf(v.z, p, acc.z); acc.w = fmaf(v.w, p, acc.w);
+                }
+            }
+        }
+    }
+    *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        a.att[h * 64 + tid] = to_half(p[0]);
+    }
+}
+
+void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
+    if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H), dim3(256), 0, s, a); return; }
+    if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
+    if (parts & 2) hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
+}
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
-    hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
+    static const bool split = getenv("BARK_HIP_ATTN_SPLIT") != nullptr;      // two-launch variant kept for A/B timing
+    launch_attn_decode_part(s, a, split ? 3 : 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,34 +660,51 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
 // 8 waves x 2 accumulator sets, LDS tree).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_qk_kernel(const AttnPrefillArgs a) {
-    const int h = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    // workgroup tile 128 queries x 128 keys; wave (wi, wj) owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles, so every
+    // 16-byte operand load feeds four MFMAs
+    const int h = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
     const int ctx = a.n_past + a.N;
     if (j0 >= ctx) return;
-    if (a.causal && j0 > a.n_past + i0 + 63) return;        // tile entirely masked
+    if (a.causal && j0 > a.n_past + i0 + 127) return;       // tile entirely masked
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int it = w >> 1, jt = w & 1;
-    const int irow = min(i0 + it * 32 + l31, a.N - 1);
-    const int jrow = min(j0 + jt * 32 + l31, ctx - 1);
-    const float4 * qp = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
-    floatx16 acc;
+    const int wi = w >> 1, wj = w & 1;
+    const float4 * qp[2]; const float4 * kp[2];
     #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int t = 0; t < 2; t++) {
+        const int irow = min(i0 + wi * 64 + t * 32 + l31, a.N - 1);
+        const int jrow = min(j0 + wj * 64 + t * 32 + l31, ctx - 1);
+        qp[t] = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
+        kp[t] = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
+    }
+    floatx16 acc[2][2];
     #pragma unroll
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    #pragma unroll 4
     for (int dq = 0; dq < 16; dq++) {
-        const float4 qv = qp[dq], kv = kp[(size_t) dq * a.P];
+        float4 qv[2], kv[2];
+        #pragma unroll
+        for (int t = 0; t < 2; t++) { qv[t] = qp[t][dq]; kv[t] = kp[t][(size_t) dq * a.P]; }
         // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv.y : qv.x, half ? kv.y : kv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv.w : qv.z, half ? kv.w : kv.z, acc, 0, 0, 0);
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].y : qv[i].x, half ? kv[j].y : kv[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].w : qv[i].z, half ? kv[j].w : kv[j].z, acc[i][j], 0, 0, 0);
+            }
     }
     // A operand = Q (accumulator rows = queries i), B operand = K (accumulator cols = keys j: coalesced stores)
     #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int i = i0 + it * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int j = j0 + jt * 32 + l31;
-        if (i < a.N && j < ctx) a.scores[((size_t) h * a.N + i) * a.P + j] = acc[r] * 0.125f;    // 1/sqrt(64), bark.cpp:1318
-    }
+    for (int ti = 0; ti < 2; ti++)
+        #pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wi * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int j = j0 + wj * 64 + tj * 32 + l31;
+                if (i < a.N && j < ctx) a.scores[((size_t) h * a.N + i) * a.P + j] = acc[ti][tj][r] * 0.125f;    // 1/sqrt(64), bark.cpp:1318
+            }
 }
 
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const AttnPrefillArgs a) {
@@ -596,16 +741,20 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
     floatx16 acc[2][2];
     #pragma unroll
     for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
+    const int jlim = (jend + 1) & ~1;                            // P rows are zero-filled up to a multiple of 32 keys
+    #pragma unroll 2
     for (int jb = 0; jb < jend; jb += 32) {
+        const int j = jb + 2 * w + 16 * half;                   // chains 2w, 2w+1: keys j, j+1 (this half-wave's k slot)
+        const bool ok = j < jlim;
+        const float2 p2 = ok ? *reinterpret_cast<const float2 *>(prow + j) : float2{0.0f, 0.0f};
         #pragma unroll
         for (int s = 0; s < 2; s++) {
-            const int j = jb + 2 * w + s + 16 * half;           // chain 2w+s: keys jb+c, jb+16+c
-            const bool ok = j < jend;
-            const float pv = ok ? prow[j] : 0.0f;
+            const bool oks = j + s < jend;
+            const float pv = s ? p2.y : p2.x;
             #pragma unroll
             for (int t = 0; t < 2; t++) {
-                const float vv = ok ? vbase[(size_t) j * 64 + t * 32 + l31] : 0.0f;
-                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, vv, acc[s][t], 0, 0, 0);
+                const float vv = oks ? vbase[(size_t) (j + s) * 64 + t * 32 + l31] : 0.0f;
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(oks ? pv : 0.0f, vv, acc[s][t], 0, 0, 0);
             }
         }
     }
@@ -630,7 +779,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
 
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
     const int ctx = a.n_past + a.N;
-    hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 63) / 64, (a.N + 63) / 64, a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 127) / 128, (a.N + 127) / 128, a.H), dim3(256), 0, s, a);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.H * a.N + 3) / 4), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_pv_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 0, s, a);
 }
