@@ -307,24 +307,34 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     }
 #define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
+        uint4 xu[2], wu[2];                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 2; t++) { xu[t] = __builtin_bit_cast(uint4, XA[s][t]); wu[t] = __builtin_bit_cast(uint4, WB[s][t]); } \
         _Pragma("unroll") for (int kp = 0; kp < 4; kp++) {                                               \
             float av[2], bv[2];                                                                          \
             _Pragma("unroll") for (int t = 0; t < 2; t++) {                                              \
-                av[t] = half ? (float) XA[s][t][2 * kp + 1] : (float) XA[s][t][2 * kp];                  \
-                bv[t] = half ? (float) WB[s][t][2 * kp + 1] : (float) WB[s][t][2 * kp];                  \
+                const unsigned xr = kp == 0 ? xu[t].x : kp == 1 ? xu[t].y : kp == 2 ? xu[t].z : xu[t].w; \
+                const unsigned wr = kp == 0 ? wu[t].x : kp == 1 ? wu[t].y : kp == 2 ? wu[t].z : wu[t].w; \
+                av[t] = (float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16));               \
+                bv[t] = (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16));               \
             }                                                                                            \
             _Pragma("unroll") for (int i = 0; i < 2; i++)                                                \
                 _Pragma("unroll") for (int j = 0; j < 2; j++)                                            \
                     acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[s][i][j], 0, 0, 0); \
         }                                                                                                \
     }
+    // lanes 32-63 feed the odd element of each f16 pair (the MFMA's second k slot): one per-lane shift selects it
+    const unsigned sh16 = half ? 16u : 0u;
     GEMM_LOAD_BLOCK(xa0, wb0, 0)
     int b = 0;
     for (; b + 1 < nblk; b += 2) {
         GEMM_LOAD_BLOCK(xa1, wb1, b + 1)
+        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
         GEMM_MFMA_BLOCK(xa0, wb0)
+        __builtin_amdgcn_sched_barrier(0);
         if (b + 2 < nblk) { GEMM_LOAD_BLOCK(xa0, wb0, b + 2) }
+        __builtin_amdgcn_sched_barrier(0);
         GEMM_MFMA_BLOCK(xa1, wb1)
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (b < nblk) { GEMM_MFMA_BLOCK(xa0, wb0) }
 #undef GEMM_LOAD_BLOCK
@@ -341,19 +351,68 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
                 mine[row * GEMM_TM + col] = acc[0][i][j][r] + acc[1][i][j][r];
             }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < GEMM_TN * GEMM_TM; idx += 512) {
-        const int row = idx >> 6, col = idx & 63;
-        const int n = n0 + row, m = m0 + col;
-        float p[8];
+    // each thread finishes 2 x 4 adjacent outputs: every epilogue operand is fetched as one 16-byte access and all
+    // of them are requested before the first is used
+    float4 bias4[2], res4[2];
+    int nn[2], mm[2];
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int idx4 = threadIdx.x + 512 * r;
+        nn[r] = n0 + (idx4 >> 4); mm[r] = m0 + ((idx4 & 15) << 2);
+        const bool ok = nn[r] < a.N && mm[r] < a.M;
+        bias4[r] = (a.bias && ok) ? *reinterpret_cast<const float4 *>(a.bias + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
+        res4[r] = (a.epi == EPI_RESID && ok) ? *reinterpret_cast<const float4 *>(a.res + (size_t) nn[r] * a.M + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int idx4 = threadIdx.x + 512 * r;
+        float4 p[8];
         #pragma unroll
-        for (int q = 0; q < 8; q++) p[q] = lds[q * (GEMM_TN * GEMM_TM) + idx];
-        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        if (n < a.N && m < a.M) linear_epilogue(a, n, m, v, 0);
+        for (int q = 0; q < 8; q++) p[q] = *reinterpret_cast<const float4 *>(lds + q * (GEMM_TN * GEMM_TM) + idx4 * 4);
+        float v[4];
+        v[0] = ((p[0].x + p[1].x) + (p[2].x + p[3].x)) + ((p[4].x + p[5].x) + (p[6].x + p[7].x));
+        v[1] = ((p[0].y + p[1].y) + (p[2].y + p[3].y)) + ((p[4].y + p[5].y) + (p[6].y + p[7].y));
+        v[2] = ((p[0].z + p[1].z) + (p[2].z + p[3].z)) + ((p[4].z + p[5].z) + (p[6].z + p[7].z));
+        v[3] = ((p[0].w + p[1].w) + (p[2].w + p[3].w)) + ((p[4].w + p[5].w) + (p[6].w + p[7].w));
+        const int n = nn[r], m = mm[r];
+        if (n >= a.N || m >= a.M) continue;
+        if (a.bias) { v[0] = v[0] + bias4[r].x; v[1] = v[1] + bias4[r].y; v[2] = v[2] + bias4[r].z; v[3] = v[3] + bias4[r].w; }
+        switch (a.epi) {
+            case EPI_QKV: {
+                const int E = a.E;
+                float4 o = {v[0], v[1], v[2], v[3]};
+                if (m < E) { *reinterpret_cast<float4 *>(a.q + (size_t) n * E + m) = o; break; }
+                const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
+                const int m2 = m < 2 * E ? m - E : m - 2 * E;
+                const int h = m2 >> 6, d = m2 & 63;                     // d is a multiple of 4: one d-quad of the K layout
+                if (m < 2 * E) *reinterpret_cast<float4 *>(a.kc + kc_index(h, d, pos, a.P)) = o;
+                else           *reinterpret_cast<float4 *>(a.vc + vc_index(h, d, pos, a.P)) = o;
+                break;
+            }
+            case EPI_RESID: {                                           // cur + inpL (bark.cpp:1352,1388)
+                float4 o = {v[0] + res4[r].x, v[1] + res4[r].y, v[2] + res4[r].z, v[3] + res4[r].w};
+                *reinterpret_cast<float4 *>(a.res + (size_t) n * a.M + m) = o;
+                break;
+            }
+            case EPI_GELU: {
+                half_t g[4];
+                #pragma unroll
+                for (int e = 0; e < 4; e++) g[e] = gelu_lut_apply(v[e], a.lut);
+                *reinterpret_cast<uint2 *>(a.out_h + (size_t) n * a.M + m) = __builtin_bit_cast(uint2, g);
+                break;
+            }
+            default: {
+                float4 o = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4 *>(a.out + (size_t) n * a.ld_out + m) = o;
+                break;
+            }
+        }
     }
 }
 
 void launch_linear(hipStream_t s, const LinArgs & a) {
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
+    if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
     const int nblk = a.K >> 7;
     if (a.N == 1) {
         switch (nblk) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
