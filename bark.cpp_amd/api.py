@@ -67,7 +67,7 @@ EXPORTS = [
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
-    "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
+    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
 
@@ -111,6 +111,9 @@ def load_library() -> C.CDLL:
     lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip]
     lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
+    lib.bark_hip_clone_context.restype = vp
+    lib.bark_hip_clone_context.argtypes = [vp, C.c_uint32]
+    lib.bark_hip_generate_audio_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_char_p), C.c_int]
     lib.bark_hip_get_semantic_tokens.argtypes = [vp, ip, C.c_int]
     lib.bark_hip_get_coarse_tokens.argtypes = [vp, ip, C.c_int]
     lib.bark_hip_get_fine_tokens.argtypes = [vp, ip, C.c_int]
@@ -277,6 +280,21 @@ class BarkContext:
         if n < 0:
             raise RuntimeError("bark_hip_codec_tap failed")
         return out[:n].copy()
+
+    def clone(self, seed: int = 0) -> "BarkContext":
+        h = self._lib.bark_hip_clone_context(self._h, seed)
+        if not h:
+            raise RuntimeError("bark_hip_clone_context failed")
+        return BarkContext(h, self._lib)
+
+    @staticmethod
+    def generate_audio_batch(ctxs, texts) -> int:
+        lib = load_library()
+        n = len(ctxs)
+        assert n == len(texts) and n > 0
+        hs = (C.c_void_p * n)(*[c._h for c in ctxs])
+        ts = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        return int(lib.bark_hip_generate_audio_batch(hs, ts, n))
 
     def semantic_tokens(self) -> np.ndarray:
         out = np.zeros(1024, np.int32)

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 using namespace barkhip;
 
@@ -188,6 +190,23 @@ int bark_hip_codec_tap(struct bark_context * bctx, const int32_t * codes, int n_
         memcpy(out, tap.data(), tap.size() * 4);
         return (int) tap.size();
     });
+}
+
+struct bark_context * bark_hip_clone_context(struct bark_context * src, uint32_t seed) {
+    if (!src) return nullptr;
+    return guarded("bark_hip_clone_context", (bark_context *) nullptr, [&] { return engine_clone(src, seed); });
+}
+
+int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * const * texts, int n) {
+    if (!ctxs || !texts || n <= 0) return 0;
+    std::vector<char> ok((size_t) n, 0);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; i++)
+        th.emplace_back([&, i] { ok[(size_t) i] = (ctxs[i] && texts[i]) ? (char) guarded("bark_hip_generate_audio_batch", false, [&] { return engine_generate(ctxs[i], texts[i]); }) : 0; });
+    for (auto & t : th) t.join();
+    int good = 0;
+    for (char c : ok) good += c;
+    return good;
 }
 
 static int copy_out(const std::vector<int32_t> & v, int per_row, int32_t * out, int capacity_rows) {

@@ -62,8 +62,11 @@ struct bark_context {
     hipStream_t stream = nullptr;
     bool use_graph = true;
 
-    // device memory
-    void * weight_slab = nullptr; size_t weight_bytes = 0;
+    // device memory.  The weight slab (and the codec codebooks) are immutable after load and shared by every
+    // context cloned from this one (bark_hip_clone_context): replicas on one GPU stream the same bytes.
+    struct SharedWeights { void * slab = nullptr; void * codebooks = nullptr; int device = 0; ~SharedWeights(); };
+    std::shared_ptr<SharedWeights> weights;
+    size_t weight_bytes = 0;
     std::vector<void *> allocs;                         // everything else (freed in destroy)
     // GPT scratch
     float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
@@ -94,6 +97,7 @@ namespace barkhip {
 
 // All functions throw std::runtime_error on failure; the C API catches at the boundary.
 bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed);
+bark_context * engine_clone(bark_context * src, uint32_t seed);          // same weights, own stream / caches / scratch
 void engine_invalidate_graphs(bark_context * ctx);
 
 int  engine_gpt_eval(bark_context * ctx, int which, const int32_t * tokens, int n_tokens, int n_past, bool merge_ctx, float * logits);

@@ -86,8 +86,12 @@ bark_context::~bark_context() {
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
     for (void * p : allocs) (void) hipFree(p);
-    if (weight_slab) (void) hipFree(weight_slab);
     if (stream) (void) hipStreamDestroy(stream);
+}
+bark_context::SharedWeights::~SharedWeights() {
+    (void) hipSetDevice(device);
+    if (slab) (void) hipFree(slab);
+    if (codebooks) (void) hipFree(codebooks);
 }
 
 namespace barkhip {
@@ -96,6 +100,52 @@ void engine_invalidate_graphs(bark_context * ctx) {
     for (auto & g : ctx->gpt) {
         if (g.decode_graph) { (void) hipGraphExecDestroy(g.decode_graph); g.decode_graph = nullptr; }
         if (g.bench_graph) { (void) hipGraphExecDestroy(g.bench_graph); g.bench_graph = nullptr; }
+    }
+}
+
+// per-context mutable state: stream, KV caches, activation scratch, GELU table
+static void init_runtime(bark_context * ctxp) {
+    struct Holder { bark_context * p; bark_context * get() const { return p; } bark_context * operator->() const { return p; } } ctx{ctxp};
+    // ---- KV caches, scratch ------------------------------------------------------------------------
+    const int P = ctx->P;
+    for (int g = 0; g < 2; g++) {
+        GptModel & m = ctx->gpt[g];
+        m.kv_layer_stride = (size_t) m.hp.n_embd * P;
+        m.kcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);     // bark.cpp:976-991
+        m.vcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);
+    }
+    {
+        GptModel & m = ctx->gpt[2];
+        m.kv_layer_stride = 0;
+        m.kcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
+        m.vcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
+    }
+    const size_t NE = (size_t) P * ctx->max_E;
+    ctx->x = dev_alloc<float>(ctx.get(), NE);
+    ctx->q = dev_alloc<float>(ctx.get(), NE);
+    ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
+    ctx->att = dev_alloc<half_t>(ctx.get(), NE);
+    ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
+    ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
+    size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
+    for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
+    ctx->logits = dev_alloc<float>(ctx.get(), n_logits);
+    ctx->d_tokens = dev_alloc<int32_t>(ctx.get(), 8 * 1024);
+    ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
+    ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
+    ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
+    ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
+    HIP_OK(hipMemset(ctx->d_hmax, 0, 64 * sizeof(unsigned)));
+    {
+        std::vector<uint16_t> lut(65536);
+        for (uint32_t i = 0; i < 65536; i++) {
+            const uint16_t bits = (uint16_t) i;
+            const _Float16 h = __builtin_bit_cast(_Float16, bits);
+            const _Float16 r = (_Float16) gelu_tanh_host((float) h);
+            lut[i] = __builtin_bit_cast(uint16_t, r);
+        }
+        ctx->d_gelu_lut = dev_alloc<uint16_t>(ctx.get(), 65536);
+        HIP_OK(hipMemcpy(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice));
     }
 }
 
@@ -209,7 +259,9 @@ bark_context * engine_load(const char * path, const bark_context_params & params
 
     // ---- upload ------------------------------------------------------------------------------------
     ctx->weight_bytes = plan.total;
-    HIP_OK(hipMalloc(&ctx->weight_slab, plan.total));
+    ctx->weights = std::make_shared<bark_context::SharedWeights>();
+    ctx->weights->device = ctx->device;
+    HIP_OK(hipMalloc(&ctx->weights->slab, plan.total));
     {
         // stage through pinned memory in 32 MiB pieces (the mapping is pageable and possibly unaligned)
         const size_t kStage = 32u << 20;
@@ -219,15 +271,17 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             for (size_t done = 0; done < it.bytes; done += kStage) {
                 const size_t n = std::min(kStage, it.bytes - done);
                 memcpy(stage, it.src + done, n);
-                HIP_OK(hipMemcpy((uint8_t *) ctx->weight_slab + it.off + done, stage, n, hipMemcpyHostToDevice));
+                HIP_OK(hipMemcpy((uint8_t *) ctx->weights->slab + it.off + done, stage, n, hipMemcpyHostToDevice));
             }
         }
         (void) hipHostFree(stage);
     }
-    for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weight_slab + f.off;
+    for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weights->slab + f.off;
     {
         const size_t per = (size_t) cm.hp.n_bins * cm.hp.hidden_dim;
-        float * cb = dev_alloc<float>(ctx.get(), per * cm.n_q);
+        float * cb = nullptr;
+        HIP_OK(hipMalloc((void **) &cb, per * cm.n_q * sizeof(float)));
+        ctx->weights->codebooks = cb;
         for (int q = 0; q < cm.n_q; q++) {
             const TensorRef & t = need(mf.codec, "quantizer.vq.layers." + std::to_string(q) + "._codebook.embed", 0, cm.hp.hidden_dim, cm.hp.n_bins);
             HIP_OK(hipMemcpy(cb + per * q, t.data, per * 4, hipMemcpyHostToDevice));
@@ -235,47 +289,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         cm.codebooks = cb;
     }
 
-    // ---- KV caches, scratch ------------------------------------------------------------------------
-    const int P = ctx->P;
-    for (int g = 0; g < 2; g++) {
-        GptModel & m = ctx->gpt[g];
-        m.kv_layer_stride = (size_t) m.hp.n_embd * P;
-        m.kcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);     // bark.cpp:976-991
-        m.vcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);
-    }
-    {
-        GptModel & m = ctx->gpt[2];
-        m.kv_layer_stride = 0;
-        m.kcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
-        m.vcache = dev_alloc<float>(ctx.get(), (size_t) m.hp.n_embd * P);
-    }
-    const size_t NE = (size_t) P * ctx->max_E;
-    ctx->x = dev_alloc<float>(ctx.get(), NE);
-    ctx->q = dev_alloc<float>(ctx.get(), NE);
-    ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
-    ctx->att = dev_alloc<half_t>(ctx.get(), NE);
-    ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
-    ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
-    size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
-    for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
-    ctx->logits = dev_alloc<float>(ctx.get(), n_logits);
-    ctx->d_tokens = dev_alloc<int32_t>(ctx.get(), 8 * 1024);
-    ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
-    ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
-    ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
-    ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
-    HIP_OK(hipMemset(ctx->d_hmax, 0, 64 * sizeof(unsigned)));
-    {
-        std::vector<uint16_t> lut(65536);
-        for (uint32_t i = 0; i < 65536; i++) {
-            const uint16_t bits = (uint16_t) i;
-            const _Float16 h = __builtin_bit_cast(_Float16, bits);
-            const _Float16 r = (_Float16) gelu_tanh_host((float) h);
-            lut[i] = __builtin_bit_cast(uint16_t, r);
-        }
-        ctx->d_gelu_lut = dev_alloc<uint16_t>(ctx.get(), 65536);
-        HIP_OK(hipMemcpy(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice));
-    }
+    init_runtime(ctx.get());
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, ctx->device));
     char buf[512];
@@ -284,6 +298,27 @@ bark_context * engine_load(const char * path, const bark_context_params & params
              ctx->gpt[2].hp.n_embd, ctx->gpt[0].hp.n_layer, ctx->gpt[1].hp.n_layer, ctx->gpt[2].hp.n_layer, (int) ctx->use_graph);
     ctx->description = buf;
     if (params.verbosity >= MEDIUM) fprintf(stderr, "%s\n", buf);
+    return ctx.release();
+}
+
+bark_context * engine_clone(bark_context * src, uint32_t seed) {
+    HIP_OK(hipSetDevice(src->device));
+    std::unique_ptr<bark_context> ctx(new bark_context());
+    ctx->params = src->params;
+    ctx->rng = std::mt19937(seed);
+    ctx->vocab = src->vocab;
+    for (int g = 0; g < 3; g++) {
+        ctx->gpt[g] = src->gpt[g];
+        ctx->gpt[g].kcache = ctx->gpt[g].vcache = nullptr;
+        ctx->gpt[g].decode_graph = ctx->gpt[g].bench_graph = nullptr;
+    }
+    ctx->codec = src->codec;
+    ctx->device = src->device; ctx->use_graph = src->use_graph;
+    ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
+    ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P;
+    HIP_OK(hipStreamCreate(&ctx->stream));
+    init_runtime(ctx.get());
+    ctx->description = src->description + " (clone)";
     return ctx.release();
 }
 
@@ -309,6 +344,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal) {
         AttnPrefillArgs at;
         at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = 0;
         at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E;
+        { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
         LinArgs p;
         p.W = L.proj_w; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;

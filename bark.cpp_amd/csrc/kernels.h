@@ -84,6 +84,7 @@ struct AttnPrefillArgs {
     int H = 0, P = 0, N = 0, n_past = 0; int causal = 1;
     float * scores = nullptr;              // scratch [H][N][P]
     half_t * att = nullptr; int ld_att = 0;
+    int dbg = 0;                          // timing experiments only (BARK_HIP_ATTN_DBG): 1 skip scores, 2 skip exp, 4 skip mix
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 

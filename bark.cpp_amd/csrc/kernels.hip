@@ -836,7 +836,171 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused prefill / fine attention: one workgroup (8 waves) per (head, 32-query tile); the 32 x ctx score tile
+// lives in LDS (row stride 1026 floats: conflict-free column reads), so scores never travel through HBM:
+//   1. S = 0.125 * Q K^T   f32 MFMA, wave w takes key tiles w, w+8, ... (C2: one accumulator chain over d)
+//   2. row softmax in LDS   (4 rows per wave; max, e = (float) exp((double)(s - max)), double sum)
+//   3. O = P V              f32 MFMA, wave w owns chains 2w, 2w+1 of C5; p = e * inv formed at the operand read
+//   4. the 16 chains meet in LDS (aliasing the score tile) in tree order
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_LD = 1026;
+__global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // [32][ATT_LD] scores, then [8][32][64] partial sums
+    __shared__ float rowinv[32];
+    const int h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctx = a.n_past + a.N;
+    // keys this tile can see: causal rows of the tile end at n_past + i0 + 31
+    const int jend = a.causal ? min(ctx, a.n_past + i0 + 32) : ctx;
+    const int jend32 = (jend + 31) & ~31;
+    // ---- 1. scores -------------------------------------------------------------------------------------
+    {
+        const int irow = min(i0 + l31, a.N - 1);
+        const float4 * qp = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
+        float4 qv[16];
+        #pragma unroll
+        for (int dq = 0; dq < 16; dq++) qv[dq] = qp[dq];
+        auto load_k = [&](float4 (&kv)[16], int jt) {
+            const int jrow = min(jt + l31, ctx - 1);
+            const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * a.P];
+        };
+        auto score_tile = [&](const float4 (&kv)[16], int jt) {
+            floatx16 acc;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].y : qv[dq].x, half ? kv[dq].y : kv[dq].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].w : qv[dq].z, half ? kv[dq].w : kv[dq].z, acc, 0, 0, 0);
+            }
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;       // accumulator row = query, column = key
+                lds[i * ATT_LD + jt + l31] = acc[r] * 0.125f;            // 1/sqrt(64), bark.cpp:1318
+            }
+        };
+        // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs
+        float4 ka[16], kb[16];
+        int jt = w * 32;
+        if (a.dbg & 1) jt = jend;
+        if (jt < jend) load_k(ka, jt);
+        for (; jt < jend; jt += 512) {
+            const bool more = jt + 256 < jend;
+            if (more) load_k(kb, jt + 256);
+            __builtin_amdgcn_sched_barrier(0);
+            score_tile(ka, jt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (jt + 512 < jend) load_k(ka, jt + 512);
+                __builtin_amdgcn_sched_barrier(0);
+                score_tile(kb, jt + 256);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. softmax, rows 4w .. 4w+3 ---------------------------------------------------------------------
+    #pragma unroll 1
+    for (int rr = 0; rr < 4; rr++) {
+        const int il = 4 * w + rr, i = i0 + il;
+        float * s = lds + il * ATT_LD;
+        const int valid = i < a.N ? (a.causal ? min(ctx, a.n_past + i + 1) : ctx) : 0;
+        float mx = -INFINITY;
+        for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
+        mx = wave_max(mx);
+        // four independent exp evaluations per lane and trip: the double-precision exp is a long dependent chain
+        double sum4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = lane; j < valid; j += 256) {
+            float e[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? ((a.dbg & 2) ? s[j + 64 * u] - mx : (float) exp((double) (s[j + 64 * u] - mx))) : 0.0f;
+            #pragma unroll
+            for (int u = 0; u < 4; u++) if (j + 64 * u < valid) { s[j + 64 * u] = e[u]; sum4[u] += (double) e[u]; }
+        }
+        const double sum = wave_sum((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
+        for (int j = valid + lane; j < jend32; j += 64) s[j] = 0.0f;   // masked keys: p == 0
+        if (lane == 0) rowinv[il] = valid ? (float) (1.0 / sum) : 0.0f;
+    }
+    __syncthreads();
+    // ---- 3. mix ------------------------------------------------------------------------------------------
+    const float inv = rowinv[l31];
+    const float * prow = lds + l31 * ATT_LD;
+    const float * vbase = a.vc + (size_t) h * a.P * 64;
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
+    // batches of 8 key blocks (256 keys): the V rows and probabilities of batch b+1 are requested before the 32 MFMAs
+    // of batch b issue (static double buffer; per-lane key slot j = jb + 2w + 16*half, chains 2w and 2w+1)
+    float va[8][2][2], vb[8][2][2];
+    float2 ea[8], eb[8];
+#define ATT_LOAD_BATCH(V, E, JB0)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                      \
+        const int j = (JB0) + 32 * u + 2 * w + 16 * half;                                                \
+        const int jc = min(j, jend32 - 2);                                                               \
+        E[u] = *reinterpret_cast<const float2 *>(prow + jc);                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                  \
+            const int jr = min(j + s, ctx - 1);                                                          \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) V[u][s][t] = vbase[(size_t) jr * 64 + t * 32 + l31]; \
+        }                                                                                                \
+    }
+#define ATT_MFMA_BATCH(V, E, JB0)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                      \
+        const int j = (JB0) + 32 * u + 2 * w + 16 * half;                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                  \
+            const bool oks = j + s < jend;                                                               \
+            const float pv = oks ? (s ? E[u].y : E[u].x) * inv : 0.0f;      /* p = e * (float)(1/sum) */ \
+            _Pragma("unroll") for (int t = 0; t < 2; t++)                                                \
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, oks ? V[u][s][t] : 0.0f, acc[s][t], 0, 0, 0); \
+        }                                                                                                \
+    }
+    const int jstop = (a.dbg & 4) ? 0 : jend;
+    if (jstop > 0) { ATT_LOAD_BATCH(va, ea, 0) }
+    for (int jb = 0; jb < jstop; jb += 512) {
+        const bool more = jb + 256 < jstop;
+        if (more) { ATT_LOAD_BATCH(vb, eb, jb + 256) }
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_MFMA_BATCH(va, ea, jb)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (jb + 512 < jstop) { ATT_LOAD_BATCH(va, ea, jb + 512) }
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MFMA_BATCH(vb, eb, jb + 256)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef ATT_LOAD_BATCH
+#undef ATT_MFMA_BATCH
+    __syncthreads();                                             // every wave is done reading the score tile
+    float * part = lds;                                          // [8][32][64]
+    #pragma unroll
+    for (int t = 0; t < 2; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            part[(w * 32 + row) * 64 + t * 32 + l31] = acc[0][t][r] + acc[1][t][r];
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 512) {
+        const int row = idx >> 6, d = idx & 63;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = part[(q * 32 + row) * 64 + d];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        const int i = i0 + row;
+        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v);
+    }
+}
+
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
+    static const bool materialised = getenv("BARK_HIP_ATTN_MATERIALISED") != nullptr;   // three-kernel variant kept for A/B checks
+    if (!materialised) {
+        hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
+        return;
+    }
     const int ctx = a.n_past + a.N;
     hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 127) / 128, (a.N + 127) / 128, a.H), dim3(256), 0, s, a);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.H * a.N + 3) / 4), dim3(256), 0, s, a);
@@ -959,6 +1123,8 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 }
 
 void init_kernel_attributes() {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(attn_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               32 * ATT_LD * (int) sizeof(float));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
 }

@@ -68,6 +68,15 @@ BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * c
  * 2..5 (the four upsampling blocks).  Returns the element count or -1. */
 BARK_API int bark_hip_codec_tap(struct bark_context * bctx, const int32_t * codes, int n_q, int T, int stage, float * out, int capacity);
 
+/* Replicas on one GPU: a clone shares the (immutable) device weights of `src` and owns its stream, KV caches and
+ * scratch, so several utterances can be in flight on one device.  Free clones and the original in any order. */
+BARK_API struct bark_context * bark_hip_clone_context(struct bark_context * src, uint32_t seed);
+
+/* Runs bark_generate_audio for n (context, text) pairs concurrently, one host thread + one HIP stream each
+ * (no collectives: utterances are independent).  Returns the number of successful generations; results are read
+ * from each context with bark_get_audio_data[_size]. */
+BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * const * texts, int n);
+
 /* Token streams of the last bark_generate_audio call (copied out; returns counts). */
 BARK_API int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity);
 BARK_API int bark_hip_get_coarse_tokens(struct bark_context * bctx, int32_t * out_Tx2, int capacity_rows);
