@@ -143,7 +143,7 @@ def main():
                 gem[name] = {"us": u, "GB/s": nb / (u * 1e-6) / 1e9}
             out["roofline_gemv_variants"] = gem
             us, nbytes = ctx.time_decode_step(0, 640, 300)
-            out["roofline_decode_step"] = {"bound": "hbm", "unit_of_work": "one semantic decode step @ctx 640 (hipGraph: 74 kernels)",
+            out["roofline_decode_step"] = {"bound": "hbm", "unit_of_work": "one semantic decode step @ctx 640 (hipGraph: 62 kernels)",
                                            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                            "frac": nbytes / (us * 1e-6) / 8e12, "us_per_step": us, "bytes_per_step": nbytes}
             fus, flops = ctx.time_fine_pass(6)
