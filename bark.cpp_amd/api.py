@@ -67,7 +67,7 @@ EXPORTS = [
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
-    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
+    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
 
@@ -111,6 +111,9 @@ def load_library() -> C.CDLL:
     lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip]
     lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
+    lib.bark_hip_generate_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
+    lib.bark_hip_batch_audio.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float))]
+    lib.bark_hip_batch_tokens.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     lib.bark_hip_clone_context.restype = vp
     lib.bark_hip_clone_context.argtypes = [vp, C.c_uint32]
     lib.bark_hip_generate_audio_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_char_p), C.c_int]
@@ -280,6 +283,28 @@ class BarkContext:
         if n < 0:
             raise RuntimeError("bark_hip_codec_tap failed")
         return out[:n].copy()
+
+    def generate_batch(self, texts) -> list:
+        """In-engine batching (bark_hip_generate_batch): returns one dict per utterance (or None if it failed)."""
+        n = len(texts)
+        ts = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        good = self._lib.bark_hip_generate_batch(self._h, ts, n)
+        if good < 0:
+            raise RuntimeError("bark_hip_generate_batch failed")
+        out = []
+        for i in range(n):
+            p = C.POINTER(C.c_float)()
+            ns = self._lib.bark_hip_batch_audio(self._h, i, C.byref(p))
+            if ns < 0:
+                out.append(None)
+                continue
+            d = {"pcm": np.ctypeslib.as_array(p, shape=(ns,)).copy() if ns else np.zeros(0, np.float32)}
+            for stage, (name, w) in enumerate((("semantic", 1), ("coarse", 2), ("fine", 8))):
+                buf = np.zeros(8192, np.int32)
+                k = self._lib.bark_hip_batch_tokens(self._h, i, stage, buf.ctypes.data, buf.size)
+                d[name] = buf[:max(k, 0)].copy().reshape(-1, w) if w > 1 else buf[:max(k, 0)].copy()
+            out.append(d)
+        return out
 
     def clone(self, seed: int = 0) -> "BarkContext":
         h = self._lib.bark_hip_clone_context(self._h, seed)

@@ -209,6 +209,25 @@ int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * cons
     return good;
 }
 
+int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n) {
+    if (!bctx || !texts || n <= 0) return -1;
+    for (int i = 0; i < n; i++) if (!texts[i]) return -1;
+    return guarded("bark_hip_generate_batch", -1, [&] { return engine_generate_batch(bctx, texts, n); });
+}
+int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data) {
+    if (!bctx || i < 0 || i >= (int) bctx->batch_results.size() || !bctx->batch_results[(size_t) i].ok) return -1;
+    if (data) *data = bctx->batch_results[(size_t) i].audio.data();
+    return (int) bctx->batch_results[(size_t) i].audio.size();
+}
+int bark_hip_batch_tokens(struct bark_context * bctx, int i, int stage, int32_t * out, int capacity) {
+    if (!bctx || i < 0 || i >= (int) bctx->batch_results.size() || stage < 0 || stage > 2) return -1;
+    const auto & r = bctx->batch_results[(size_t) i];
+    const std::vector<int32_t> & v = stage == 0 ? r.semantic : stage == 1 ? r.coarse : r.fine;
+    if (!out || capacity < (int) v.size()) return -1;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * 4);
+    return (int) v.size();
+}
+
 static int copy_out(const std::vector<int32_t> & v, int per_row, int32_t * out, int capacity_rows) {
     const int rows = (int) v.size() / per_row;
     if (!out || capacity_rows < rows) return -1;

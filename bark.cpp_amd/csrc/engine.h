@@ -83,6 +83,19 @@ struct bark_context {
     float * c_gi = nullptr, * c_cell = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr; size_t c_T = 0;
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
 
+    // batched decode (several utterances in lock step on this context, bark_hip_generate_batch): per-slot KV caches
+    // and decode rows; prefill / fine / codec still run one utterance at a time on the buffers above
+    struct Batch {
+        int cap = 0;
+        float * kc[2] = {nullptr, nullptr}, * vc[2] = {nullptr, nullptr}; size_t slot_stride[2] = {0, 0};
+        float * x = nullptr, * q = nullptr, * logits = nullptr; barkhip::half_t * att = nullptr, * h = nullptr;
+        barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr;
+        size_t ld_logits = 0;
+        hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
+    } batch;
+    struct BatchResult { std::vector<int32_t> semantic, coarse, fine; std::vector<float> audio; bool ok = false; };
+    std::vector<BatchResult> batch_results;
+
     // results of the last generate call
     std::vector<int32_t> tokens, semantic_tokens, coarse_tokens, fine_tokens;
     std::vector<float> audio;
@@ -109,6 +122,7 @@ std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> 
 // tap_stage >= 0: *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
 std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap);
 bool engine_generate(bark_context * ctx, const char * text);
+int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n);     // greedy only; returns #ok
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);

@@ -49,6 +49,9 @@ struct LinArgs {
     // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
     // the row window starts at parity_rows * (st->step & 1) rows into W (and bias)
     int parity_rows = 0;
+    // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
+    // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
+    int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 
@@ -73,6 +76,7 @@ struct AttnDecodeArgs {
     const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
     float * scores = nullptr;             // scratch [H][P]
+    int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
@@ -96,6 +100,7 @@ struct SampleArgs {
     int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
     int32_t * out_tokens = nullptr; float * eos_trace = nullptr; StepState * st = nullptr;
+    int nbatch = 1; int ld_logits = 0; int out_stride = 0;   // batched decode: slot b reads logits + b*ld_logits, writes out_tokens + b*out_stride, x + b*E
     // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
 };

@@ -94,7 +94,7 @@ DEVINL EpiPre epilogue_prefetch(const LinArgs & a, int n, int m, int row_off) {
     EpiPre p;
     p.bias = a.bias ? a.bias[row_off + m] : 0.0f;
     p.res = a.epi == EPI_RESID ? a.res[(size_t) n * a.M + m] : 0.0f;
-    p.n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
+    p.n_past = (a.epi == EPI_QKV && a.st) ? (a.batched ? a.st[n].n_past : a.st->n_past) : 0;
     return p;
 }
 DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, const EpiPre & p) {
@@ -104,10 +104,12 @@ DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, cons
         case EPI_QKV: {
             const int E = a.E;
             if (m < E) { a.q[(size_t) n * E + m] = v; break; }
-            const int pos = a.pos0 + p.n_past + n;
+            // batched decode: row n is sequence slot n with its own cache and position; otherwise rows are consecutive positions
+            const int pos = a.pos0 + p.n_past + (a.batched ? 0 : n);
+            const size_t slot = a.batched ? (size_t) n * a.kv_slot_stride : 0;
             const int mm = m < 2 * E ? m - E : m - 2 * E;
             const int h = mm >> 6, d = mm & 63;
-            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else a.vc[vc_index(h, d, pos, a.P)] = v;
+            if (m < 2 * E) a.kc[slot + kc_index(h, d, pos, a.P)] = v; else a.vc[slot + vc_index(h, d, pos, a.P)] = v;
             break;
         }
         case EPI_RESID: a.res[(size_t) n * a.M + m] = v + p.res; break;                          // cur + inpL (bark.cpp:1352,1388)
@@ -241,6 +243,120 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
         } else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
     } else {
         hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a);
+    }
+}
+
+// Batched decode GEMV (several utterances in lock step): grid.y walks the sequence slots, BPW slots per wave.
+// The weight rows of a workgroup column are read from HBM once (same XCD L2 for every grid.y: grid.x is a multiple
+// of 8) and each slot's dot product is the same C1 chain as in gemv_kernel, so results do not depend on the batch.
+template <int NBLK, bool LN, bool LNB, int BPW>
+__global__ __launch_bounds__(64) void gemv_batch_kernel(const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int b0 = blockIdx.y * BPW;
+    constexpr int K = NBLK * 128;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    EpiPre pre[BPW];
+    int bi[BPW];
+    #pragma unroll
+    for (int bb = 0; bb < BPW; bb++) { bi[bb] = min(b0 + bb, a.nbatch - 1); pre[bb] = epilogue_prefetch(a, bi[bb], live ? m : 0, row_off); }
+    float acc[BPW];
+    #pragma unroll
+    for (int bb = 0; bb < BPW; bb++) acc[bb] = 0.0f;
+
+    if constexpr (LN) {
+        static_assert(NBLK <= 8, "LayerNorm-fused GEMV keeps the row in registers (n_embd <= 1024)");
+        half8 wv[NBLK];
+        float4 xa[BPW][NBLK][2], ga[NBLK][2], ba[NBLK][2];
+        #pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const int k0 = (b * 16 + c) << 3;
+            wv[b] = ld_half8(wrow + (b << 7));
+            #pragma unroll
+            for (int bb = 0; bb < BPW; bb++) {
+                const float * xrow = a.x_f32 + (size_t) bi[bb] * K;
+                xa[bb][b][0] = *reinterpret_cast<const float4 *>(xrow + k0); xa[bb][b][1] = *reinterpret_cast<const float4 *>(xrow + k0 + 4);
+            }
+            ga[b][0] = *reinterpret_cast<const float4 *>(a.ln_g + k0);  ga[b][1] = *reinterpret_cast<const float4 *>(a.ln_g + k0 + 4);
+            if constexpr (LNB) { ba[b][0] = *reinterpret_cast<const float4 *>(a.ln_b + k0); ba[b][1] = *reinterpret_cast<const float4 *>(a.ln_b + k0 + 4); }
+        }
+        #pragma unroll
+        for (int bb = 0; bb < BPW; bb++) {
+            float xr[NBLK][8];
+            double p1[4] = {0.0, 0.0, 0.0, 0.0};
+            #pragma unroll
+            for (int b = 0; b < NBLK; b++) {
+                xr[b][0] = xa[bb][b][0].x; xr[b][1] = xa[bb][b][0].y; xr[b][2] = xa[bb][b][0].z; xr[b][3] = xa[bb][b][0].w;
+                xr[b][4] = xa[bb][b][1].x; xr[b][5] = xa[bb][b][1].y; xr[b][6] = xa[bb][b][1].z; xr[b][7] = xa[bb][b][1].w;
+                #pragma unroll
+                for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+            }
+            const double s1 = group16_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+            const float mean = (float) (s1 / (double) K);
+            double p2[4] = {0.0, 0.0, 0.0, 0.0};
+            #pragma unroll
+            for (int b = 0; b < NBLK; b++) {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; p2[e & 3] += (double) (v * v); }
+            }
+            const double s2 = group16_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+            const float var = (float) (s2 / (double) K);
+            const float scale = 1.0f / sqrtf(var + 1e-5f);
+            #pragma unroll
+            for (int b = 0; b < NBLK; b++) {
+                const float gg[8] = {ga[b][0].x, ga[b][0].y, ga[b][0].z, ga[b][0].w, ga[b][1].x, ga[b][1].y, ga[b][1].z, ga[b][1].w};
+                float bv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (LNB) { bv[0] = ba[b][0].x; bv[1] = ba[b][0].y; bv[2] = ba[b][0].z; bv[3] = ba[b][0].w; bv[4] = ba[b][1].x; bv[5] = ba[b][1].y; bv[6] = ba[b][1].z; bv[7] = ba[b][1].w; }
+                #pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = xr[b][e] * scale;
+                    v = v * gg[e];
+                    if constexpr (LNB) v = v + bv[e];
+                    acc[bb] = fmaf((float) wv[b][e], (float) to_half(v), acc[bb]);
+                }
+            }
+        }
+    } else {
+        constexpr int G = NBLK < 8 ? NBLK : 8;
+        static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+        #pragma unroll
+        for (int g = 0; g < NBLK / G; g++) {
+            half8 wv[G], xv[BPW][G];
+            #pragma unroll
+            for (int i = 0; i < G; i++) {
+                wv[i] = ld_half8(wrow + ((g * G + i) << 7));
+                #pragma unroll
+                for (int bb = 0; bb < BPW; bb++) xv[bb][i] = ld_half8(a.x_f16 + (size_t) bi[bb] * K + (c << 3) + ((g * G + i) << 7));
+            }
+            #pragma unroll
+            for (int bb = 0; bb < BPW; bb++)
+                #pragma unroll
+                for (int i = 0; i < G; i++)
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) acc[bb] = fmaf((float) wv[i][e], (float) xv[bb][i][e], acc[bb]);
+        }
+    }
+    #pragma unroll
+    for (int bb = 0; bb < BPW; bb++) {
+        const float r = wave_xor_add16(acc[bb]);
+        if (live && c == 0 && b0 + bb < a.nbatch) linear_epilogue_pre(a, b0 + bb, m, r, pre[bb]);
+    }
+}
+
+template <int NBLK>
+static void launch_gemv_batch_n(hipStream_t s, const LinArgs & a) {
+    constexpr int BPW = 2;
+    dim3 grid((a.M + 3) / 4, (a.nbatch + BPW - 1) / BPW), block(64);
+    if (a.x_f32) {
+        if constexpr (NBLK <= 8) {
+            if (a.ln_b) hipLaunchKernelGGL((gemv_batch_kernel<NBLK, true, true, BPW>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_batch_kernel<NBLK, true, false, BPW>), grid, block, 0, s, a);
+        } else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
+    } else {
+        hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, BPW>), grid, block, 0, s, a);
     }
 }
 
@@ -414,6 +530,20 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
     if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
     const int nblk = a.K >> 7;
+    if (a.batched) {
+        switch (nblk) {
+            case 1:  launch_gemv_batch_n<1>(s, a); break;
+            case 2:  launch_gemv_batch_n<2>(s, a); break;
+            case 4:  launch_gemv_batch_n<4>(s, a); break;
+            case 6:  launch_gemv_batch_n<6>(s, a); break;
+            case 8:  launch_gemv_batch_n<8>(s, a); break;
+            case 16: launch_gemv_batch_n<16>(s, a); break;
+            case 24: launch_gemv_batch_n<24>(s, a); break;
+            case 32: launch_gemv_batch_n<32>(s, a); break;
+            default: fprintf(stderr, "bark-hip: unsupported K=%d in batched decode GEMV\n", a.K); abort();
+        }
+        return;
+    }
     if (a.N == 1) {
         switch (nblk) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
             case 1:  launch_gemv_n<1>(s, a); break;
@@ -632,15 +762,17 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     __shared__ float red_f[4];
     __shared__ double red_d[4];
     __shared__ float part[16][64];
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
-    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+    const int E = a.H * 64;
+    const float * __restrict__ qh = a.q + (size_t) slot * E + h * 64;            // wave-uniform: scalar loads
+    const float * kc = a.kc + (size_t) slot * a.kv_slot_stride, * vc = a.vc + (size_t) slot * a.kv_slot_stride;
+    const float4 * kp = reinterpret_cast<const float4 *>(kc) + (size_t) h * 16 * P + tid;
     const int chain = 4 * wave + (lane >> 4), d4 = lane & 15;
-    const float4 * vp = reinterpret_cast<const float4 *>(a.vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;   // row `chain`, dims 4*d4..
+    const float4 * vp = reinterpret_cast<const float4 *>(vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;   // row `chain`, dims 4*d4..
     float4 k0[16], k1[16];
     load_k_group<0>(k0, kp, P);                                // keys 0..255: always inside the cache
-    const int ctx = a.st->n_past + 1;
+    const int ctx = a.st[slot].n_past + 1;
     if (ctx > 256) load_k_group<1>(k1, kp, P);
     float4 vv[64];
     #pragma unroll
@@ -699,12 +831,12 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
         for (int st = 1; st < 16; st <<= 1)
             #pragma unroll
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        a.att[h * 64 + tid] = to_half(p[0]);
+        a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
     }
 }
 
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
-    if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H), dim3(256), 0, s, a); return; }
+    if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
     if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
     if (parts & 2) hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
 }
@@ -1024,16 +1156,18 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     __shared__ float red_s[16];
     __shared__ int next_tok, next_pos;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;                               // sequence slot (batched decode); 0 otherwise
+    const float * logits = a.logits + (size_t) slot * a.ld_logits;
     constexpr int MAXV = 12;                                   // up to 12288 logits
     float sv[MAXV];
     float mx = -INFINITY;
     #pragma unroll
     for (int k = 0; k < MAXV; k++) {
         const int i = tid + 1024 * k;
-        sv[k] = i < a.n ? a.logits[i] / 0.7f : -INFINITY;      // gpt_argmax_sample divides by 0.7 whatever the temperature
+        sv[k] = i < a.n ? logits[i] / 0.7f : -INFINITY;        // gpt_argmax_sample divides by 0.7 whatever the temperature
         mx = fmaxf(mx, sv[k]);
     }
-    const float last_logit = a.logits[a.n - 1];
+    const float last_logit = logits[a.n - 1];
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
@@ -1061,7 +1195,7 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     __syncthreads();
     if (tid == 0) {
         for (int i = 1; i < 16; i++) { best = min(best, red_i[i]); close += red_c[i]; sum += red_s[i]; }
-        StepState * st = a.st;
+        StepState * st = a.st + slot;
         const int step = st->step;
         int tok = best;
         float eos_p = 0.0f;
@@ -1069,12 +1203,12 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
             // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
             eos_p = (float) exp((double) (last_logit / 0.7f - mx)) / sum;
             if ((tok == a.eos_token || eos_p >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
-            if (a.eos_trace) a.eos_trace[step] = eos_p;
+            if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = eos_p;
         } else {
             tok += a.token_base + ((step & 1) ? 1024 : 0);   // slice start (bark.cpp:1829-1841)
         }
         if (close > 1) st->near_tie += 1;
-        a.out_tokens[st->n_out] = tok;
+        a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
         st->n_out += 1;
         st->cur_token = tok;
         st->step = step + 1;
@@ -1089,11 +1223,12 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
         const int tok = min(max(next_tok, 0), a.n_in - 1);
         const half_t * r = a.wte + (size_t) tok * a.E;
         const float * pe = a.wpe + (size_t) next_pos * a.E;
-        for (int e = tid; e < a.E; e += 1024) a.x[e] = (float) r[e] + pe[e];
+        float * xo = a.x + (size_t) slot * a.E;
+        for (int e = tid; e < a.E; e += 1024) xo[e] = (float) r[e] + pe[e];
     }
 }
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
-    hipLaunchKernelGGL(sample_greedy_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,

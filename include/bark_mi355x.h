@@ -77,6 +77,17 @@ BARK_API struct bark_context * bark_hip_clone_context(struct bark_context * src,
  * from each context with bark_get_audio_data[_size]. */
 BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * const * texts, int n);
 
+/* In-engine batching: n utterances (n <= 32) advance in lock step through the semantic and coarse decode loops of ONE
+ * context, so every decode kernel reads the weights once per step for all of them; prefill, fine passes and the codec
+ * run per utterance.  Greedy parameters only (temp == fine_temp == 0); otherwise the call degrades to a sequential
+ * loop.  Per-utterance results are bit-identical to bark_generate_audio.  The first call fixes the batch capacity.
+ * Returns the number of utterances that produced audio.  Results: bark_hip_batch_audio / bark_hip_batch_tokens. */
+BARK_API int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n);
+/* audio of utterance i of the last batch: returns the sample count (-1 on error), *data points into the context */
+BARK_API int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data);
+/* token stream of utterance i: stage 0 semantic, 1 coarse [T][2], 2 fine [T][8]; returns the id count or -1 */
+BARK_API int bark_hip_batch_tokens(struct bark_context * bctx, int i, int stage, int32_t * out, int capacity);
+
 /* Token streams of the last bark_generate_audio call (copied out; returns counts). */
 BARK_API int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity);
 BARK_API int bark_hip_get_coarse_tokens(struct bark_context * bctx, int32_t * out_Tx2, int capacity_rows);
