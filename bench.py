@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--preset", default="small")
     ap.add_argument("--n-semantic", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +153,20 @@ def main():
                                          "hbm_frac_on_algorithmic_bytes": 171.5e6 / (fus * 1e-6) / 8e12}
         except Exception as e:      # noqa: BLE001
             out["roofline"] = {"error": str(e)}
+        # in-engine batching: 8 utterances in lock step on this GPU (reported beside the
+        # single-prompt headline, never instead of it)
+        if world == 1 and not a.no_batched:
+            try:
+                bctx = pkg.BarkContext.load_model(path, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=a.n_semantic), seed=0)
+                bctx.generate_batch(prompts[:8])
+                tb = time.perf_counter()
+                res = bctx.generate_batch(prompts[8:16])
+                dtb = time.perf_counter() - tb
+                out["batched_8_utterances"] = {"prompts_per_s": 8 / dtb, "audio_s_per_s": sum(len(r["pcm"]) for r in res) / 24000.0 / dtb,
+                                               "wall_ms": dtb * 1e3, "note": "bark_hip_generate_batch: lock-step decode, per-utterance results bit-identical to the single path"}
+                bctx.free()
+            except Exception as e:      # noqa: BLE001
+                out["batched_8_utterances"] = {"error": str(e)}
         if not a.no_cpu_baseline and world == 1:
             from oracle.pyoracle import Oracle
             cores = min(os.cpu_count() or 4, 8)

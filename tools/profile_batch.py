@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bark_amd_loader import load_package
+from tools.make_synth_model import ensure_model
+import bench
+pkg = load_package()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ctx = pkg.BarkContext.load_model(ensure_model("small", 0), pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=40), 0)
+res = ctx.generate_batch(bench.synth_prompts(64)[:B])
+print(ctx.stats())
+ctx.free()
