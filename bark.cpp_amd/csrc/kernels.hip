@@ -178,18 +178,21 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
         for (int b = 0; b < NBLK; b++) {
             xr[b][0] = xa[b][0].x; xr[b][1] = xa[b][0].y; xr[b][2] = xa[b][0].z; xr[b][3] = xa[b][0].w;
             xr[b][4] = xa[b][1].x; xr[b][5] = xa[b][1].y; xr[b][6] = xa[b][1].z; xr[b][7] = xa[b][1].w;
-            #pragma unroll
-            for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+            // the wave's four 16-lane groups hold identical rows: group rg sums only the blocks b = rg (mod 4)
+            if ((b & 3) == rg) {
+                #pragma unroll
+                for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+            }
         }
-        const double s1 = group16_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
         const float mean = (float) (s1 / (double) K);
         double p2[4] = {0.0, 0.0, 0.0, 0.0};
         #pragma unroll
         for (int b = 0; b < NBLK; b++) {
             #pragma unroll
-            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; p2[e & 3] += (double) (v * v); }
+            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; if ((b & 3) == rg) p2[e & 3] += (double) (v * v); }
         }
-        const double s2 = group16_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+        const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
         const float var = (float) (s2 / (double) K);
         const float scale = 1.0f / sqrtf(var + 1e-5f);
         #pragma unroll
@@ -291,18 +294,20 @@ __global__ __launch_bounds__(64) void gemv_batch_kernel(const LinArgs a) {
             for (int b = 0; b < NBLK; b++) {
                 xr[b][0] = xa[bb][b][0].x; xr[b][1] = xa[bb][b][0].y; xr[b][2] = xa[bb][b][0].z; xr[b][3] = xa[bb][b][0].w;
                 xr[b][4] = xa[bb][b][1].x; xr[b][5] = xa[bb][b][1].y; xr[b][6] = xa[bb][b][1].z; xr[b][7] = xa[bb][b][1].w;
-                #pragma unroll
-                for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+                if ((b & 3) == rg) {
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+                }
             }
-            const double s1 = group16_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+            const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
             const float mean = (float) (s1 / (double) K);
             double p2[4] = {0.0, 0.0, 0.0, 0.0};
             #pragma unroll
             for (int b = 0; b < NBLK; b++) {
                 #pragma unroll
-                for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; p2[e & 3] += (double) (v * v); }
+                for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; if ((b & 3) == rg) p2[e & 3] += (double) (v * v); }
             }
-            const double s2 = group16_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+            const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
             const float var = (float) (s2 / (double) K);
             const float scale = 1.0f / sqrtf(var + 1e-5f);
             #pragma unroll
