@@ -75,6 +75,8 @@ struct bark_context {
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;
     unsigned * d_hmax = nullptr;
+    double * d_u = nullptr;                             // uniform draws for on-device multinomial sampling (8192)
+    bool host_sampling = false;                         // BARK_HIP_HOST_SAMPLING=1: sample temp > 0 on the host (A/B path)
     uint16_t * d_gelu_lut = nullptr;
     int max_E = 0, max_H = 0, P = 1024;
     // codec scratch (grown on demand)

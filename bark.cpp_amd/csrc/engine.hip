@@ -136,6 +136,8 @@ static void init_runtime(bark_context * ctxp) {
     ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
     ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
     ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
+    ctx->d_u = dev_alloc<double>(ctx.get(), 8192);
+    { const char * e = getenv("BARK_HIP_HOST_SAMPLING"); ctx->host_sampling = e && atoi(e) != 0; }
     ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
     HIP_OK(hipMemset(ctx->d_hmax, 0, 64 * sizeof(unsigned)));
     {
@@ -438,12 +440,13 @@ int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge, float 
 }
 
 struct StageCfg {            // what differs between the semantic and the coarse decode step
-    int which; int mode; int lm_row0, lm_rows, parity_rows; int token_base; float min_eos_p; int eos_token;
+    int which; int mode; int lm_row0, lm_rows, parity_rows; int token_base; float min_eos_p; int eos_token; float temp;
 };
 StageCfg stage_cfg(bark_context * c, int which) {
     const bark_context_params & p = c->params;
     StageCfg s{};
     s.which = which;
+    s.temp = p.temp;
     if (which == 0) {
         // the reference samples over ALL n_out logits (bark.cpp:1682-1688)
         s.mode = 0; s.lm_row0 = 0; s.lm_rows = c->gpt[0].hp.n_out_vocab; s.parity_rows = 0; s.token_base = 0;
@@ -461,6 +464,7 @@ void run_sample(bark_context * c, const StageCfg & s, int n_past_add) {
     a.logits = c->logits; a.n = s.lm_rows; a.mode = s.mode; a.min_eos_p = s.min_eos_p; a.eos_token = s.eos_token;
     a.token_base = s.token_base; a.n_past_add = n_past_add; a.out_tokens = c->d_out_tokens;
     a.eos_trace = s.mode == 0 ? c->d_eos_trace : nullptr; a.st = c->d_state;
+    a.temp = s.temp; a.u = c->d_u;
     const GptModel & m = c->gpt[s.which];
     a.wte = m.wte[0]; a.wpe = m.wpe; a.E = m.hp.n_embd; a.n_in = m.hp.n_in_vocab; a.P = c->P; a.x = c->x;
     launch_sample_greedy(c->stream, a);
@@ -534,6 +538,20 @@ std::vector<float> fetch_logits(bark_context * c, size_t n) {
     HIP_OK(hipStreamSynchronize(c->stream));
     return l;
 }
+
+// Uniform draws for `n` multinomial samples, taken from a COPY of the context's generator exactly as
+// std::discrete_distribution would take them (one std::generate_canonical<double, 53> per sample = two mt19937 words);
+// consume_uniforms() then advances the real generator by the samples that were actually used, so the random stream
+// stays aligned with the reference's (bark.cpp:201-221) even when a stage stops early.
+void upload_uniforms(bark_context * c, int n) {
+    if (n > 8192) throw std::runtime_error("too many samples in one stage");
+    std::mt19937 tmp = c->rng;
+    std::vector<double> u((size_t) n);
+    for (auto & v : u) v = std::generate_canonical<double, 53>(tmp);
+    HIP_OK(hipMemcpyAsync(c->d_u, u.data(), (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+void consume_uniforms(bark_context * c, int n_used) { c->rng.discard(2ull * (unsigned long long) n_used); }
 
 void progress(bark_context * c, bark_encoding_step step, int pct) {
     if (c->params.progress_callback) c->params.progress_callback(c, step, pct, c->params.progress_callback_user_data);
@@ -621,7 +639,8 @@ std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t
     upload_tokens(c, prompt.data(), prompt.size());
     StepState st = fresh_state();
     set_state(c, st);
-    const bool greedy = p.temp == 0.0f;
+    const bool greedy = p.temp == 0.0f || !c->host_sampling;      // "greedy" == sampled on the device (argmax or multinomial)
+    if (p.temp != 0.0f && greedy) upload_uniforms(c, n_steps);
     const int N = run_prefill(c, m, 513, true);
     run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, s.lm_row0, s.lm_rows, 0);
     if (greedy) {
@@ -646,8 +665,10 @@ std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t
             eos_trace->resize((size_t) n_tr);
             if (n_tr) HIP_OK(hipMemcpy(eos_trace->data(), c->d_eos_trace, (size_t) n_tr * 4, hipMemcpyDeviceToHost));
         }
-        c->stats.n_sample_semantic += std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
+        const int n_used = std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
+        c->stats.n_sample_semantic += n_used;
         c->stats.n_near_tie += cur.near_tie;
+        if (p.temp != 0.0f) consume_uniforms(c, n_used);
     } else {
         int n_past = N;
         for (int i = 0; i < n_steps; i++) {
@@ -687,7 +708,8 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
     const int n_steps = (int) (floorf(semantic.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);  // bark.cpp:1775-1779
     if (n_steps <= 0) throw std::runtime_error("coarse: no steps to run");
     const int n_windows = (int) ceilf((float) n_steps / p.sliding_window_size);
-    const bool greedy = p.temp == 0.0f;
+    const bool greedy = p.temp == 0.0f || !c->host_sampling;
+    if (p.temp != 0.0f && greedy) upload_uniforms(c, n_steps);
     std::vector<int32_t> out;            // offset ids, as fed back into the model
     int step_idx = 0;
     for (int w = 0; w < n_windows; w++) {
@@ -746,6 +768,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
             }
         }
     }
+    if (p.temp != 0.0f && greedy) consume_uniforms(c, n_steps);
     // de-offset into [T][2] (bark.cpp:1851-1857)
     std::vector<int32_t> res;
     for (size_t i = 0; i + 1 < out.size(); i += 2) {
@@ -773,6 +796,8 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
     for (int t = 0; t < T; t++) for (int ch = 0; ch < nc; ch++) buf[(size_t) ch * 1024 + t] = coarse[(size_t) t * nc + ch];
     upload_tokens(c, buf.data(), buf.size());
     const bool greedy = p.fine_temp == 0.0f;
+    const bool device_multinomial = !greedy && !c->host_sampling;
+    if (device_multinomial) upload_uniforms(c, (nf - nc) * 1024);
     StepState st = fresh_state();
     set_state(c, st);
     // one window (T <= 1024  =>  n_loops == 1, start_idx == 0, rel_start_fill_idx == 0)
@@ -781,6 +806,10 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
         if (greedy) {
             run_fine_forward(c, nn, cs);                   // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
             launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, c->d_tokens + (size_t) nn * 1024, 1, c->d_state);
+        } else if (device_multinomial) {
+            run_fine_forward(c, nn, cs);
+            launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024,
+                                           c->d_tokens + (size_t) nn * 1024, 1);
         } else {
             const int n_out = m.hp.n_out_vocab;
             run_fine_forward(c, nn, n_out);
@@ -795,6 +824,7 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
         }
         c->stats.n_sample_fine += 1024;
     }
+    if (device_multinomial) consume_uniforms(c, (nf - nc) * 1024);
     HIP_OK(hipMemcpyAsync(buf.data(), c->d_tokens, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
     const StepState cur = get_state(c);
     c->stats.n_near_tie += cur.near_tie;

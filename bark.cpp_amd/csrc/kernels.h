@@ -96,6 +96,8 @@ void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 struct SampleArgs {
     const float * logits = nullptr; int n = 0;
     int mode = 0;                          // 0 semantic (stop rule on eos token / eos_p), 1 coarse
+    float temp = 0.0f;                     // 0: greedy (gpt_argmax_sample); > 0: multinomial with the uniform draws u[st->step]
+    const double * u = nullptr;
     float min_eos_p = 0.2f; int eos_token = 10000;
     int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
@@ -106,6 +108,9 @@ struct SampleArgs {
 };
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]
+// fine stage, fine_temp > 0: row r picks with the uniform draw u[r]
+void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, float temp, const double * u,
+                                    int32_t * out, int out_stride);
 void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
                         int out_stride, StepState * st);
 

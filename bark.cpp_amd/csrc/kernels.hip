@@ -1232,8 +1232,158 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
         for (int e = tid; e < a.E; e += 1024) xo[e] = (float) r[e] + pe[e];
     }
 }
+// ------------------------------------------------------------------------------------------------
+// multinomial sampling on the device (gpt_multinomial_sample, bark.cpp:201-221): l /= temp; softmax;
+// std::discrete_distribution.  libstdc++'s distribution normalises the probabilities once more in double, takes the
+// running sums (last one forced to 1.0) and returns lower_bound(sums, u) for ONE uniform double u in [0,1) drawn with
+// std::generate_canonical<double, 53> - the host draws those u from the context's std::mt19937 in the order the
+// reference would (one per sample) and uploads them, so a seed selects the same random stream as in the reference.
+// The running sums are formed per thread range + block scan instead of sequentially: a pick can differ from libstdc++
+// only if u falls within ~1e-16 of a boundary.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleArgs a) {
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ int red_i[16];
+    __shared__ int next_tok, next_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;
+    const float * logits = a.logits + (size_t) slot * a.ld_logits;
+    StepState * st = a.st + slot;
+    const int step = st->step;
+    const double u = a.u[step];
+    constexpr int CH = 12;                                      // thread t owns the contiguous ids [t*CH, t*CH+CH): up to 12288 logits
+    float pv[CH];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = tid * CH + k;
+        pv[k] = i < a.n ? logits[i] / a.temp : -INFINITY;
+        mx = fmaxf(mx, pv[k]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    float fsum = 0.0f;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = tid * CH + k < a.n ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
+    __syncthreads();
+    if (lane == 0) red_f[wave] = fsum;
+    __syncthreads();
+    fsum = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) fsum += red_f[i];
+    double dsum = 0.0;
+    float eos_p = 0.0f;                                         // set in the thread that owns the last id
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        pv[k] = pv[k] / fsum; dsum += (double) pv[k];           // softmax probabilities (float), bark.cpp:197-199
+        if (tid * CH + k == a.n - 1) eos_p = pv[k];
+    }
+    double wtot = wave_sum(dsum);
+    if (lane == 0) red_d[wave] = wtot;
+    __syncthreads();
+    double total = 0.0, wave_off = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) { if (i < wave) wave_off += red_d[i]; total += red_d[i]; }
+    // exclusive prefix of the per-thread sums inside the wave
+    double incl = dsum;
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    double run = (wave_off + (incl - dsum)) / total;
+    int pick = INT32_MAX;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = tid * CH + k;
+        if (i < a.n) {
+            run += (double) pv[k] / total;
+            const double cp = i == a.n - 1 ? 1.0 : run;                                    // libstdc++ pins the last running sum to 1.0
+            if (cp >= u && i < pick) pick = i;
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
+    if (lane == 0) red_i[wave] = pick;
+    if (tid == ((a.n - 1) / CH)) red_f[0] = eos_p;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; i++) pick = min(pick, red_i[i]);
+        int tok = pick;
+        float ep = 0.0f;
+        if (a.mode == 0) {
+            ep = red_f[0];                                      // probability of the LAST logit (bark.cpp:217-218)
+            if ((tok == a.eos_token || ep >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = ep;
+        } else {
+            tok += a.token_base + ((step & 1) ? 1024 : 0);
+        }
+        a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
+        st->n_out += 1;
+        st->cur_token = tok;
+        st->step = step + 1;
+        const int np = st->n_past + a.n_past_add;
+        st->n_past = np;
+        st->last_eos_p = ep;
+        next_tok = tok; next_pos = np;
+    }
+    __syncthreads();
+    if (a.x && next_pos < a.P) {
+        const int tok = min(max(next_tok, 0), a.n_in - 1);
+        const half_t * r = a.wte + (size_t) tok * a.E;
+        const float * pe = a.wpe + (size_t) next_pos * a.E;
+        float * xo = a.x + (size_t) slot * a.E;
+        for (int e = tid; e < a.E; e += 1024) xo[e] = (float) r[e] + pe[e];
+    }
+}
+
+// fine stage: one wave per row, multinomial over the first n_cols logits of the row; u[row] is that sample's uniform draw
+__global__ __launch_bounds__(256) void sample_rows_multinomial_kernel(const float * logits, int ld, int n_rows, int n_cols, float temp,
+                                                                     const double * u, int32_t * out, int out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float * l = logits + (size_t) row * ld;
+    constexpr int CH = 16;                                      // lane owns ids [lane*16, lane*16+16): n_cols <= 1024
+    float pv[CH];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { const int i = lane * CH + k; pv[k] = i < n_cols ? l[i] / temp : -INFINITY; mx = fmaxf(mx, pv[k]); }
+    mx = wave_max(mx);
+    float fsum = 0.0f;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = lane * CH + k < n_cols ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
+    double dsum = 0.0;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = pv[k] / fsum; dsum += (double) pv[k]; }
+    const double total = wave_sum(dsum);
+    double incl = dsum;
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    double run = (incl - dsum) / total;
+    const double uu = u[row];
+    int pick = INT32_MAX;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = lane * CH + k;
+        if (i < n_cols) {
+            run += (double) pv[k] / total;
+            const double cp = i == n_cols - 1 ? 1.0 : run;
+            if (cp >= uu && i < pick) pick = i;
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
+    if (lane == 0) out[(size_t) row * out_stride] = pick;
+}
+void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, float temp, const double * u,
+                                    int32_t * out, int out_stride) {
+    hipLaunchKernelGGL(sample_rows_multinomial_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, temp, u, out, out_stride);
+}
+
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
-    hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+    if (a.temp > 0.0f) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
