@@ -37,7 +37,7 @@ class BarkHipStats(C.Structure):
         ("t_load_us", C.c_int64), ("t_eval_us", C.c_int64), ("t_semantic_us", C.c_int64), ("t_coarse_us", C.c_int64),
         ("t_fine_us", C.c_int64), ("t_codec_us", C.c_int64), ("n_sample_semantic", C.c_int64), ("n_sample_coarse", C.c_int64),
         ("n_sample_fine", C.c_int64), ("n_semantic", C.c_int32), ("n_frames", C.c_int32), ("n_samples", C.c_int32),
-        ("n_near_tie", C.c_int32), ("graph_replays", C.c_int32),
+        ("n_near_tie", C.c_int32), ("graph_replays", C.c_int32), ("n_prefix_rows_reused", C.c_int32),
     ]
 
     def as_dict(self):

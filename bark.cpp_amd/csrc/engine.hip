@@ -335,7 +335,7 @@ float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
 
 // N > 1 rows through all layers (bark.cpp:1261-1389 causal, :1474-1562 fine); x holds the embeddings.
-void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr) {
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
     // kbase / vbase: another utterance slot's cache (batched decode); default: the context's own cache
@@ -346,10 +346,10 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
         LinArgs a;
         a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.bias = L.attn_b; a.epi = EPI_QKV;
-        a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0;
+        a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         launch_linear(s, a);
         AttnPrefillArgs at;
-        at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = 0;
+        at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
         at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E;
         { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
@@ -430,12 +430,13 @@ void check_ids(const int32_t * tok, size_t n, int n_in, const char * what) {
 }
 
 // prompt rows -> x, all layers.  merge: the 513-id semantic prompt collapses to 257 rows (bark.cpp:1231-1248)
-int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge, float * kbase = nullptr, float * vbase = nullptr) {
+// pos0 > 0: the cache already holds rows 0..pos0-1 of this very sequence (prefix reuse); d_tokens then holds only the new ids
+int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0) {
     const int N = merge ? n_tokens - 256 : n_tokens;
     EmbedArgs e;
-    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.tokens = c->d_tokens; e.n_rows = N; e.merge = merge ? 1 : 0; e.pos0 = 0; e.x = c->x;
+    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.tokens = c->d_tokens; e.n_rows = N; e.merge = merge ? 1 : 0; e.pos0 = pos0; e.x = c->x;
     launch_embed_causal(c->stream, e);
-    run_layers_rows(c, m, N, true, kbase, vbase);
+    run_layers_rows(c, m, N, true, kbase, vbase, pos0);
     return N;
 }
 
@@ -711,6 +712,8 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
     const bool greedy = p.temp == 0.0f || !c->host_sampling;
     if (p.temp != 0.0f && greedy) upload_uniforms(c, n_steps);
     std::vector<int32_t> out;            // offset ids, as fed back into the model
+    std::vector<int32_t> cached;         // token ids whose K/V rows are valid in the cache (prefix reuse)
+    static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
     int step_idx = 0;
     for (int w = 0; w < n_windows; w++) {
         // window prompt (bark.cpp:1787-1807)
@@ -726,13 +729,35 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
         const int steps_here = std::min(p.sliding_window_size, n_steps - step_idx);
         if (N + steps_here - 1 > m.hp.block_size) throw std::runtime_error("coarse: window exceeds the context");
         check_ids(in.data(), in.size(), m.hp.n_in_vocab, "coarse");
-        upload_tokens(c, in.data(), in.size());
-        StepState st = fresh_state(); st.step = step_idx;
+        // Prefix reuse: the cache still holds the rows of the previous window's prompt and of the tokens decoded after
+        // it.  While the semantic slice does not move and the history is not truncated, the new prompt is that very
+        // sequence plus ONE token, so the reference's full re-evaluation (n_past = 0, bark.cpp:1809) collapses to a
+        // decode step; in general rows [0, L) are kept and only [L, N) are evaluated.  Row i depends on rows <= i only
+        // and both paths use the same canonical arithmetic, so the logits are bit-identical either way.
+        int L = 0;
+        if (greedy && reuse_prefix) {
+            while (L < N && L < (int) cached.size() && cached[(size_t) L] == in[(size_t) L]) L++;
+            if (L >= N) L = N - 1;
+        }
+        const int rows = N - L;
+        StepState st = fresh_state(); st.step = step_idx; st.n_past = L; st.cur_token = in[(size_t) L];
         set_state(c, st);
-        run_prefill(c, m, N, false);
+        if (greedy && rows == 1) {
+            EmbedArgs e;
+            e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
+            launch_embed_causal(c->stream, e);
+            decode_step_greedy(c, s);
+            c->stats.n_prefix_rows_reused += L;
+        } else {
+            upload_tokens(c, in.data() + L, (size_t) rows);
+            run_prefill(c, m, rows, false, nullptr, nullptr, L);
+            c->stats.n_prefix_rows_reused += L;
+        }
         if (greedy) {
-            run_lm_head(c, m, c->x + (size_t) (N - 1) * m.hp.n_embd, s.lm_row0, s.lm_rows, s.parity_rows);
-            run_sample(c, s, N);
+            if (rows > 1) {
+                run_lm_head(c, m, c->x + (size_t) (rows - 1) * m.hp.n_embd, s.lm_row0, s.lm_rows, s.parity_rows);
+                run_sample(c, s, rows);
+            }
             progress(c, COARSE, 100 * (step_idx + 1) / n_steps);
             for (int j = 1; j < steps_here; j++) {
                 decode_step_greedy(c, s);
@@ -742,6 +767,8 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
             std::vector<int32_t> got((size_t) steps_here);
             HIP_OK(hipMemcpy(got.data(), c->d_out_tokens, (size_t) steps_here * 4, hipMemcpyDeviceToHost));
             out.insert(out.end(), got.begin(), got.end());
+            cached = in;                                               // rows now in the cache: the prompt + every token fed back
+            cached.insert(cached.end(), got.begin(), got.end() - 1);
             step_idx += steps_here;
             c->stats.n_sample_coarse += steps_here;
             c->stats.n_near_tie += cur.near_tie;

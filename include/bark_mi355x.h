@@ -101,6 +101,7 @@ struct bark_hip_stats {
     int32_t n_semantic, n_frames, n_samples;
     int32_t n_near_tie;                                          /* greedy picks settled on the host  */
     int32_t graph_replays;                                       /* hipGraph launches issued          */
+    int32_t n_prefix_rows_reused;                                /* coarse prompt rows served from the KV cache */
 };
 BARK_API void bark_hip_get_stats(struct bark_context * bctx, struct bark_hip_stats * out);
 
