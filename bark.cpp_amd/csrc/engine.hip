@@ -1045,9 +1045,8 @@ std::vector<StepState> get_slot_states(bark_context * c, int B) {
 }
 
 // all slots: layers -> LM head -> greedy sample (+ embedding of the sampled token)
-void enqueue_batch_step(bark_context * c, const StageCfg & s, int B) {
+void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_context::Batch & bb) {
     GptModel & m = c->gpt[s.which];
-    bark_context::Batch & bb = c->batch;
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t st = c->stream;
     float * kc0 = bb.kc[s.which], * vc0 = bb.vc[s.which];
@@ -1098,7 +1097,7 @@ void batch_step(bark_context * c, const StageCfg & s, int B) {
         if (!bb.graph[s.which]) {
             hipGraph_t graph = nullptr;
             HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            try { enqueue_batch_step(c, s, B); }
+            try { enqueue_batch_step(c, s, B, bb); }
             catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
             HIP_OK(hipStreamEndCapture(c->stream, &graph));
             HIP_OK(hipGraphInstantiate(&bb.graph[s.which], graph, nullptr, nullptr, 0));
@@ -1108,20 +1107,39 @@ void batch_step(bark_context * c, const StageCfg & s, int B) {
         HIP_OK(hipGraphLaunch(bb.graph[s.which], c->stream));
         c->stats.graph_replays++;
     } else {
-        enqueue_batch_step(c, s, B);
+        enqueue_batch_step(c, s, B, bb);
     }
 }
 
+// the buffers of slot b alone, as a batch of one
+bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b) {
+    bark_context::Batch v = c->batch;
+    const size_t E = (size_t) c->gpt[s.which].hp.n_embd;
+    for (int g = 0; g < 2; g++) { v.kc[g] += v.slot_stride[g] * (size_t) b; v.vc[g] += v.slot_stride[g] * (size_t) b; }
+    v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
+    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048;
+    v.graph[0] = v.graph[1] = nullptr;
+    return v;
+}
+void embed_slot(bark_context * c, const StageCfg & s, int b) {
+    GptModel & m = c->gpt[s.which];
+    EmbedArgs e;
+    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1;
+    e.st = c->batch.state + b; e.x = c->batch.x + (size_t) b * m.hp.n_embd;
+    launch_embed_causal(c->stream, e);
+}
+
 // prompt of one slot through the model (single-utterance kernels, the slot's own cache), first sample of the slot
-void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, const std::vector<int32_t> & ids, bool merge, int step0) {
+// L > 0: rows [0, L) of the prompt are already in the slot's cache (prefix reuse); only ids[L..] are evaluated
+void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, const std::vector<int32_t> & ids, bool merge, int step0, int L = 0) {
     GptModel & m = c->gpt[s.which];
     bark_context::Batch & bb = c->batch;
     check_ids(ids.data(), ids.size(), m.hp.n_in_vocab, "batch prefill");
-    upload_tokens(c, ids.data(), ids.size());
-    StepState st = fresh_state(); st.step = step0;
+    upload_tokens(c, ids.data() + L, ids.size() - (size_t) L);
+    StepState st = fresh_state(); st.step = step0; st.n_past = L;
     set_slot_state(c, slot, st);
     float * kb = bb.kc[s.which] + bb.slot_stride[s.which] * (size_t) slot, * vb = bb.vc[s.which] + bb.slot_stride[s.which] * (size_t) slot;
-    const int N = run_prefill(c, m, (int) ids.size(), merge, kb, vb);
+    const int N = run_prefill(c, m, (int) ids.size() - L, merge, kb, vb, L);
     LinArgs h;
     h.W = m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd; h.M = s.lm_rows; h.K = m.hp.n_embd; h.N = 1;
     h.x_f32 = c->x + (size_t) (N - 1) * m.hp.n_embd; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
@@ -1213,16 +1231,15 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
             n_steps[(size_t) b] = (int) (floorf(sem.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);
             max_windows = std::max(max_windows, (int) ceilf((float) n_steps[(size_t) b] / p.sliding_window_size));
         }
+        std::vector<std::vector<int32_t>> cached((size_t) B);          // per slot: ids whose K/V rows are in its cache
+        static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
         for (int w = 0; w < max_windows; w++) {
             int max_here = 0;
-            std::vector<int> here((size_t) B, 0);
+            std::vector<int> here((size_t) B, 0), Ls((size_t) B, 0);
+            std::vector<std::vector<int32_t>> ins((size_t) B);
+            bool all_single = true;                                      // every live slot needs exactly one new row
             for (int b = 0; b < B; b++) {
-                if (step_idx[(size_t) b] >= n_steps[(size_t) b]) {           // finished (or empty) slot: park it at position 0
-                    StepState idle = fresh_state(); idle.cur_token = 0;
-                    idle.step = w * p.sliding_window_size;          // same codebook parity as the live slots (slot 0's step selects the LM-head rows)
-                    set_slot_state(c, b, idle);
-                    continue;
-                }
+                if (step_idx[(size_t) b] >= n_steps[(size_t) b]) continue;
                 const auto & sem = c->batch_results[(size_t) b].semantic;
                 auto & out = coarse_out[(size_t) b];
                 const int semantic_idx = (int) roundf(step_idx[(size_t) b] / stc_ratio);
@@ -1235,16 +1252,51 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
                 in.insert(in.end(), out.end() - nh, out.end());
                 here[(size_t) b] = std::min(p.sliding_window_size, n_steps[(size_t) b] - step_idx[(size_t) b]);
                 if ((int) in.size() + here[(size_t) b] - 1 > m.hp.block_size) throw std::runtime_error("coarse: window exceeds the context");
-                batch_prefill_and_sample(c, s, b, in, false, step_idx[(size_t) b]);
+                check_ids(in.data(), in.size(), m.hp.n_in_vocab, "coarse");
+                int L = 0;
+                if (reuse_prefix) {
+                    const auto & cd = cached[(size_t) b];
+                    while (L < (int) in.size() && L < (int) cd.size() && cd[(size_t) L] == in[(size_t) L]) L++;
+                    if (L >= (int) in.size()) L = (int) in.size() - 1;
+                }
+                Ls[(size_t) b] = L;
+                if ((int) in.size() - L != 1) all_single = false;
+                ins[(size_t) b] = std::move(in);
                 max_here = std::max(max_here, here[(size_t) b]);
             }
-            for (int j = 1; j < max_here; j++) batch_step(c, s, B);
+            int lock_steps = max_here - 1;                               // batched steps after every live slot has its first sample
+            for (int b = 0; b < B; b++) {
+                if (!here[(size_t) b]) {                                 // finished (or empty) slot: park it at position 0
+                    StepState idle = fresh_state(); idle.cur_token = 0;
+                    idle.step = w * p.sliding_window_size;          // same codebook parity as the live slots (slot 0's step selects the LM-head rows)
+                    set_slot_state(c, b, idle);
+                    continue;
+                }
+                const auto & in = ins[(size_t) b];
+                const int L = Ls[(size_t) b];
+                c->stats.n_prefix_rows_reused += L;
+                if ((int) in.size() - L == 1) {
+                    // the prompt is the cached sequence plus one token: a decode step (prefix reuse, see engine_coarse)
+                    StepState st1 = fresh_state(); st1.step = step_idx[(size_t) b]; st1.n_past = L; st1.cur_token = in[(size_t) L];
+                    set_slot_state(c, b, st1);
+                    embed_slot(c, s, b);
+                    if (!all_single) enqueue_batch_step(c, s, 1, slot_view(c, s, b));      // mixed window: this slot alone, eagerly
+                } else {
+                    batch_prefill_and_sample(c, s, b, in, false, step_idx[(size_t) b], L);
+                }
+            }
+            if (all_single && max_here > 0) lock_steps = max_here;       // the first sample of the window is a lock-step too
+            for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
             const std::vector<StepState> st = get_slot_states(c, B);
             for (int b = 0; b < B; b++) {
                 if (!here[(size_t) b]) continue;
                 std::vector<int32_t> got((size_t) here[(size_t) b]);
                 HIP_OK(hipMemcpy(got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4, hipMemcpyDeviceToHost));
                 coarse_out[(size_t) b].insert(coarse_out[(size_t) b].end(), got.begin(), got.end());
+                // rows now in the slot's cache: its prompt and every token fed back (a parked tail of lock steps past `here`
+                // wrote further rows, but those are never matched because the ids are not recorded)
+                cached[(size_t) b] = ins[(size_t) b];
+                cached[(size_t) b].insert(cached[(size_t) b].end(), got.begin(), got.end() - 1);
                 step_idx[(size_t) b] += here[(size_t) b];
                 c->stats.n_sample_coarse += here[(size_t) b];
                 c->stats.n_near_tie += st[(size_t) b].near_tie;
