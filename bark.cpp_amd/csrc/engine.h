@@ -91,7 +91,7 @@ struct bark_context {
         int cap = 0;
         float * kc[2] = {nullptr, nullptr}, * vc[2] = {nullptr, nullptr}; size_t slot_stride[2] = {0, 0};
         float * x = nullptr, * q = nullptr, * logits = nullptr; barkhip::half_t * att = nullptr, * h = nullptr;
-        barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr;
+        barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr; float * ln_stats = nullptr;
         size_t ld_logits = 0;
         hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
     } batch;

@@ -1028,6 +1028,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.h = dev_alloc<half_t>(c, (size_t) B * 4 * E);
     bb.logits = dev_alloc<float>(c, (size_t) B * bb.ld_logits);
     bb.state = dev_alloc<StepState>(c, (size_t) B);
+    bb.ln_stats = dev_alloc<float>(c, (size_t) B * 2);
     bb.out_tokens = dev_alloc<int32_t>(c, (size_t) B * 2048);
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
     bb.cap = B;
@@ -1051,11 +1052,15 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     hipStream_t st = c->stream;
     float * kc0 = bb.kc[s.which], * vc0 = bb.vc[s.which];
     const size_t slot = bb.slot_stride[s.which];
+    // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
+    // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
+    const bool hoist = B >= 24;
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
+        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs a;
-        a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot;
+        a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
         a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
         launch_linear(st, a);
@@ -1067,8 +1072,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
         launch_linear(st, p);
+        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
-        f.batched = 1; f.nbatch = B;
+        f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
         f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.lut = c->d_gelu_lut;
         launch_linear(st, f);
@@ -1077,8 +1083,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = 1; o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
         launch_linear(st, o);
     }
+    if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
     LinArgs h;
-    h.batched = 1; h.nbatch = B;
+    h.batched = 1; h.nbatch = B; h.ln_stats = hoist ? bb.ln_stats : nullptr;
     h.W = m.lm_head[0] + (size_t) s.lm_row0 * E; h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
     launch_linear(st, h);
@@ -1117,7 +1124,7 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
     const size_t E = (size_t) c->gpt[s.which].hp.n_embd;
     for (int g = 0; g < 2; g++) { v.kc[g] += v.slot_stride[g] * (size_t) b; v.vc[g] += v.slot_stride[g] * (size_t) b; }
     v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
-    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048;
+    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b;
     v.graph[0] = v.graph[1] = nullptr;
     return v;
 }

@@ -35,6 +35,7 @@ struct LinArgs {
     const half_t * x_f16 = nullptr;
     // ... or (decode GEMV only) one f32 row normalised in the kernel prologue (LayerNorm fused)
     const float * x_f32 = nullptr; const float * ln_g = nullptr; const float * ln_b = nullptr;
+    const float * ln_stats = nullptr;     // batched decode: {mean, 1/sqrt(var+eps)} per row from ln_stats_kernel (else computed in the kernel)
     const float * bias = nullptr;
     int epi = EPI_LOGITS;
     // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
@@ -69,6 +70,7 @@ void launch_embed_causal(hipStream_t s, const EmbedArgs & a);
 void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const float * wpe, int E, int n_in,
                        const int32_t * tokens_8x1024, int nn, float * x);
 
+void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats);
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
 
 // Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.

@@ -289,27 +289,40 @@ __global__ __launch_bounds__(64) void gemv_batch_kernel(const LinArgs a) {
         #pragma unroll
         for (int bb = 0; bb < BPW; bb++) {
             float xr[NBLK][8];
-            double p1[4] = {0.0, 0.0, 0.0, 0.0};
             #pragma unroll
             for (int b = 0; b < NBLK; b++) {
                 xr[b][0] = xa[bb][b][0].x; xr[b][1] = xa[bb][b][0].y; xr[b][2] = xa[bb][b][0].z; xr[b][3] = xa[bb][b][0].w;
                 xr[b][4] = xa[bb][b][1].x; xr[b][5] = xa[bb][b][1].y; xr[b][6] = xa[bb][b][1].z; xr[b][7] = xa[bb][b][1].w;
-                if ((b & 3) == rg) {
-                    #pragma unroll
-                    for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
-                }
             }
-            const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
-            const float mean = (float) (s1 / (double) K);
-            double p2[4] = {0.0, 0.0, 0.0, 0.0};
-            #pragma unroll
-            for (int b = 0; b < NBLK; b++) {
+            float mean, scale;
+            if (a.ln_stats) {
+                // statistics hoisted into ln_stats_kernel: otherwise every (row group, slot pair) wave would redo them
+                mean = a.ln_stats[2 * bi[bb]]; scale = a.ln_stats[2 * bi[bb] + 1];
                 #pragma unroll
-                for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; if ((b & 3) == rg) p2[e & 3] += (double) (v * v); }
+                for (int b = 0; b < NBLK; b++)
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) xr[b][e] = xr[b][e] - mean;
+            } else {
+                double p1[4] = {0.0, 0.0, 0.0, 0.0};
+                #pragma unroll
+                for (int b = 0; b < NBLK; b++) {
+                    if ((b & 3) == rg) {
+                        #pragma unroll
+                        for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
+                    }
+                }
+                const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+                mean = (float) (s1 / (double) K);
+                double p2[4] = {0.0, 0.0, 0.0, 0.0};
+                #pragma unroll
+                for (int b = 0; b < NBLK; b++) {
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; if ((b & 3) == rg) p2[e & 3] += (double) (v * v); }
+                }
+                const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+                const float var = (float) (s2 / (double) K);
+                scale = 1.0f / sqrtf(var + 1e-5f);
             }
-            const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
-            const float var = (float) (s2 / (double) K);
-            const float scale = 1.0f / sqrtf(var + 1e-5f);
             #pragma unroll
             for (int b = 0; b < NBLK; b++) {
                 const float gg[8] = {ga[b][0].x, ga[b][0].y, ga[b][0].z, ga[b][0].w, ga[b][1].x, ga[b][1].y, ga[b][1].z, ga[b][1].w};
@@ -648,6 +661,25 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float * x, int N, in
         if (b) v = v + b[e];
         o[e] = to_half(v);
     }
+}
+// LayerNorm statistics only (batched decode): stats[row] = {mean, 1/sqrt(var + eps)}, same arithmetic as ln_rows_kernel
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float * x, int N, int E, float * stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = 1.0f / sqrtf(var + 1e-5f); }
+}
+void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, stats);
 }
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
     hipLaunchKernelGGL(ln_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);
