@@ -93,6 +93,127 @@ void launch_convtr1d(hipStream_t s, const half_t * w, const float * bias, int ci
     hipLaunchKernelGGL(convtr1d_kernel, dim3((T * stride + 255) / 256, cout), dim3(256), 0, s, w, bias, cin, cout, K, stride, xh, T, y);
 }
 
+// Register-blocked variants (same chain order per output element: ci ascending, k ascending, bias last).
+// Weights are kept as f32 copies of the f16 file values (exact) so that a wave-uniform weight becomes a scalar load and an
+// SGPR operand of v_fma_f32; every x value loaded is reused by CO x (taps that touch it) multiply-adds.
+template <int CO, int TT, int K>
+__global__ __launch_bounds__(256) void conv1d_blocked_kernel(const float * __restrict__ w, const float * __restrict__ bias, int cout, int cin,
+                                                            const half_t * __restrict__ xh, int T, const float * add, float * y) {
+    const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * TT;
+    const int co0 = blockIdx.y * CO;
+    if (t0 >= T) return;
+    float acc[CO][TT];
+    #pragma unroll
+    for (int c = 0; c < CO; c++)
+        #pragma unroll
+        for (int j = 0; j < TT; j++) acc[c][j] = 0.0f;
+    const bool interior = t0 >= K - 1 && t0 + TT <= T;
+    for (int ci = 0; ci < cin; ci++) {
+        const half_t * xr = xh + (size_t) ci * T;
+        float xv[TT + K - 1];                                   // inputs t0-(K-1) .. t0+TT-1, reflect-padded on the left
+        if (interior) {
+            #pragma unroll
+            for (int i = 0; i < TT + K - 1; i++) xv[i] = (float) xr[t0 - (K - 1) + i];
+        } else {
+            #pragma unroll
+            for (int i = 0; i < TT + K - 1; i++) {
+                int j = t0 - (K - 1) + i;
+                j = j < 0 ? -j : j;
+                xv[i] = j < T ? (float) xr[j] : 0.0f;
+            }
+        }
+        #pragma unroll
+        for (int c = 0; c < CO; c++) {
+            const float * wr = w + ((size_t) min(co0 + c, cout - 1) * cin + ci) * K;     // wave-uniform: scalar loads
+            #pragma unroll
+            for (int k = 0; k < K; k++) {
+                const float wk = wr[k];
+                #pragma unroll
+                for (int j = 0; j < TT; j++) acc[c][j] = fmaf(wk, xv[j + k], acc[c][j]);
+            }
+        }
+    }
+    #pragma unroll
+    for (int c = 0; c < CO; c++) {
+        const int co = co0 + c;
+        if (co >= cout) break;
+        #pragma unroll
+        for (int j = 0; j < TT; j++) {
+            const int t = t0 + j;
+            if (t >= T) break;
+            float v = acc[c][j] + bias[co];
+            if (add) v = v + add[(size_t) co * T + t];
+            y[(size_t) co * T + t] = v;
+        }
+    }
+}
+
+// transposed conv with K == 2 * stride: output to = t*s + kk takes x[t-1] (tap kk+s) then x[t] (tap kk).
+// Thread = time step t; the block owns CO output channels x KB phases kk, whose weights are wave-uniform.
+template <int CO, int KB>
+__global__ __launch_bounds__(256) void convtr1d_blocked_kernel(const float * __restrict__ w, const float * __restrict__ bias, int cin, int cout,
+                                                              int stride, const half_t * __restrict__ xh, int T, float * y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nkb = stride / KB;                                  // phase groups per channel group (stride % KB == 0)
+    const int co0 = (blockIdx.y / nkb) * CO, kk0 = (blockIdx.y % nkb) * KB;
+    if (t >= T) return;
+    const int K = 2 * stride;
+    float acc[CO][KB];
+    #pragma unroll
+    for (int c = 0; c < CO; c++)
+        #pragma unroll
+        for (int q = 0; q < KB; q++) acc[c][q] = 0.0f;
+    for (int ci = 0; ci < cin; ci++) {
+        const half_t * xr = xh + (size_t) ci * T;
+        const float xp = t > 0 ? (float) xr[t - 1] : 0.0f, xc = (float) xr[t];
+        #pragma unroll
+        for (int c = 0; c < CO; c++) {
+            const float * wr = w + ((size_t) ci * cout + min(co0 + c, cout - 1)) * K + kk0;      // wave-uniform
+            #pragma unroll
+            for (int q = 0; q < KB; q++) {
+                if (t > 0) acc[c][q] = fmaf(wr[q + stride], xp, acc[c][q]);
+                acc[c][q] = fmaf(wr[q], xc, acc[c][q]);
+            }
+        }
+    }
+    const int Tout = T * stride;
+    #pragma unroll
+    for (int c = 0; c < CO; c++) {
+        const int co = co0 + c;
+        if (co >= cout) break;
+        #pragma unroll
+        for (int q = 0; q < KB; q++) y[(size_t) co * Tout + (size_t) t * stride + kk0 + q] = acc[c][q] + bias[co];
+    }
+}
+
+void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
+                        const float * add, float * y) {
+    constexpr int TT = 4;
+    const int co_grp = cout >= 4 ? 4 : 1;
+    dim3 grid((T + 256 * TT - 1) / (256 * TT), (cout + co_grp - 1) / co_grp), block(256);
+#define LAUNCH_CONV(CO, KK) hipLaunchKernelGGL((conv1d_blocked_kernel<CO, TT, KK>), grid, block, 0, s, w, bias, cout, cin, xh, T, add, y)
+    if (co_grp == 4) { if (K == 7) LAUNCH_CONV(4, 7); else if (K == 3) LAUNCH_CONV(4, 3); else if (K == 1) LAUNCH_CONV(4, 1); else abort(); }
+    else             { if (K == 7) LAUNCH_CONV(1, 7); else if (K == 3) LAUNCH_CONV(1, 3); else if (K == 1) LAUNCH_CONV(1, 1); else abort(); }
+#undef LAUNCH_CONV
+}
+bool conv1d_f32w_supported(int K) { return K == 7 || K == 3 || K == 1; }
+
+void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh, int T, float * y) {
+    if (K != 2 * stride) abort();
+    const int KB = stride % 4 == 0 ? 4 : (stride % 2 == 0 ? 2 : 1);
+    const int CO = cout >= 2 ? 2 : 1;
+    dim3 grid((T + 255) / 256, ((cout + CO - 1) / CO) * (stride / KB)), block(256);
+    if (CO == 2) {
+        if (KB == 4) hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 4>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+        else if (KB == 2) hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 2>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+        else hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 1>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+    } else {
+        if (KB == 4) hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 4>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+        else if (KB == 2) hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 2>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+        else hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 1>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y);
+    }
+}
+
 __global__ void transpose_round_kernel(const float * x, int C, int T, half_t * xt) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;

@@ -40,8 +40,9 @@ struct CodecModel {
     CodecHparams hp;
     int n_q = 0, D = 0;
     const float * codebooks = nullptr;                  // [n_q][n_bins][hidden_dim]
-    struct Conv { const half_t * w = nullptr; const float * b = nullptr; int cout = 0, cin = 0, k = 0; };
-    struct ConvT { const half_t * w = nullptr; const float * b = nullptr; int cin = 0, cout = 0, k = 0, stride = 0; };
+    // w32: f32 copy of the f16 weights (exact), read through scalar loads by the register-blocked kernels
+    struct Conv { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; int cout = 0, cin = 0, k = 0; };
+    struct ConvT { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; int cin = 0, cout = 0, k = 0, stride = 0; };
     struct Lstm { const half_t * w_ih = nullptr, * w_hh = nullptr; const float * b_ih = nullptr, * b_hh = nullptr; };
     Conv init, fin;
     Lstm lstm[2];
@@ -64,7 +65,7 @@ struct bark_context {
 
     // device memory.  The weight slab (and the codec codebooks) are immutable after load and shared by every
     // context cloned from this one (bark_hip_clone_context): replicas on one GPU stream the same bytes.
-    struct SharedWeights { void * slab = nullptr; void * codebooks = nullptr; int device = 0; ~SharedWeights(); };
+    struct SharedWeights { void * slab = nullptr; void * codebooks = nullptr; std::vector<void *> extra; int device = 0; ~SharedWeights(); };
     std::shared_ptr<SharedWeights> weights;
     size_t weight_bytes = 0;
     std::vector<void *> allocs;                         // everything else (freed in destroy)

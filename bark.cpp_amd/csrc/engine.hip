@@ -93,6 +93,7 @@ bark_context::SharedWeights::~SharedWeights() {
     (void) hipSetDevice(device);
     if (slab) (void) hipFree(slab);
     if (codebooks) (void) hipFree(codebooks);
+    for (void * p : extra) (void) hipFree(p);
 }
 
 namespace barkhip {
@@ -281,6 +282,29 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         (void) hipHostFree(stage);
     }
     for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weights->slab + f.off;
+    {
+        // f32 copies of the codec's conv weights (19 MB of f16 in the file): exact, and wave-uniform f32 weights become
+        // scalar loads / SGPR operands in the register-blocked conv kernels
+        auto widen = [&](const TensorRef & t) -> const float * {
+            std::vector<float> f((size_t) t.nelements());
+            for (size_t i = 0; i < f.size(); i++) { uint16_t b; memcpy(&b, t.data + 2 * i, 2); f[i] = (float) __builtin_bit_cast(_Float16, b); }
+            float * d = nullptr;
+            HIP_OK(hipMalloc((void **) &d, f.size() * sizeof(float)));
+            ctx->weights->extra.push_back(d);
+            HIP_OK(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+            return d;
+        };
+        auto cw = [&](const std::string & p) { return widen(need(mf.codec, p + ".weight", 1, 0, 0)); };
+        cm.init.w32 = cw("decoder.model.0.conv.conv");
+        for (int i = 0; i < 4; i++) {
+            const int idx = 3 + 3 * i;
+            cm.blocks[i].up.w32 = cw("decoder.model." + std::to_string(idx) + ".convtr.convtr");
+            cm.blocks[i].c1.w32 = cw("decoder.model." + std::to_string(idx + 1) + ".block.1.conv.conv");
+            cm.blocks[i].c2.w32 = cw("decoder.model." + std::to_string(idx + 1) + ".block.3.conv.conv");
+            cm.blocks[i].sc.w32 = cw("decoder.model." + std::to_string(idx + 1) + ".shortcut.conv.conv");
+        }
+        cm.fin.w32 = cw("decoder.model.15.conv.conv");
+    }
     {
         const size_t per = (size_t) cm.hp.n_bins * cm.hp.hidden_dim;
         float * cb = nullptr;
@@ -890,10 +914,12 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
     HIP_OK(hipMemcpyAsync(c->d_codes, codes, (size_t) n_q * T * 4, hipMemcpyHostToDevice, s));
     float * A = c->cbuf[0], * B = c->cbuf[1], * R = c->cbuf[2];
     half_t * Hh = c->cbuf_h;
+    static const bool blocked = !getenv("BARK_HIP_CODEC_NAIVE");      // register-blocked convs (default) vs the one-output-per-thread kernels
 
     auto conv = [&](const CodecModel::Conv & cv, const float * in, bool elu, int Tc, const float * add, float * out) {
         launch_act_round(s, in, (size_t) cv.cin * Tc, elu ? 1 : 0, Hh);
-        launch_conv1d(s, cv.w, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
+        if (blocked && cv.w32 && conv1d_f32w_supported(cv.k)) launch_conv1d_f32w(s, cv.w32, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
+        else launch_conv1d(s, cv.w, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
     };
     // RVQ de-embedding, first conv
     launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, T, A);
@@ -931,7 +957,8 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
     for (int b = 0; b < 4; b++) {
         const CodecModel::Block & bl = cm.blocks[b];
         launch_act_round(s, cur, (size_t) bl.up.cin * Tc, 1, Hh);
-        launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
+        if (blocked && bl.up.w32 && bl.up.k == 2 * bl.up.stride) launch_convtr1d_f32w(s, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
+        else launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
         Tc *= bl.up.stride;
         std::swap(cur, other);                                          // cur = upsampled x
         // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)

@@ -131,6 +131,12 @@ void launch_conv1d(hipStream_t s, const half_t * w, const float * bias, int cout
 // causal transposed conv, stride s, output trimmed to T*s: y[co][to] = b[co] + chain over (ci, t) of w[ci][co][to - t*s] * xh[ci][t]
 void launch_convtr1d(hipStream_t s, const half_t * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
                      int T, float * y);
+// register-blocked variants reading f32 copies of the (f16-valued) weights; same per-element chain order
+void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
+                        const float * add, float * y);
+bool conv1d_f32w_supported(int K);
+void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
+                          int T, float * y);
 // xt[t][c] = f16(x[c][t])
 void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt);
 // one LSTM time step for all D units (PyTorch gate order i,f,g,o); hprev_h: f16 h_{t-1} [D] or nullptr at t = 0

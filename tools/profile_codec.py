@@ -1,0 +1,10 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bark_amd_loader import load_package
+from tools.make_synth_model import ensure_model
+pkg = load_package()
+c = pkg.BarkContext.load_model(ensure_model("small", 0), pkg.default_params(temp=0.0, fine_temp=0.0), 0)
+codes = np.random.default_rng(0).integers(0, 1024, (8, 384)).astype(np.int32)
+for _ in range(3):
+    c.codec_decode(codes)
