@@ -237,11 +237,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmStepArgs a) {
     const int c = lane & 15, g = lane >> 4;
     const int d = blockIdx.x * 4 + wave;
     const int D = a.D, nblk = D >> 7;
-    if (d >= D) return;
+    // time step: either baked into the launch (a.t) or base + node offset (a.t_base, graph replay of a block of steps)
+    const int t = a.t_base ? a.t_base[0] + a.t : a.t;
+    const int T = a.t_base ? a.t_base[1] : a.T;              // replayed block: the sequence length also lives on the device
+    if (d >= D || t >= T) return;
+    const float * gi = a.gi + (size_t) t * 4 * D;
+    const half_t * hprev = t ? a.hseq_h + (size_t) (t - 1) * D : nullptr;
     float acc = 0.0f;
-    if (a.hprev_h) {
+    if (hprev) {
         const half_t * wrow = a.w_hh + (size_t) (g * D + d) * D + (c << 3);
-        const half_t * hrow = a.hprev_h + (c << 3);
+        const half_t * hrow = hprev + (c << 3);
         for (int b = 0; b < nblk; b++) {
             const half8 wv = *reinterpret_cast<const half8 *>(wrow + (b << 7));
             const half8 hv = *reinterpret_cast<const half8 *>(hrow + (b << 7));
@@ -251,25 +256,26 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmStepArgs a) {
     }
     acc = acc + __shfl_xor(acc, 1, 64); acc = acc + __shfl_xor(acc, 2, 64);
     acc = acc + __shfl_xor(acc, 4, 64); acc = acc + __shfl_xor(acc, 8, 64);
-    // gate pre-activation (gi + b_ih) + (gh + b_hh), evaluated by lane 0 of each 16-lane group
-    const float pre = (a.gi[g * D + d] + a.b_ih[g * D + d]) + (acc + a.b_hh[g * D + d]);
-    const float pi = __shfl(pre, 0, 64), pf = __shfl(pre, 16, 64), pg = __shfl(pre, 32, 64), po = __shfl(pre, 48, 64);
+    // gate pre-activation (gi + b_ih) + (gh + b_hh); every lane of 16-lane group g evaluates gate g's non-linearity, so
+    // the four double-precision transcendentals run side by side instead of back to back on one lane
+    const float pre = (gi[g * D + d] + a.b_ih[g * D + d]) + (acc + a.b_hh[g * D + d]);
+    const float act = g == 2 ? (float) tanh((double) pre) : 1.0f / (1.0f + (float) exp((double) (-pre)));
+    const float i_t = __shfl(act, 0, 64), f_t = __shfl(act, 16, 64), g_t = __shfl(act, 32, 64), o_t = __shfl(act, 48, 64);
     if (lane == 0) {
-        const float i_t = 1.0f / (1.0f + (float) exp((double) (-pi)));
-        const float f_t = 1.0f / (1.0f + (float) exp((double) (-pf)));
-        const float g_t = (float) tanh((double) pg);
-        const float o_t = 1.0f / (1.0f + (float) exp((double) (-po)));
-        const float cn = f_t * a.c[d] + i_t * g_t;
+        const float cprev = t ? a.c[d] : 0.0f;
+        const float cn = f_t * cprev + i_t * g_t;
         const float hn = o_t * (float) tanh((double) cn);
         a.c[d] = cn;
-        a.hout_h[d] = to_half(hn);
-        a.hseq[(size_t) d * a.T + a.t] = hn;
+        a.hseq_h[(size_t) t * D + d] = to_half(hn);
+        a.hseq[(size_t) d * T + t] = hn;
     }
 }
 void launch_lstm_step(hipStream_t s, const LstmStepArgs & a) {
     hipLaunchKernelGGL(lstm_step_kernel, dim3((a.D + 3) / 4), dim3(256), 0, s, a);
 }
 
+__global__ void add_int_kernel(int * p, int v) { *p += v; }      // p[0]: step base of the replayed LSTM block
+void launch_add_int(hipStream_t s, int * p, int v) { hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, s, p, v); }
 __global__ void add_kernel(const float * a, const float * b, size_t n, float * out) {
     for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }

@@ -86,6 +86,7 @@ bark_context::~bark_context() {
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
+    for (auto & g : lstm_graphs) if (g.exec) (void) hipGraphExecDestroy(g.exec);
     for (void * p : allocs) (void) hipFree(p);
     if (stream) (void) hipStreamDestroy(stream);
 }
@@ -137,6 +138,7 @@ static void init_runtime(bark_context * ctxp) {
     ctx->d_out_tokens = dev_alloc<int32_t>(ctx.get(), 2048);
     ctx->d_eos_trace = dev_alloc<float>(ctx.get(), 2048);
     ctx->d_state = dev_alloc<StepState>(ctx.get(), 1);
+    ctx->d_lstm_t = dev_alloc<int>(ctx.get(), 2);
     ctx->d_u = dev_alloc<double>(ctx.get(), 8192);
     { const char * e = getenv("BARK_HIP_HOST_SAMPLING"); ctx->host_sampling = e && atoi(e) != 0; }
     ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
@@ -933,14 +935,33 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
         LinArgs g;
         g.W = cm.lstm[l].w_ih; g.M = 4 * D; g.K = D; g.N = T; g.x_f16 = seq_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
         launch_linear(s, g);
-        HIP_OK(hipMemsetAsync(c->c_cell, 0, (size_t) D * 4, s));
         float * hseq = (l == 0) ? A : R;                                // layer outputs [D][T]
-        for (int t = 0; t < T; t++) {
-            LstmStepArgs a;
-            a.w_hh = cm.lstm[l].w_hh; a.b_ih = cm.lstm[l].b_ih; a.b_hh = cm.lstm[l].b_hh; a.gi = c->c_gi + (size_t) t * 4 * D;
-            a.hprev_h = t ? c->c_hseq_h + (size_t) (t - 1) * D : nullptr; a.c = c->c_cell; a.hout_h = c->c_hseq_h + (size_t) t * D;
-            a.hseq = hseq; a.T = T; a.t = t; a.D = D;
-            launch_lstm_step(s, a);
+        // T strictly sequential steps.  64 of them are captured once per context and layer as a hipGraph whose nodes
+        // take their step index from a device counter (base) + the node's offset, so one graph serves every T.
+        LstmStepArgs a;
+        a.w_hh = cm.lstm[l].w_hh; a.b_ih = cm.lstm[l].b_ih; a.b_hh = cm.lstm[l].b_hh; a.gi = c->c_gi;
+        a.c = c->c_cell; a.hseq_h = c->c_hseq_h; a.hseq = hseq; a.T = T; a.D = D;
+        if (!c->use_graph) {
+            for (int t = 0; t < T; t++) { a.t = t; launch_lstm_step(s, a); }
+        } else {
+            constexpr int kBlock = 64;
+            auto & slot = c->lstm_graphs[l];
+            if (slot.exec && (slot.hseq != hseq || slot.gi != c->c_gi)) { (void) hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+            if (!slot.exec) {
+                hipGraph_t graph = nullptr;
+                HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                a.t_base = c->d_lstm_t;
+                for (int i = 0; i < kBlock; i++) { a.t = i; launch_lstm_step(s, a); }
+                launch_add_int(s, c->d_lstm_t, kBlock);
+                HIP_OK(hipStreamEndCapture(s, &graph));
+                HIP_OK(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
+                (void) hipGraphDestroy(graph);
+                slot.T = T; slot.hseq = hseq; slot.gi = c->c_gi;
+            }
+            const int hdr[2] = {0, T};
+            HIP_OK(hipMemcpyAsync(c->d_lstm_t, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+            HIP_OK(hipStreamSynchronize(s));                         // hdr is a stack object
+            for (int t0 = 0; t0 < T; t0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
         }
     }
     auto grab = [&](int stage, const float * buf, size_t n) {

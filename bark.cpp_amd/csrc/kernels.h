@@ -142,12 +142,15 @@ void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t
 // one LSTM time step for all D units (PyTorch gate order i,f,g,o); hprev_h: f16 h_{t-1} [D] or nullptr at t = 0
 struct LstmStepArgs {
     const half_t * w_hh = nullptr; const float * b_ih = nullptr; const float * b_hh = nullptr;
-    const float * gi = nullptr;          // W_ih x_t for this t: [4D]
-    const half_t * hprev_h = nullptr; float * c = nullptr;   // cell state [D], updated in place
-    half_t * hout_h = nullptr;           // f16(h_t) [D]  (row t of the time-major sequence)
-    float * hseq = nullptr; int T = 0, t = 0; int D = 0;     // hseq[d*T + t] = h_t
+    const float * gi = nullptr;          // W_ih x_t for every t: [T][4D]
+    float * c = nullptr;                 // cell state [D] (read from step 1 on, written every step)
+    half_t * hseq_h = nullptr;           // f16(h_t), time major [T][D]: row t-1 is this step's recurrent input
+    float * hseq = nullptr; int T = 0, D = 0;     // hseq[d*T + t] = h_t
+    int t = 0;                           // this launch's step, or its offset inside a replayed block of steps ...
+    const int * t_base = nullptr;        // ... added to t_base[0] (device) when non-null; then t_base[1] holds T
 };
 void launch_lstm_step(hipStream_t s, const LstmStepArgs & a);
+void launch_add_int(hipStream_t s, int * p, int v);       // *p += v
 void launch_add(hipStream_t s, const float * a, const float * b, size_t n, float * out);
 
 }  // namespace barkhip
