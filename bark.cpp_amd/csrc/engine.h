@@ -85,6 +85,7 @@ struct bark_context {
     barkhip::half_t * cbuf_h = nullptr; size_t cbuf_h_elems = 0;
     float * c_gi = nullptr, * c_cell = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr; size_t c_T = 0;
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
+    hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook
     int * d_lstm_t = nullptr;                           // step counter of the replayed LSTM block
     struct LstmGraph { hipGraphExec_t exec = nullptr; int T = 0; const float * hseq = nullptr; const float * gi = nullptr; } lstm_graphs[2];
 

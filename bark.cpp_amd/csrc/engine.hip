@@ -87,6 +87,7 @@ bark_context::~bark_context() {
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
     for (auto & g : lstm_graphs) if (g.exec) (void) hipGraphExecDestroy(g.exec);
+    for (auto & g : fine_graphs) if (g) (void) hipGraphExecDestroy(g);
     for (void * p : allocs) (void) hipFree(p);
     if (stream) (void) hipStreamDestroy(stream);
 }
@@ -101,6 +102,7 @@ namespace barkhip {
 
 void engine_invalidate_graphs(bark_context * ctx) {
     for (auto & g : ctx->batch.graph) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
+    for (auto & g : ctx->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
     for (auto & g : ctx->gpt) {
         if (g.decode_graph) { (void) hipGraphExecDestroy(g.decode_graph); g.decode_graph = nullptr; }
         if (g.bench_graph) { (void) hipGraphExecDestroy(g.bench_graph); g.bench_graph = nullptr; }
@@ -856,13 +858,30 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
     // one window (T <= 1024  =>  n_loops == 1, start_idx == 0, rel_start_fill_idx == 0)
     for (int nn = nc; nn < nf; nn++) {
         progress(c, FINE, 100 * (nn - nc + 1) / (nf - nc));
-        if (greedy) {
-            run_fine_forward(c, nn, cs);                   // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
-            launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, c->d_tokens + (size_t) nn * 1024, 1, c->d_state);
-        } else if (device_multinomial) {
-            run_fine_forward(c, nn, cs);
-            launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024,
-                                           c->d_tokens + (size_t) nn * 1024, 1);
+        if (greedy || device_multinomial) {
+            // one pass = embed -> 12 layers -> head -> per-row pick, captured once per codebook as a hipGraph
+            auto enqueue = [&] {
+                run_fine_forward(c, nn, cs);               // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
+                if (greedy) launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, c->d_tokens + (size_t) nn * 1024, 1, c->d_state);
+                else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024,
+                                                    c->d_tokens + (size_t) nn * 1024, 1);
+            };
+            if (c->use_graph) {
+                hipGraphExec_t & g = c->fine_graphs[nn];
+                if (!g) {
+                    hipGraph_t graph = nullptr;
+                    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                    try { enqueue(); }
+                    catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+                    HIP_OK(hipStreamEndCapture(c->stream, &graph));
+                    HIP_OK(hipGraphInstantiate(&g, graph, nullptr, nullptr, 0));
+                    (void) hipGraphDestroy(graph);
+                }
+                HIP_OK(hipGraphLaunch(g, c->stream));
+                c->stats.graph_replays++;
+            } else {
+                enqueue();
+            }
         } else {
             const int n_out = m.hp.n_out_vocab;
             run_fine_forward(c, nn, n_out);
