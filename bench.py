@@ -57,12 +57,16 @@ def main():
     ap.add_argument("--n-semantic", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N > 1 path on a single GPU (with --backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.all_ranks_on_device0:
+        local_rank = 0
     os.environ["BARK_HIP_DEVICE"] = str(local_rank)
 
     import numpy as np
@@ -73,7 +77,7 @@ def main():
 
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")          # RCCL
+        dist.init_process_group(a.backend)       # "nccl" is RCCL on ROCm
     pkg = load_package()
     if rank == 0:
         path = ensure_model(a.preset, 0)
@@ -108,13 +112,13 @@ def main():
             agg[k] += st[k]
     sync_all()
     dt = time.perf_counter() - t0
-    dt, audio_total = reduce_timing(dt, audio_s, world, device="cuda" if world > 1 else None)
+    dt, audio_total = reduce_timing(dt, audio_s, world, device="cuda" if (world > 1 and a.backend == "nccl") else None)
 
     if rank == 0:
         out = {
             "metric": "audio-sec/sec (RTF), bark-small f16 greedy", "value": audio_total / dt, "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / max(1, a.steps),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32-accumulate over f16 weights (exact fmaf chains)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"bark-{a.preset} f16 on 1xMI355X per rank, single prompt per step, greedy, hipGraph decode, "
                                    f"n_steps_text_encoder={a.n_semantic}", "prompts_per_step": world,
