@@ -22,6 +22,12 @@ for f in model_file.cpp tokenizer.cpp; do
         pids+=($!)
     fi
 done
+# quantize.cpp uses _Float16 conversions: ROCm's clang has the type on the host, gcc 11 does not
+o="$OUT/obj/quantize.o"
+if [ ! -f "$o" ] || [ "$SRC/quantize.cpp" -nt "$o" ] || [ -n "$(find "$SRC" -name '*.h' -newer "$o" 2>/dev/null | head -1)" ]; then
+    /opt/rocm/lib/llvm/bin/clang++ -O2 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wall -I"$SRC" -c "$SRC/quantize.cpp" -o "$o" &
+    pids+=($!)
+fi
 for p in "${pids[@]}"; do wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbark.so" "$OUT"/obj/*.o
 echo "built $OUT/libbark.so"

@@ -85,9 +85,12 @@ void bark_reset_statistics(struct bark_context * bctx) {
 }
 
 bool bark_model_quantize(const char * fname_inp, const char * fname_out, enum ggml_ftype ftype) {
-    (void) fname_inp; (void) fname_out; (void) ftype;
-    fprintf(stderr, "bark_model_quantize: the offline quantizer is outside this engine's scope (hot path only); use the reference tool\n");
-    return false;
+    if (!fname_inp || !fname_out) { fprintf(stderr, "bark_model_quantize: null path\n"); return false; }
+    return guarded("bark_model_quantize", false, [&] {
+        std::string err;
+        if (!model_quantize(fname_inp, fname_out, (int) ftype, err)) { fprintf(stderr, "bark_model_quantize: %s\n", err.c_str()); return false; }
+        return true;
+    });
 }
 
 void bark_free(struct bark_context * bctx) { delete bctx; }

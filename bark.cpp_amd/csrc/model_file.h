@@ -56,4 +56,7 @@ struct ModelFile {
     bool open(const char * path, std::string & err);
 };
 
+// bark_model_quantize (bark.cpp:2300-2377): f16/f32 file -> Q4_0 file (quantize.cpp)
+bool model_quantize(const char * fname_inp, const char * fname_out, int ftype, std::string & err);
+
 }  // namespace barkhip
