@@ -84,7 +84,7 @@ static inline uint16_t ld_u16(const uint8_t * p, size_t i) { uint16_t v; memcpy(
 // model file (layout: convert.py:59-110,202-322 ; bark.cpp:664-727,995-1068)
 // ------------------------------------------------------------------------------------
 struct Tensor {
-    int      ttype = 0;            // 0 f32, 1 f16
+    int      ttype = 0;            // 0 f32, 1 f16, 2 q4_0
     int      n_dims = 0;
     int64_t  ne[4] = {1, 1, 1, 1}; // ne[0] innermost
     const uint8_t * data = nullptr;  // into the file mapping; NOT necessarily aligned
@@ -113,11 +113,12 @@ static bool read_tensor_record(Reader & r, std::string & name, Tensor & t) {
     const uint8_t * nm = r.skip(len);
     if (!r.ok) return false;
     name.assign((const char *) nm, len);
-    if (t.ttype != 0 && t.ttype != 1) {
-        fprintf(stderr, "oracle: tensor '%s' has type %d; only f32/f16 files are restated\n", name.c_str(), t.ttype);
+    if (t.ttype != 0 && t.ttype != 1 && t.ttype != 2) {
+        fprintf(stderr, "oracle: tensor '%s' has type %d; only f32 / f16 / q4_0 files are restated\n", name.c_str(), t.ttype);
         return false;
     }
-    size_t bytes = (size_t) t.nelements() * (t.ttype == 1 ? 2 : 4);
+    // q4_0: 32 weights per 18-byte block {f16 d; 16 nibble bytes}  (ggml block_q4_0)
+    size_t bytes = t.ttype == 2 ? (size_t) t.nelements() / 32 * 18 : (size_t) t.nelements() * (t.ttype == 1 ? 2 : 4);
     t.data = r.skip(bytes);
     return r.ok;
 }
@@ -169,10 +170,11 @@ static void canon_image_f32(const float * src, int K, float * dst) {
 // Weight matrices are re-imaged once at load time (CanonW); f16 weights stay f16 (exact).
 struct CanonW {
     int M = 0, K = 0, Kp = 0; bool f16 = false;
+    const uint8_t * q4 = nullptr;                       // q4_0 weights stay in file order: [M][K/32] blocks of 18 bytes
     uint8_t * data = nullptr; size_t bytes = 0;         // [M][Kp] in chain-major order
     CanonW() = default;
     CanonW(const CanonW &) = delete; CanonW & operator=(const CanonW &) = delete;
-    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), data(o.data), bytes(o.bytes) { o.data = nullptr; }
+    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), q4(o.q4), data(o.data), bytes(o.bytes) { o.data = nullptr; }
     ~CanonW() { if (data) munmap(data, bytes); }
     void build(const uint8_t * src, bool src_f16, int M_, int K_) {
         M = M_; K = K_; Kp = canon_kp(K); f16 = src_f16;
@@ -235,8 +237,8 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
     m.n_out = r.get<int32_t>(); m.n_lm_heads = r.get<int32_t>(); m.n_wtes = r.get<int32_t>();
     m.ftype = r.get<int32_t>();
     if (!r.ok) return false;
-    if (m.ftype / 1000 != 0 || (m.ftype % 1000) > 1) {   // bark.cpp:711,727,2254: quantised = 2000 + ggml_ftype
-        fprintf(stderr, "oracle: quantised model files are not restated (ftype %d)\n", m.ftype);
+    if ((m.ftype % 1000) > 2) {   // bark.cpp:711,727,2254: quantised files carry 2000 + ggml_ftype; f32 (0), f16 (1), q4_0 (2) are restated
+        fprintf(stderr, "oracle: ftype %d is not restated\n", m.ftype);
         return false;
     }
     if (m.n_layer <= 0 || m.n_layer > 256 || m.n_embd <= 0 || m.n_head <= 0 || m.n_embd % m.n_head) return false;
@@ -266,6 +268,7 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
     };
     auto needw = [&](const std::string & n, CanonW & out, int64_t ne0, int64_t ne1) {
         Tensor t; if (!need(n, t, ne0, ne1)) return false;
+        if (t.ttype == 2) { out.M = (int) ne1; out.K = (int) ne0; out.q4 = t.data; return ne0 % 32 == 0; }
         out.build(t.data, t.ttype == 1, (int) ne1, (int) ne0); return true;
     };
     const int E = m.n_embd;
@@ -450,8 +453,52 @@ static void softmax_row(float * s, int n) {
 }
 
 // C[n*ldc + m] = C1-dot(W[m], B[n])   (B rows: f32, already holding f16-rounded values where ggml rounds)
+// ggml's q4_0 x q8_0 product (ggml_vec_dot_q4_0_q8_0; the f32 activation row is quantised to q8_0 blocks by mul_mat,
+// SURVEY.md A.4 item 1): per 32-element block  sumi = sum (nibble - 8) * q8 (exact int32),  t = ((float) sumi * d4) * d8.
+// Canonical order C1q: block b belongs to chain (b mod 16), chains add their t in ascending b from +0, then the C1 tree.
+struct Q8Row { std::vector<int8_t> q; std::vector<float> d; };
+static void quantize_row_q8_0(const float * x, int K, Q8Row & r) {
+    r.q.resize((size_t) K); r.d.resize((size_t) K / 32);
+    for (int b = 0; b < K / 32; b++) {
+        float amax = 0.0f;
+        for (int j = 0; j < 32; j++) amax = std::max(amax, fabsf(x[b * 32 + j]));
+        const float d = amax / 127.0f;                       // amax / ((1 << 7) - 1)
+        const float id = d ? 1.0f / d : 0.0f;
+        r.d[(size_t) b] = round_h(d);                        // the block scale is stored as f16
+        for (int j = 0; j < 32; j++) r.q[(size_t) b * 32 + j] = (int8_t) roundf(x[b * 32 + j] * id);
+    }
+}
+static float dot_q4_0_q8_0(const uint8_t * wrow, const Q8Row & x, int K) {
+    float acc[16];
+    for (float & a : acc) a = 0.0f;
+    for (int b = 0; b < K / 32; b++) {
+        const uint8_t * blk = wrow + (size_t) b * 18;
+        const float d4 = h2f(ld_u16(blk, 0));
+        const int8_t * q8 = x.q.data() + (size_t) b * 32;
+        int sumi = 0;
+        for (int j = 0; j < 16; j++) {
+            sumi += ((int) (blk[2 + j] & 0x0F) - 8) * q8[j];
+            sumi += ((int) (blk[2 + j] >> 4) - 8) * q8[j + 16];
+        }
+        const float t = ((float) sumi * d4) * x.d[(size_t) b];
+        acc[b & 15] = acc[b & 15] + t;
+    }
+    for (int st = 1; st < 16; st <<= 1) for (int c = 0; c < 16; c += 2 * st) acc[c] = acc[c] + acc[c + st];
+    return acc[0];
+}
+static void gemm_q4(const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
+    std::vector<Q8Row> rows((size_t) N);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
+    for (int n = 0; n < N; n++) quantize_row_q8_0(B + (size_t) n * ldb, K, rows[(size_t) n]);
+    const size_t rb = (size_t) K / 32 * 18;
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
+    for (int m = 0; m < M; m++)
+        for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_q4_0_q8_0(W.q4 + (size_t) m * rb, rows[(size_t) n], K);
+}
+
 static void gemm_w(Oracle & o, const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
     assert(M == W.M && K == W.K);
+    if (W.q4) { gemm_q4(W, B, ldb, C, ldc, M, N, K, nth); return; }
     const int Kp = W.Kp;
     o.ximg.ensure((size_t) N * Kp);
     float * xi = o.ximg.p;
@@ -539,7 +586,7 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
     float * xn = o.xn.p, * qkv = o.qkv.p, * att = o.att.p, * fc = o.fc.p, * tmp = o.tmp.p;
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln1_g.data(), L.ln1_b.empty() ? nullptr : L.ln1_b.data());
-    round_rows(o, xn, (size_t) N * E);
+    if (!L.attn_w.q4) round_rows(o, xn, (size_t) N * E);     // f16 weights: activation -> f16; q4_0 weights: activation -> q8_0 inside the product
     gemm_w(o, L.attn_w, xn, E, qkv, 3 * E, 3 * E, N, E, nth);
     add_bias_rows(qkv, 3 * E, N, 3 * E, L.attn_b);
 
@@ -561,23 +608,35 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
         attention(o, qkv, 3 * E, kc, vc, att, N, N, 0, false, E, H, nth);
     }
 
-    round_rows(o, att, (size_t) N * E);
+    if (!L.proj_w.q4) round_rows(o, att, (size_t) N * E);
     gemm_w(o, L.proj_w, att, E, tmp, E, E, N, E, nth);
     add_bias_rows(tmp, E, N, E, L.proj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpL  (bark.cpp:1352)
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln2_g.data(), L.ln2_b.empty() ? nullptr : L.ln2_b.data());
-    round_rows(o, xn, (size_t) N * E);
+    if (!L.fc_w.q4) round_rows(o, xn, (size_t) N * E);
     gemm_w(o, L.fc_w, xn, E, fc, 4 * E, 4 * E, N, E, nth);
     add_bias_rows(fc, 4 * E, N, 4 * E, L.fc_b);
     for (size_t i = 0; i < (size_t) N * 4 * E; i++) fc[i] = gelu_apply(o, fc[i]);
-    round_rows(o, fc, (size_t) N * 4 * E);
+    if (!L.mproj_w.q4) round_rows(o, fc, (size_t) N * 4 * E);
     gemm_w(o, L.mproj_w, fc, 4 * E, tmp, E, E, N, 4 * E, nth);
     add_bias_rows(tmp, E, N, E, L.mproj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpFF (bark.cpp:1388)
 }
 
 static void embed_row(const Tensor & wte, int id, float * out, int E) {
+    if (wte.ttype == 2) {
+        const uint8_t * row = wte.data + (size_t) id * (E / 32) * 18;
+        for (int b = 0; b < E / 32; b++) {
+            const uint8_t * blk = row + (size_t) b * 18;
+            const float d = h2f(ld_u16(blk, 0));
+            for (int j = 0; j < 16; j++) {
+                out[b * 32 + j] = (float) ((int) (blk[2 + j] & 0x0F) - 8) * d;
+                out[b * 32 + j + 16] = (float) ((int) (blk[2 + j] >> 4) - 8) * d;
+            }
+        }
+        return;
+    }
     const uint8_t * row = wte.data + (size_t) id * E * (wte.ttype == 1 ? 2 : 4);
     for (int e = 0; e < E; e++) out[e] = wte.ttype == 1 ? h2f(ld_u16(row, e)) : ld_f32(row, e);
 }
@@ -615,7 +674,7 @@ static bool gpt_eval(Oracle & o, Gpt & m, const int32_t * tokens, int n_tokens, 
     // final norm + LM head on the last row only (bark.cpp:1391-1405)
     std::vector<float> last(E);
     layer_norm_row(x + (size_t) (N - 1) * E, last.data(), E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
-    round_rows(o, last.data(), E);
+    if (!m.lm_heads[0].q4) round_rows(o, last.data(), E);
     gemm_w(o, m.lm_heads[0], last.data(), E, logits, m.n_out, m.n_out, 1, E, nth);
     *n_past += N;
     m.t_predict_us += now_us() - t0;
@@ -647,7 +706,7 @@ static bool fine_eval(Oracle & o, const int32_t * tokens, int nn, float * logits
     for (int il = 0; il < m.n_layer; il++) block_forward(o, m, il, x, N, 0, false, nth);
     o.xn.ensure((size_t) N * E);
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, o.xn.p + (size_t) i * E, E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
-    round_rows(o, o.xn.p, (size_t) N * E);
+    if (!m.lm_heads[nn - 1].q4) round_rows(o, o.xn.p, (size_t) N * E);
     gemm_w(o, m.lm_heads[nn - 1], o.xn.p, E, logits, m.n_out, m.n_out, N, E, nth);   // lm_heads[codebook_idx - n_codes_given]
     m.t_predict_us += now_us() - t0;
     return true;
@@ -1075,6 +1134,11 @@ float orc_test_wdot(const uint16_t * w, const float * x, int K) {
 void orc_test_attention(const float * q, const float * kc, const float * vc, int N, int ctx, int n_past, int causal, float * out) {
     Oracle o;
     attention(o, q, 64, kc, vc, out, N, ctx, n_past, causal != 0, 64, 1, 1);
+}
+// y = C1q dot of one q4_0 row (K/32 blocks of 18 bytes) with the f32 row x (quantised to q8_0 as mul_mat does)
+float orc_test_q4dot(const uint8_t * blocks, const float * x, int K) {
+    Q8Row r; quantize_row_q8_0(x, K, r);
+    return dot_q4_0_q8_0(blocks, r, K);
 }
 void orc_test_layer_norm(const float * x, float * y, int E, const float * g, const float * b) { layer_norm_row(x, y, E, g, b); }
 

@@ -18,6 +18,8 @@ def lib():
     L.orc_test_wdot.restype = C.c_float
     L.orc_test_wdot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_test_q4dot.restype = C.c_float
+    L.orc_test_q4dot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.orc_test_layer_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return L
 
@@ -132,3 +134,28 @@ def test_layer_norm_double_sums(lib):
     scale = np.float32(1.0) / np.sqrt(np.float32(var + np.float32(1e-5)))
     want = ((d * scale).astype(np.float32) * g).astype(np.float32) + b
     assert np.array_equal(y, want.astype(np.float32))
+
+
+@pytest.mark.parametrize("K", [128, 768])
+def test_c1q_q4_0_times_q8_0_dot(lib, K):
+    """q4_0 weights x q8_0-quantised activations (ggml_vec_dot_q4_0_q8_0) in the canonical block-chain order."""
+    from tests.test_quantize import q4_0_ref
+    rng = np.random.default_rng(K)
+    w = (rng.standard_normal(K) * 0.05).astype(np.float32)
+    x = rng.standard_normal(K).astype(np.float32)
+    d4, qs = q4_0_ref(w[None, :])
+    blocks = np.concatenate([d4.view(np.uint8).reshape(-1, 2), qs], axis=1).astype(np.uint8).copy()
+    got = np.float32(lib.orc_test_q4dot(blocks.ctypes.data, x.ctypes.data, K))
+    acc = [np.float32(0.0)] * 16
+    for b in range(K // 32):
+        xb = x[32 * b:32 * b + 32]
+        amax = np.float32(np.max(np.abs(xb)))
+        d = np.float32(amax / np.float32(127.0))
+        inv = np.float32(1.0) / d if d != 0 else np.float32(0.0)
+        q8 = [int(math.copysign(math.floor(abs(float(np.float32(v * inv))) + 0.5), float(v))) for v in xb]     # roundf: half away from zero
+        d8 = np.float32(np.float16(d))
+        q4 = [int(qs[b, j] & 15) - 8 for j in range(16)] + [int(qs[b, j] >> 4) - 8 for j in range(16)]
+        sumi = sum(a * c for a, c in zip(q4, q8))
+        t = np.float32(np.float32(np.float32(sumi) * np.float32(d4[b])) * d8)
+        acc[b % 16] = add32(acc[b % 16], t)
+    assert got == tree16(acc)
