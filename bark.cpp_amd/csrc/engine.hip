@@ -55,8 +55,17 @@ const TensorRef & need(const std::map<std::string, TensorRef> & m, const std::st
     if (ne0 > 0 && (t.ne[0] != ne0 || (ne1 > 0 && t.ne[1] != ne1)))       // shape check on ne[0], ne[1] (bark.cpp:1034)
         throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
     if (t.ttype != ttype)
-        throw std::runtime_error("tensor '" + name + "' is " + (t.ttype ? "f16" : "f32") + "; this engine needs the f16 model file (convert.py --use-f16)");
+        throw std::runtime_error("tensor '" + name + "' is " + (t.ttype == 2 ? "q4_0" : t.ttype ? "f16" : "f32") + "; this engine needs the f16 model file (convert.py --use-f16) or its q4_0 quantisation");
     return t;
+}
+// a weight matrix: f16, or q4_0 (uploaded later as a Q4Mat)
+const TensorRef & need_w(const std::map<std::string, TensorRef> & m, const std::string & name, int64_t ne0, int64_t ne1) {
+    auto it = m.find(name);
+    if (it == m.end()) throw std::runtime_error("missing tensor '" + name + "'");
+    return need(m, name, it->second.ttype == 2 ? 2 : 1, ne0, ne1);
+}
+Q4Mat q4_rows(const Q4Mat & w, size_t row0, int K) {
+    Q4Mat r; r.d = w.d + row0 * (size_t) (K / 32); r.qs = w.qs + row0 * (size_t) (K / 32) * 16; return r;
 }
 const TensorRef * maybe(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0) {
     auto it = m.find(name);
@@ -133,6 +142,12 @@ static void init_runtime(bark_context * ctxp) {
     ctx->att = dev_alloc<half_t>(ctx.get(), NE);
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
     ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
+    if (ctx->any_q4) {
+        ctx->att32 = dev_alloc<float>(ctx.get(), NE);
+        ctx->h32 = dev_alloc<float>(ctx.get(), NE * 4);
+        ctx->xq8 = dev_alloc<int8_t>(ctx.get(), NE * 4);
+        ctx->xd8 = dev_alloc<float>(ctx.get(), NE * 4 / 32);
+    }
     size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
     for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
     ctx->logits = dev_alloc<float>(ctx.get(), n_logits);
@@ -184,6 +199,15 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     struct Fix { const void ** dst; size_t off; };
     std::vector<Fix> fixes;
     auto place = [&](const TensorRef & t, const void ** dst) { fixes.push_back({dst, plan.add(t)}); };
+    struct Q4Job { const TensorRef * t; Q4Mat * dst; };
+    std::vector<Q4Job> q4_jobs;
+    int n_w16 = 0, n_wq4 = 0;
+    GptModel * cur_model = nullptr;
+    auto place_w = [&](const TensorRef & t, const half_t ** dst16, Q4Mat * dstq) {
+        if (t.ttype == 2) { q4_jobs.push_back({&t, dstq}); n_wq4++; }
+        else { place(t, (const void **) dst16); n_w16++; }
+        (void) cur_model;
+    };
 
     for (int g = 0; g < 3; g++) {
         GptModel & m = ctx->gpt[g];
@@ -195,8 +219,9 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         if (m.hp.block_size != 1024) throw std::runtime_error("block_size must be 1024");
         if (m.hp.n_wtes > 8 || m.hp.n_lm_heads > 8 || m.hp.n_layer > 64) throw std::runtime_error("unsupported GPT shape");
         m.layers.resize((size_t) m.hp.n_layer);
-        for (int i = 0; i < m.hp.n_wtes; i++) place(need(T, "model/wte/" + std::to_string(i), 1, E, m.hp.n_in_vocab), (const void **) &m.wte[i]);
-        for (int i = 0; i < m.hp.n_lm_heads; i++) place(need(T, "model/lm_head/" + std::to_string(i), 1, E, m.hp.n_out_vocab), (const void **) &m.lm_head[i]);
+        n_w16 = n_wq4 = 0;
+        for (int i = 0; i < m.hp.n_wtes; i++) place_w(need_w(T, "model/wte/" + std::to_string(i), E, m.hp.n_in_vocab), &m.wte[i], &m.wte_q[i]);
+        for (int i = 0; i < m.hp.n_lm_heads; i++) place_w(need_w(T, "model/lm_head/" + std::to_string(i), E, m.hp.n_out_vocab), &m.lm_head[i], &m.lm_head_q[i]);
         place(need(T, "model/wpe", 0, E, m.hp.block_size), (const void **) &m.wpe);
         place(need(T, "model/ln_f/g", 0, E, 0), (const void **) &m.lnf_g);
         if (auto * t = maybe(T, "model/ln_f/b", 0, E)) place(*t, (const void **) &m.lnf_b);
@@ -207,15 +232,19 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             place(need(T, p + "/ln_2/g", 0, E, 0), (const void **) &L.ln2_g);
             if (auto * t = maybe(T, p + "/ln_1/b", 0, E)) place(*t, (const void **) &L.ln1_b);
             if (auto * t = maybe(T, p + "/ln_2/b", 0, E)) place(*t, (const void **) &L.ln2_b);
-            place(need(T, p + "/attn/c_attn/w", 1, E, 3 * E), (const void **) &L.attn_w);
-            place(need(T, p + "/attn/c_proj/w", 1, E, E), (const void **) &L.proj_w);
-            place(need(T, p + "/mlp/c_fc/w", 1, E, 4 * E), (const void **) &L.fc_w);
-            place(need(T, p + "/mlp/c_proj/w", 1, 4 * E, E), (const void **) &L.mproj_w);
+            place_w(need_w(T, p + "/attn/c_attn/w", E, 3 * E), &L.attn_w, &L.attn_q);
+            place_w(need_w(T, p + "/attn/c_proj/w", E, E), &L.proj_w, &L.proj_q);
+            place_w(need_w(T, p + "/mlp/c_fc/w", E, 4 * E), &L.fc_w, &L.fc_q);
+            place_w(need_w(T, p + "/mlp/c_proj/w", 4 * E, E), &L.mproj_w, &L.mproj_q);
             if (auto * t = maybe(T, p + "/attn/c_attn/b", 0, 3 * E)) place(*t, (const void **) &L.attn_b);
             if (auto * t = maybe(T, p + "/attn/c_proj/b", 0, E)) place(*t, (const void **) &L.proj_b);
             if (auto * t = maybe(T, p + "/mlp/c_fc/b", 0, 4 * E)) place(*t, (const void **) &L.fc_b);
             if (auto * t = maybe(T, p + "/mlp/c_proj/b", 0, E)) place(*t, (const void **) &L.mproj_b);
         }
+        // bark_model_quantize converts every matrix of a model or none (bark.cpp:2277-2289)
+        if (n_w16 && n_wq4) throw std::runtime_error("model mixes f16 and q4_0 weight matrices");
+        m.q4 = n_wq4 > 0;
+        ctx->any_q4 = ctx->any_q4 || m.q4;
         ctx->max_E = std::max(ctx->max_E, E);
         ctx->max_H = std::max(ctx->max_H, m.hp.n_head);
     }
@@ -286,6 +315,20 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         (void) hipHostFree(stage);
     }
     for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weights->slab + f.off;
+    for (const auto & j : q4_jobs) {
+        // q4_0 blocks (f16 d + 16 bytes, 18-byte stride) -> separate scale and nibble arrays: 16-byte aligned vector loads
+        const size_t nb = (size_t) j.t->nelements() / 32;
+        std::vector<uint16_t> d(nb);
+        std::vector<uint8_t> qs(nb * 16);
+        for (size_t b = 0; b < nb; b++) { memcpy(&d[b], j.t->data + b * 18, 2); memcpy(&qs[b * 16], j.t->data + b * 18 + 2, 16); }
+        void * dd = nullptr, * dq = nullptr;
+        HIP_OK(hipMalloc(&dd, nb * 2)); ctx->weights->extra.push_back(dd);
+        HIP_OK(hipMalloc(&dq, nb * 16)); ctx->weights->extra.push_back(dq);
+        HIP_OK(hipMemcpy(dd, d.data(), nb * 2, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dq, qs.data(), nb * 16, hipMemcpyHostToDevice));
+        j.dst->d = (const half_t *) dd; j.dst->qs = (const uint8_t *) dq;
+        ctx->weight_bytes += nb * 18;
+    }
     {
         // f32 copies of the codec's conv weights (19 MB of f16 in the file): exact, and wave-uniform f32 weights become
         // scalar loads / SGPR operands in the register-blocked conv kernels
@@ -347,7 +390,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     ctx->codec = src->codec;
     ctx->device = src->device; ctx->use_graph = src->use_graph;
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
-    ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P;
+    ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4;
     HIP_OK(hipStreamCreate(&ctx->stream));
     init_runtime(ctx.get());
     ctx->description = src->description + " (clone)";
@@ -371,25 +414,31 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
-        launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
+        // f16 weights: activations are rounded to f16 rows (xn / att / hbuf); q4_0 weights: f32 rows quantised to q8_0 (xq8 / xd8)
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq8, c->xd8);
+        else      launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
         LinArgs a;
-        a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq8 = c->xq8; a.xd8 = c->xd8; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         launch_linear(s, a);
         AttnPrefillArgs at;
         at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
-        at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E;
+        at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
         { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
+        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq8, c->xd8);
         LinArgs p;
-        p.W = L.proj_w; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq8 = c->xq8; p.xd8 = c->xd8; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
         launch_linear(s, p);
-        launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq8, c->xd8);
+        else      launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
         LinArgs f;
-        f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.bias = L.fc_b; f.epi = EPI_GELU; f.out_h = c->hbuf; f.lut = c->d_gelu_lut;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq8 = c->xq8; f.xd8 = c->xd8; f.bias = L.fc_b; f.epi = EPI_GELU;
+        f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(s, f);
+        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq8, c->xd8);
         LinArgs o;
-        o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq8 = c->xq8; o.xd8 = c->xd8; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
         launch_linear(s, o);
     }
 }
@@ -401,21 +450,22 @@ void run_layers_decode(bark_context * c, GptModel & m) {
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         LinArgs a;
-        a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
+        at.att32 = m.q4 ? c->att32 : nullptr;
         launch_attn_decode(s, at);
         LinArgs p;
-        p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = c->att32; else p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
         launch_linear(s, p);
         LinArgs f;
-        f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
-        f.epi = EPI_GELU; f.out_h = c->hbuf; f.lut = c->d_gelu_lut;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
+        f.epi = EPI_GELU; f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(s, f);
         LinArgs o;
-        o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = 1; o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = c->h32; else o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
         launch_linear(s, o);
     }
 }
@@ -424,7 +474,8 @@ void run_layers_decode(bark_context * c, GptModel & m) {
 // or the parity-selected codebook window of the coarse model.
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows) {
     LinArgs a;
-    a.W = m.lm_head[0] + (size_t) row0 * m.hp.n_embd; a.M = n_rows; a.K = m.hp.n_embd; a.N = 1;
+    if (m.q4) a.wq = q4_rows(m.lm_head_q[0], (size_t) row0, m.hp.n_embd); else a.W = m.lm_head[0] + (size_t) row0 * m.hp.n_embd;
+    a.M = n_rows; a.K = m.hp.n_embd; a.N = 1;
     a.x_f32 = xrow; a.ln_g = m.lnf_g; a.ln_b = m.lnf_b; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     a.parity_rows = parity_rows; a.st = c->d_state;
     launch_linear(c->stream, a);
@@ -462,7 +513,7 @@ void check_ids(const int32_t * tok, size_t n, int n_in, const char * what) {
 int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0) {
     const int N = merge ? n_tokens - 256 : n_tokens;
     EmbedArgs e;
-    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.tokens = c->d_tokens; e.n_rows = N; e.merge = merge ? 1 : 0; e.pos0 = pos0; e.x = c->x;
+    e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.tokens = c->d_tokens; e.n_rows = N; e.merge = merge ? 1 : 0; e.pos0 = pos0; e.x = c->x;
     launch_embed_causal(c->stream, e);
     run_layers_rows(c, m, N, true, kbase, vbase, pos0);
     return N;
@@ -495,7 +546,7 @@ void run_sample(bark_context * c, const StageCfg & s, int n_past_add) {
     a.eos_trace = s.mode == 0 ? c->d_eos_trace : nullptr; a.st = c->d_state;
     a.temp = s.temp; a.u = c->d_u;
     const GptModel & m = c->gpt[s.which];
-    a.wte = m.wte[0]; a.wpe = m.wpe; a.E = m.hp.n_embd; a.n_in = m.hp.n_in_vocab; a.P = c->P; a.x = c->x;
+    a.wte = m.wte[0]; a.wte_q = m.wte_q[0]; a.wpe = m.wpe; a.E = m.hp.n_embd; a.n_in = m.hp.n_in_vocab; a.P = c->P; a.x = c->x;
     launch_sample_greedy(c->stream, a);
 }
 
@@ -505,7 +556,7 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
     GptModel & m = c->gpt[s.which];
     if (embed) {
         EmbedArgs e;
-        e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
+        e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
         launch_embed_causal(c->stream, e);
     }
     run_layers_decode(c, m);
@@ -631,11 +682,12 @@ namespace {
 void run_fine_forward(bark_context * c, int nn, int n_rows) {
     GptModel & m = c->gpt[2];
     const int E = m.hp.n_embd;
-    launch_embed_fine(c->stream, m.wte, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
+    launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
     run_layers_rows(c, m, 1024, false);
-    launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
+    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq8, c->xd8);
+    else      launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
-    a.W = m.lm_head[nn - 1]; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq8 = c->xq8; a.xd8 = c->xd8; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace
@@ -772,7 +824,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
         set_state(c, st);
         if (greedy && rows == 1) {
             EmbedArgs e;
-            e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
+            e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
             launch_embed_causal(c->stream, e);
             decode_step_greedy(c, s);
             c->stats.n_prefix_rows_reused += L;
@@ -1234,8 +1286,8 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
     const bark_context_params & p = c->params;
     if (n <= 0 || n > 32) throw std::runtime_error("generate_batch: batch size must be in 1..32");
     c->batch_results.assign((size_t) n, bark_context::BatchResult());
-    if (p.temp != 0.0f || p.fine_temp != 0.0f || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd) {
-        // host-side sampling keeps one utterance in flight: fall back to the sequential loop
+    if (p.temp != 0.0f || p.fine_temp != 0.0f || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_q4) {
+        // sampled decoding and q4_0 models keep one utterance in flight: fall back to the sequential loop
         int good = 0;
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];
@@ -1442,7 +1494,8 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     if (bytes_per_step) {
         const double E = m.hp.n_embd, L = m.hp.n_layer;
         // f16 weights of all layers + evaluated LM-head rows + f32 K and V rows read
-        *bytes_per_step = L * 12.0 * E * E * 2.0 + (double) s.lm_rows * E * 2.0 + 2.0 * ctxlen * E * L * 4.0;
+        const double wb = m.q4 ? 18.0 / 32.0 : 2.0;      // bytes per weight: f16, or q4_0 blocks (18 bytes per 32 weights)
+        *bytes_per_step = L * 12.0 * E * E * wb + (double) s.lm_rows * E * wb + 2.0 * ctxlen * E * L * 4.0;
     }
     return (double) ms * 1000.0 / std::max(1, iters);
 }
@@ -1469,6 +1522,7 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
     HIP_OK(hipMemsetAsync(c->x, 0, (size_t) E * 4, c->stream));
     HIP_OK(hipMemsetAsync(c->att, 0, (size_t) E * 2, c->stream));
     HIP_OK(hipMemsetAsync(c->hbuf, 0, (size_t) 4 * E * 2, c->stream));
+    if (m.q4) { HIP_OK(hipMemsetAsync(c->att32, 0, (size_t) E * 4, c->stream)); HIP_OK(hipMemsetAsync(c->h32, 0, (size_t) 4 * E * 4, c->stream)); }
     auto launch = [&](int l) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         if (attn) {
@@ -1481,12 +1535,12 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
         LinArgs a;
         a.N = 1;
         switch (op) {
-            case 0: a.W = L.attn_w; a.M = 3 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b; a.epi = EPI_QKV;
+            case 0: a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b; a.epi = EPI_QKV;
                     a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.st = c->d_state; break;
-            case 1: a.W = L.proj_w; a.M = E; a.K = E; a.x_f16 = c->att; a.bias = L.proj_b; a.epi = EPI_RESID; a.res = c->x; break;
-            case 2: a.W = L.fc_w; a.M = 4 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.bias = L.fc_b; a.epi = EPI_GELU;
-                    a.out_h = c->hbuf; a.lut = c->d_gelu_lut; break;
-            default: a.W = L.mproj_w; a.M = E; a.K = 4 * E; a.x_f16 = c->hbuf; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = c->x; break;
+            case 1: a.W = L.proj_w; a.wq = L.proj_q; a.M = E; a.K = E; if (m.q4) a.x_f32 = c->att32; else a.x_f16 = c->att; a.bias = L.proj_b; a.epi = EPI_RESID; a.res = c->x; break;
+            case 2: a.W = L.fc_w; a.wq = L.fc_q; a.M = 4 * E; a.K = E; a.x_f32 = c->x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.bias = L.fc_b; a.epi = EPI_GELU;
+                    a.out_h = c->hbuf; a.out_h32 = m.q4 ? c->h32 : nullptr; a.lut = c->d_gelu_lut; break;
+            default: a.W = L.mproj_w; a.wq = L.mproj_q; a.M = E; a.K = 4 * E; if (m.q4) a.x_f32 = c->h32; else a.x_f16 = c->hbuf; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = c->x; break;
         }
         launch_linear(c->stream, a);
     };
@@ -1515,7 +1569,7 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
     if (bytes_per_launch) {
         const double Ed = E;
         const double w = op == 0 ? 3 * Ed * Ed : op == 1 ? Ed * Ed : 4 * Ed * Ed;
-        *bytes_per_launch = w * 2.0;          // f16 weight matrix; vectors are < 1 % of it
+        *bytes_per_launch = w * (m.q4 ? 18.0 / 32.0 : 2.0);          // f16 (or q4_0) weight matrix; vectors are < 1 % of it
     }
     return (double) ms * 1000.0 / std::max(1, iters);
 }

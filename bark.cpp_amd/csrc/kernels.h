@@ -25,6 +25,10 @@ struct StepState {
     float   pad1;
 };
 
+// ggml Q4_0 matrix, re-laid out at load time: scales [M][K/32] f16 and nibbles [M][K/32][16 bytes]
+// (low nibble of byte j = element j of the block, high nibble = element j + 16)
+struct Q4Mat { const half_t * d = nullptr; const uint8_t * qs = nullptr; };
+
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
 // One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
@@ -36,6 +40,10 @@ struct LinArgs {
     // ... or (decode GEMV only) one f32 row normalised in the kernel prologue (LayerNorm fused)
     const float * x_f32 = nullptr; const float * ln_g = nullptr; const float * ln_b = nullptr;
     const float * ln_stats = nullptr;     // batched decode: {mean, 1/sqrt(var+eps)} per row from ln_stats_kernel (else computed in the kernel)
+    // Q4_0 weights (wq.qs != nullptr): the input rows are f32 (x_f32 with ld K, LayerNorm applied when ln_g != nullptr) and are
+    // quantised to q8_0 blocks inside the kernel, as ggml's mul_mat does for a q4_0 src0
+    Q4Mat wq;
+    const int8_t * xq8 = nullptr; const float * xd8 = nullptr;   // N > 1: rows already quantised by launch_q8_rows
     const float * bias = nullptr;
     int epi = EPI_LOGITS;
     // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
@@ -45,6 +53,7 @@ struct LinArgs {
     float * res = nullptr;
     // EPI_GELU: out_h[n][m] = f16(gelu_lut(dot + bias))
     half_t * out_h = nullptr; const uint16_t * lut = nullptr;
+    float * out_h32 = nullptr;            // q4_0 path: the GELU output stays f32 (it is quantised to q8_0 by the next product)
     // EPI_LOGITS: out[n*ld_out + m] = dot (+ bias)
     float * out = nullptr; int ld_out = 0;
     // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
@@ -59,6 +68,7 @@ void launch_linear(hipStream_t s, const LinArgs & a);
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024;
+    Q4Mat wte_q;                           // q4_0 embedding table (rows are dequantised, ggml_get_rows)
     const int32_t * tokens = nullptr;      // n_tokens ids (prefill) - ignored when st != nullptr
     int n_rows = 1; int merge = 0;         // merge: 513 ids -> 257 rows
     int pos0 = 0;
@@ -67,16 +77,19 @@ struct EmbedArgs {
 };
 void launch_embed_causal(hipStream_t s, const EmbedArgs & a);
 // fine: x[i] = sum_{c<=nn} wte_c[tok[c][i]] + wpe[i]                   (bark.cpp:1450-1472)
-void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const float * wpe, int E, int n_in,
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const Q4Mat * wte_q, const float * wpe, int E, int n_in,
                        const int32_t * tokens_8x1024, int nn, float * x);
 
 void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats);
+// q8_0 quantisation of N f32 rows of length K (LayerNorm first when ln_g != nullptr): q [N][K] int8, d [N][K/32] f32
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d);
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
 
 // Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.
 struct AttnDecodeArgs {
     const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
+    float * att32 = nullptr;              // q4_0 path: attention output kept in f32
     float * scores = nullptr;             // scratch [H][P]
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
@@ -90,6 +103,7 @@ struct AttnPrefillArgs {
     int H = 0, P = 0, N = 0, n_past = 0; int causal = 1;
     float * scores = nullptr;              // scratch [H][N][P]
     half_t * att = nullptr; int ld_att = 0;
+    float * att32 = nullptr;              // q4_0 path: attention output kept in f32 (same leading dimension)
     int dbg = 0;                          // timing experiments only (BARK_HIP_ATTN_DBG): 1 skip scores, 2 skip exp, 4 skip mix
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
@@ -107,6 +121,7 @@ struct SampleArgs {
     int nbatch = 1; int ld_logits = 0; int out_stride = 0;   // batched decode: slot b reads logits + b*ld_logits, writes out_tokens + b*out_stride, x + b*E
     // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
+    Q4Mat wte_q;
 };
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]

@@ -84,6 +84,16 @@ DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
     return __builtin_bit_cast(half_t, lut[bits]);
 }
 
+// one element of an embedding row: f16 table, or q4_0 table dequantised as ggml_get_rows does ((nibble - 8) * d)
+DEVINL float wte_elem(const half_t * wte, const Q4Mat & q, int E, int tok, int e) {
+    if (!q.qs) return (float) wte[(size_t) tok * E + e];
+    const size_t blk = (size_t) tok * (E >> 5) + (e >> 5);
+    const int j = e & 31;
+    const uint8_t byte = q.qs[blk * 16 + (j & 15)];
+    const int nib = j < 16 ? (byte & 0x0F) : (byte >> 4);
+    return (float) (nib - 8) * (float) q.d[blk];
+}
+
 // K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
 DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
 DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
@@ -113,7 +123,11 @@ DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, cons
             break;
         }
         case EPI_RESID: a.res[(size_t) n * a.M + m] = v + p.res; break;                          // cur + inpL (bark.cpp:1352,1388)
-        case EPI_GELU:  a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v, a.lut); break;
+        case EPI_GELU: {
+            const half_t g = gelu_lut_apply(v, a.lut);
+            if (a.out_h32) a.out_h32[(size_t) n * a.M + m] = (float) g; else a.out_h[(size_t) n * a.M + m] = g;
+            break;
+        }
         default:        a.out[(size_t) n * a.ld_out + m] = v; break;
     }
 }
@@ -131,7 +145,11 @@ DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_
             break;
         }
         case EPI_RESID: { float * r = a.res + (size_t) n * a.M + m; *r = v + *r; break; }       // cur + inpL (bark.cpp:1352,1388)
-        case EPI_GELU:  a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v, a.lut); break;
+        case EPI_GELU: {
+            const half_t g = gelu_lut_apply(v, a.lut);
+            if (a.out_h32) a.out_h32[(size_t) n * a.M + m] = (float) g; else a.out_h[(size_t) n * a.M + m] = g;
+            break;
+        }
         default:        a.out[(size_t) n * a.ld_out + m] = v; break;
     }
 }
@@ -544,7 +562,253 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Q4_0 weights (BASELINE config 4; ggml_vec_dot_q4_0_q8_0 as restated by the oracle's C1q order).
+// The activation row is quantised to q8_0 blocks of 32 (d = amax / 127, q = roundf(x / d), d stored
+// as f16), every block product is an exact integer sum scaled as ((float) sumi * d4) * d8, block b
+// belongs to chain b mod 16, chains are plain float adds in ascending block order and meet in the
+// C1 tree.  One wave = 4 output rows x 16 lanes, lane c = chain c: a lane only ever touches the
+// blocks c, c + 16, ... of both operands, so quantisation and the integer dot product are lane-local
+// (v_dot4_i32_i8); nothing goes through LDS.
+// ------------------------------------------------------------------------------------------------
+struct Q8Block { int q[8]; float d; };      // 32 int8 values (element 4 i + j in byte j of q[i]) and the f16-rounded scale
+
+DEVINL Q8Block quantize_q8_block(const float (&v)[32]) {
+    float amax = 0.0f;
+    #pragma unroll
+    for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
+    const float d = amax / 127.0f;
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;
+    Q8Block o;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        unsigned w = 0;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float t = v[4 * i + j] * id;
+            const int qi = (int) __builtin_roundf(t);                // round half away from zero, as roundf on the host
+            w |= ((unsigned) qi & 0xFFu) << (8 * j);
+        }
+        o.q[i] = (int) w;
+    }
+    o.d = (float) to_half(d);
+    return o;
+}
+// nibbles of one q4_0 block -> eight dwords of int8 values (n - 8): dwords 0..3 = elements 0..15, 4..7 = elements 16..31
+DEVINL void unpack_q4_block(const uint4 w, int (&o)[8]) {
+    const unsigned r[4] = {w.x, w.y, w.z, w.w};
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned lo = r[i] & 0x0F0F0F0Fu, hi = (r[i] >> 4) & 0x0F0F0F0Fu;
+        // per-byte (n - 8) without borrows: set bit 7, subtract 8, flip bit 7 back
+        o[i]     = (int) (((lo | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+        o[4 + i] = (int) (((hi | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+    }
+}
+DEVINL int dot_q4_q8(const int (&w)[8], const int (&q)[8]) {
+    int s = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) s = __builtin_amdgcn_sdot4(w[i], q[i], s, false);
+    return s;
+}
+
+// decode (N = 1): x is an f32 row, optionally LayerNorm-ed in registers (K <= 1024 -> at most two blocks per lane)
+template <bool LN, bool LNB>
+__global__ __launch_bounds__(64) void gemv_q4_kernel(const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int K = a.K, nblk = K >> 5;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
+    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + wrow;
+    const half_t * wd = a.wq.d + wrow;
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    float acc = 0.0f;
+    if constexpr (LN) {
+        // blocks c and c + 16 of the row (the second one only when it exists)
+        const bool own0 = c < nblk, two = c + 16 < nblk;
+        const int bsel[2] = {own0 ? c : 0, two ? c + 16 : (own0 ? c : 0)};       // lanes without a block re-read a valid one
+        float v[2][32];
+        #pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int b = bsel[t];
+            const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (b << 5));
+            #pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[t][4 * i] = f.x; v[t][4 * i + 1] = f.y; v[t][4 * i + 2] = f.z; v[t][4 * i + 3] = f.w; }
+        }
+        double s1 = 0.0;
+        #pragma unroll
+        for (int j = 0; j < 32; j++) { if (own0) s1 += (double) v[0][j]; if (two) s1 += (double) v[1][j]; }
+        s1 = group16_sum(s1);
+        const float mean = (float) (s1 / (double) K);
+        double s2 = 0.0;
+        #pragma unroll
+        for (int t = 0; t < 2; t++) {
+            #pragma unroll
+            for (int j = 0; j < 32; j++) { const float u = v[t][j] - mean; v[t][j] = u; if (t == 0 ? own0 : two) s2 += (double) (u * u); }
+        }
+        s2 = group16_sum(s2);
+        const float var = (float) (s2 / (double) K);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int b = bsel[t];
+            const float4 * gp = reinterpret_cast<const float4 *>(a.ln_g + (b << 5));
+            const float4 * bp = reinterpret_cast<const float4 *>((LNB ? a.ln_b : a.ln_g) + (b << 5));
+            #pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float4 g = gp[i];
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (LNB) bb = bp[i];
+                const float gg[4] = {g.x, g.y, g.z, g.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float u = v[t][4 * i + j] * scale;
+                    u = u * gg[j];
+                    if constexpr (LNB) u = u + bv[j];
+                    v[t][4 * i + j] = u;
+                }
+            }
+        }
+        #pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (t == 0 ? own0 : two) {
+                const int b = c + 16 * t;
+                const Q8Block xq = quantize_q8_block(v[t]);
+                int w[8]; unpack_q4_block(wq[b], w);
+                const int sumi = dot_q4_q8(w, xq.q);
+                const float tb = ((float) sumi * (float) wd[b]) * xq.d;
+                acc = acc + tb;
+            }
+        }
+    } else {
+        for (int b = c; b < nblk; b += 16) {
+            const uint4 wv = wq[b];
+            const float d4 = (float) wd[b];
+            float v[32];
+            const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (b << 5));
+            #pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+            const Q8Block xq = quantize_q8_block(v);
+            int w[8]; unpack_q4_block(wv, w);
+            const int sumi = dot_q4_q8(w, xq.q);
+            const float tb = ((float) sumi * d4) * xq.d;
+            acc = acc + tb;
+        }
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+}
+
+// rows (N > 1): q8_0 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
+struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; };
+__global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
+    const int lane = threadIdx.x, n = blockIdx.x;
+    const int K = a.K, nblk = K >> 5;
+    const float * xr = a.x + (size_t) n * K;
+    float mean = 0.0f, scale = 1.0f;
+    if (a.ln_g) {
+        double s1 = 0.0;
+        for (int e = lane; e < K; e += 64) s1 += (double) xr[e];
+        s1 = wave_sum(s1);
+        mean = (float) (s1 / (double) K);
+        double s2 = 0.0;
+        for (int e = lane; e < K; e += 64) { const float u = xr[e] - mean; s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        const float var = (float) (s2 / (double) K);
+        scale = 1.0f / sqrtf(var + 1e-5f);
+    }
+    for (int b = lane; b < nblk; b += 64) {
+        float v[32];
+        const float4 * xp = reinterpret_cast<const float4 *>(xr + (b << 5));
+        #pragma unroll
+        for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+        if (a.ln_g) {
+            #pragma unroll
+            for (int j = 0; j < 32; j++) {
+                float u = (v[j] - mean) * scale;
+                u = u * a.ln_g[(b << 5) + j];
+                if (a.ln_b) u = u + a.ln_b[(b << 5) + j];
+                v[j] = u;
+            }
+        }
+        const Q8Block xq = quantize_q8_block(v);
+        int4 * qp = reinterpret_cast<int4 *>(a.q + (size_t) n * K + (b << 5));
+        qp[0] = make_int4(xq.q[0], xq.q[1], xq.q[2], xq.q[3]);
+        qp[1] = make_int4(xq.q[4], xq.q[5], xq.q[6], xq.q[7]);
+        a.d[(size_t) n * nblk + b] = xq.d;
+    }
+}
+
+// rows (N > 1): NB pre-quantised activation rows per wave share each unpacked weight block.
+// TODO(next round): v_mfma_i32_32x32x32_i8 holds exactly one q4_0 block per instruction; this first version keeps the
+// integer sums on v_dot4 and is bound by L2 re-reads of the weights.
+struct Q4RowsArgs { LinArgs lin; const int8_t * q; const float * d; };
+template <int NB>
+__global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
+    const LinArgs & a = qa.lin;
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int n0 = blockIdx.y * NB;
+    const int K = a.K, nblk = K >> 5;
+    const bool live = m < a.M;
+    const size_t wrow = (size_t) (live ? m : 0) * nblk;
+    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + wrow;
+    const half_t * wd = a.wq.d + wrow;
+    float acc[NB];
+    #pragma unroll
+    for (int i = 0; i < NB; i++) acc[i] = 0.0f;
+    for (int b = c; b < nblk; b += 16) {
+        int w[8]; unpack_q4_block(wq[b], w);
+        const float d4 = (float) wd[b];
+        #pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int n = min(n0 + i, a.N - 1);
+            const int4 * qp = reinterpret_cast<const int4 *>(qa.q + (size_t) n * K + (b << 5));
+            const int4 q0 = qp[0], q1 = qp[1];
+            const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int sumi = dot_q4_q8(w, q);
+            const float tb = ((float) sumi * d4) * qa.d[(size_t) n * nblk + b];
+            acc[i] = acc[i] + tb;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const float r = wave_xor_add16(acc[i]);
+        if (live && c == 0 && n0 + i < a.N) linear_epilogue(a, n0 + i, m, r, 0);
+    }
+}
+
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d) {
+    Q8RowsArgs a{x, N, K, ln_g, ln_b, q, d};
+    hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
+}
+
+static void launch_linear_q4(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 31) != 0) { fprintf(stderr, "bark-hip: q4_0 rows must be a multiple of 32 long\n"); abort(); }
+    if (a.batched) { fprintf(stderr, "bark-hip: the lock-step batched decode has no q4_0 kernels yet\n"); abort(); }
+    if (a.N == 1) {
+        if (!a.x_f32) { fprintf(stderr, "bark-hip: q4_0 GEMV needs an f32 activation row\n"); abort(); }
+        dim3 grid((a.M + 3) / 4), block(64);
+        if (a.ln_g) {
+            if (a.K > 1024) { fprintf(stderr, "bark-hip: LayerNorm-fused q4_0 GEMV supports n_embd <= 1024\n"); abort(); }
+            if (a.ln_b) hipLaunchKernelGGL((gemv_q4_kernel<true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_q4_kernel<true, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((gemv_q4_kernel<false, false>), grid, block, 0, s, a);
+        return;
+    }
+    if (!a.xq8 || !a.xd8 || a.parity_rows) { fprintf(stderr, "bark-hip: q4_0 row product needs pre-quantised rows\n"); abort(); }
+    constexpr int NB = 8;
+    Q4RowsArgs qa{a, a.xq8, a.xd8};
+    dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
+    hipLaunchKernelGGL((gemm_q4_rows_kernel<NB>), grid, block, 0, s, qa);
+}
+
 void launch_linear(hipStream_t s, const LinArgs & a) {
+    if (a.wq.qs) { launch_linear_q4(s, a); return; }
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
     if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
     const int nblk = a.K >> 7;
@@ -601,13 +865,11 @@ __global__ void embed_causal_kernel(const EmbedArgs a) {
     }
     tok = min(max(tok, 0), a.n_in - 1);
     if (tok2 >= 0) tok2 = min(tok2, a.n_in - 1);
-    const half_t * r1 = a.wte + (size_t) tok * a.E;
-    const half_t * r2 = tok2 >= 0 ? a.wte + (size_t) tok2 * a.E : nullptr;
     const float * pe = a.wpe + (size_t) pos * a.E;
     float * out = a.x + (size_t) i * a.E;
     for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
-        float v = (float) r1[e];
-        if (r2) v = v + (float) r2[e];                      // wte[text] + wte[history]  (bark.cpp:1237-1248)
+        float v = wte_elem(a.wte, a.wte_q, a.E, tok, e);
+        if (tok2 >= 0) v = v + wte_elem(a.wte, a.wte_q, a.E, tok2, e);   // wte[text] + wte[history]  (bark.cpp:1237-1248)
         out[e] = v + pe[e];
     }
 }
@@ -615,7 +877,7 @@ void launch_embed_causal(hipStream_t s, const EmbedArgs & a) {
     hipLaunchKernelGGL(embed_causal_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
 }
 
-struct FineEmbedArgs { const half_t * wte[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
+struct FineEmbedArgs { const half_t * wte[8]; Q4Mat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
 __global__ void embed_fine_kernel(const FineEmbedArgs a) {
     const int i = blockIdx.x;
     float * out = a.x + (size_t) i * a.E;
@@ -625,14 +887,14 @@ __global__ void embed_fine_kernel(const FineEmbedArgs a) {
         for (int cb = 0; cb <= a.nn; cb++) {
             int id = a.tok[cb * 1024 + i];
             id = min(max(id, 0), a.n_in - 1);
-            v = v + (float) a.wte[cb][(size_t) id * a.E + e];
+            v = v + wte_elem(a.wte[cb], a.wte_q[cb], a.E, id, e);
         }
         out[e] = v + pe[e];
     }
 }
-void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const float * wpe, int E, int n_in,
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const Q4Mat * wte_q, const float * wpe, int E, int n_in,
                        const int32_t * tokens_8x1024, int nn, float * x) {
-    FineEmbedArgs a; for (int i = 0; i < 8; i++) a.wte[i] = wte[i];
+    FineEmbedArgs a; for (int i = 0; i < 8; i++) { a.wte[i] = wte[i]; a.wte_q[i] = wte_q[i]; }
     a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens_8x1024; a.nn = nn; a.x = x;
     hipLaunchKernelGGL(embed_fine_kernel, dim3(1024), dim3(256), 0, s, a);
 }
@@ -765,7 +1027,7 @@ __global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) 
         for (int st = 1; st < 16; st <<= 1)
             #pragma unroll
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        a.att[h * 64 + tid] = to_half(p[0]);
+        if (a.att32) a.att32[h * 64 + tid] = p[0]; else a.att[h * 64 + tid] = to_half(p[0]);
     }
 }
 // ------------------------------------------------------------------------------------------------
@@ -868,7 +1130,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
         for (int st = 1; st < 16; st <<= 1)
             #pragma unroll
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
+        if (a.att32) a.att32[(size_t) slot * E + h * 64 + tid] = p[0]; else a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
     }
 }
 
@@ -1001,7 +1263,7 @@ __global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
         for (int q = 0; q < 8; q++) p[q] = part[q][row][d];
         const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         const int i = i0 + row;
-        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v);
+        if (i < a.N) { if (a.att32) a.att32[(size_t) i * a.ld_att + h * 64 + d] = v; else a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v); }
     }
 }
 
@@ -1160,7 +1422,7 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
         for (int q = 0; q < 8; q++) p[q] = part[(q * 32 + row) * 64 + d];
         const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         const int i = i0 + row;
-        if (i < a.N) a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v);
+        if (i < a.N) { if (a.att32) a.att32[(size_t) i * a.ld_att + h * 64 + d] = v; else a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v); }
     }
 }
 
@@ -1258,10 +1520,9 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
     if (a.x && next_pos < a.P) {
         const int tok = min(max(next_tok, 0), a.n_in - 1);
-        const half_t * r = a.wte + (size_t) tok * a.E;
         const float * pe = a.wpe + (size_t) next_pos * a.E;
         float * xo = a.x + (size_t) slot * a.E;
-        for (int e = tid; e < a.E; e += 1024) xo[e] = (float) r[e] + pe[e];
+        for (int e = tid; e < a.E; e += 1024) xo[e] = wte_elem(a.wte, a.wte_q, a.E, tok, e) + pe[e];
     }
 }
 // ------------------------------------------------------------------------------------------------
@@ -1363,10 +1624,9 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     __syncthreads();
     if (a.x && next_pos < a.P) {
         const int tok = min(max(next_tok, 0), a.n_in - 1);
-        const half_t * r = a.wte + (size_t) tok * a.E;
         const float * pe = a.wpe + (size_t) next_pos * a.E;
         float * xo = a.x + (size_t) slot * a.E;
-        for (int e = tid; e < a.E; e += 1024) xo[e] = (float) r[e] + pe[e];
+        for (int e = tid; e < a.E; e += 1024) xo[e] = wte_elem(a.wte, a.wte_q, a.E, tok, e) + pe[e];
     }
 }
 

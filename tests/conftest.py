@@ -46,3 +46,46 @@ def mini_oracle(mini_model):
     o = Oracle(mini_model, n_threads=4)
     yield o
     o.close()
+
+
+def _quantized(src: str) -> str:
+    """bark_model_quantize (native writer, no GPU needed) -> <src>_q4_0.bin next to the f16 file, made once."""
+    dst = src[:-4] + "_q4_0.bin"
+    if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+        from bark_amd_loader import load_package
+        lib = load_package().load_library()
+        tmp = dst + ".tmp%d" % os.getpid()
+        assert lib.bark_model_quantize(src.encode(), tmp.encode(), 2)          # GGML_FTYPE_MOSTLY_Q4_0
+        os.replace(tmp, dst)
+    return dst
+
+
+@pytest.fixture(scope="session")
+def toy_q4_model(toy_model):
+    return _quantized(toy_model)
+
+
+@pytest.fixture(scope="session")
+def mini_q4_model(mini_model):
+    return _quantized(mini_model)
+
+
+@pytest.fixture(scope="session")
+def small_q4_model(small_model):
+    return _quantized(small_model)
+
+
+@pytest.fixture(scope="session")
+def toy_q4_oracle(toy_q4_model):
+    from oracle.pyoracle import Oracle
+    o = Oracle(toy_q4_model, n_threads=4)
+    yield o
+    o.close()
+
+
+@pytest.fixture(scope="session")
+def mini_q4_oracle(mini_q4_model):
+    from oracle.pyoracle import Oracle
+    o = Oracle(mini_q4_model, n_threads=4)
+    yield o
+    o.close()
