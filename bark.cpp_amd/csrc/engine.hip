@@ -1504,7 +1504,7 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
 // stream comes from HBM / Infinity Cache like in a real step, not from a hot L2).  op: 0 LN+QKV, 1 proj,
 // 2 LN+FC+GELU, 3 mlp proj.  Returns the average device time per launch in microseconds.
 double engine_time_gemv(bark_context * c, int which, int op, int iters, double * bytes_per_launch) {
-    if (which < 0 || which > 1 || op < 0 || op > 11) throw std::runtime_error("time_gemv: bad arguments");
+    if (which < 0 || which > 1 || op < 0 || op > 12) throw std::runtime_error("time_gemv: bad arguments");
     const bool attn = op >= 8;            // 8: attn_scores_kernel, 9: attn_mix_kernel, 10: both (context = n_past + 1 = 641)
     const int attn_op = op;
     const bool hot = op >= 4 && !attn;
@@ -1529,7 +1529,7 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
             AttnDecodeArgs at;
             at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = m.hp.n_head; at.P = P; at.st = c->d_state; at.att = c->att;
             at.scores = c->scores; at.hmax = c->d_hmax;
-            launch_attn_decode_part(c->stream, at, attn_op == 8 ? 1 : attn_op == 9 ? 2 : attn_op == 10 ? 3 : 4);
+            launch_attn_decode_part(c->stream, at, attn_op == 8 ? 1 : attn_op == 9 ? 2 : attn_op == 10 ? 3 : attn_op == 11 ? 4 : 5);
             return;
         }
         LinArgs a;

@@ -1134,14 +1134,110 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// decode attention spread over ATTN_SPLIT workgroups per head, without any cross-workgroup traffic.
+// One CU streams a head's K and V rows at only ~40-65 GB/s (attn_fused_kernel: two dependent load
+// rounds, 512 B per key), and 12 heads leave 244 CUs idle for the longest kernel of the step.
+// Workgroup (h, s) scores ALL keys of head h (every workgroup repeats the C2 chains and the softmax
+// statistics in the same order, so all of them hold identical bits) but mixes only the value dims
+// [16 s, 16 s + 16) - with all 16 C5 chains, so the tree is local.  Per workgroup that is 256 + 64
+// instead of 512 bytes per key, all of them requested up front (one memory round trip; the
+// workgroup's four waves sit alone on their SIMDs, so ~350 VGPRs per lane are available).
+// A variant that also split the keys and exchanged scores through agent-scope atomics measured
+// 10.7 us vs 8.2 us fused at ctx 641: each cross-XCD hop costs ~2 us.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATTN_SPLIT = 4;
+__global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    __shared__ float part[16][16];
+    const int h = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float * __restrict__ qh = a.q + h * 64;
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+    const int chain = tid >> 4, d = tid & 15;
+    const float * vp = a.vc + ((size_t) h * P + chain) * 64 + 16 * s + d;        // key `chain`, value dim 16 s + d
+    const int ctx = a.st->n_past + 1;
+    float4 k0[16], k1[16], k2[16], k3[16];
+    load_k_group<0>(k0, kp, P);
+    if (ctx > 256) load_k_group<1>(k1, kp, P);
+    if (ctx > 512) load_k_group<2>(k2, kp, P);
+    if (ctx > 768) load_k_group<3>(k3, kp, P);
+    float vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];     // key chain + 16 (16 g + i)
+        }
+    }
+    float sv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    { const float v = score_chain(k0, qh); if (tid < ctx) sv[0] = v; }
+    if (ctx > 256) { const float v = score_chain(k1, qh); if (tid + 256 < ctx) sv[1] = v; }
+    if (ctx > 512) { const float v = score_chain(k2, qh); if (tid + 512 < ctx) sv[2] = v; }
+    if (ctx > 768) { const float v = score_chain(k3, qh); if (tid + 768 < ctx) sv[3] = v; }
+    float mx = wave_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = tid + 256 * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (sv[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    const float inv = (float) (1.0 / sum);
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int j = chain + 16 * (16 * g + i);
+                if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc);
+            }
+        }
+    }
+    part[chain][d] = acc;
+    __syncthreads();
+    if (tid < 16) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        const int o = h * 64 + 16 * s + tid;
+        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
+    }
+}
+
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
     if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
+    if (parts == 5) {
+        if (a.nbatch != 1 || a.P != 1024) { fprintf(stderr, "bark-hip: value-sliced decode attention needs one sequence and block_size 1024\n"); abort(); }
+        hipLaunchKernelGGL(attn_dslice_kernel, dim3(a.H, ATTN_SPLIT), dim3(256), 0, s, a);
+        return;
+    }
     if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
     if (parts & 2) hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
 }
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     static const bool split = getenv("BARK_HIP_ATTN_SPLIT") != nullptr;      // two-launch variant kept for A/B timing
-    launch_attn_decode_part(s, a, split ? 3 : 4);
+    static const bool one_wg = getenv("BARK_HIP_ATTN_ONE_WG") != nullptr;    // one workgroup per head (A/B timing)
+    if (split) { launch_attn_decode_part(s, a, 3); return; }
+    // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
+    const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
+    launch_attn_decode_part(s, a, can_split ? 5 : 4);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ for rep in range(1):
     for op in range(8):
         us, nb = ctx.time_gemv(0, op, 2400)
         print(f"{names[op & 3]:7s} {'hot ' if op >= 4 else 'cold'} {us:6.2f} us  {nb / us / 1e3:7.1f} GB/s")
-for op, nm in ((8, "scores"), (9, "mix"), (10, "scores+mix"), (11, "fused")):
+for op, nm in ((8, "scores"), (9, "mix"), (10, "scores+mix"), (11, "fused"), (12, "split4")):
     print(nm, ctx.time_gemv(0, op, 2400)[0], "us")
 print("decode step", ctx.time_decode_step(0, 640, 300))
 ctx.free()
