@@ -612,89 +612,118 @@ DEVINL int dot_q4_q8(const int (&w)[8], const int (&q)[8]) {
     return s;
 }
 
-// decode (N = 1): x is an f32 row, optionally LayerNorm-ed in registers (K <= 1024 -> at most two blocks per lane)
+// decode (N = 1): x is an f32 row, optionally LayerNorm-ed first.  A 256-thread workgroup owns 16 output rows:
+//   1. every lane requests the weight blocks of its chain (up to 8 x 18 bytes) before anything else,
+//   2. the q8_0 quantisation of x (~8 VALU ops per element) is spread over the workgroup - two threads per block of 32,
+//      block maximum through one DPP exchange - and published in LDS once for the 16 rows,
+//   3. wave w dots rows 4 w .. 4 w + 3: lane c of a row walks the blocks c, c + 16, ... (chain c of C1q).
+// The first version quantised inside every 16-lane group (each lane its own blocks): 1500 VALU instructions per wave
+// for K = 3072, 8.0 us per launch; this one measures about half of that.
 template <bool LN, bool LNB>
-__global__ __launch_bounds__(64) void gemv_q4_kernel(const LinArgs a) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
+    constexpr int MAXB = 8;                                    // blocks per chain: K <= 4096
+    __shared__ int4 xq[128][2];                                // q8 values of block b: elements 0..15 and 16..31
+    __shared__ float xd[128];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
-    const int m = blockIdx.x * 4 + rg;
+    const int m = blockIdx.x * 16 + wave * 4 + rg;
     const int K = a.K, nblk = K >> 5;
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;
     const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
     const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + wrow;
     const half_t * wd = a.wq.d + wrow;
+    uint4 wv[MAXB]; half_t wdv[MAXB];
+    #pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        const int b = c + 16 * i;
+        if (b < nblk) { wv[i] = wq[b]; wdv[i] = wd[b]; }
+    }
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
-    float acc = 0.0f;
+
+    // ---- x -> q8_0: thread t quantises elements [16 (t & 1), +16) of block t >> 1
+    const int qb = tid >> 1, qh = tid & 1;
+    const bool mine = qb < nblk;
+    const int k0 = mine ? (qb << 5) + (qh << 4) : 0;
+    float v[16];
+    {
+        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + k0);
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    }
     if constexpr (LN) {
-        // blocks c and c + 16 of the row (the second one only when it exists)
-        const bool own0 = c < nblk, two = c + 16 < nblk;
-        const int bsel[2] = {own0 ? c : 0, two ? c + 16 : (own0 ? c : 0)};       // lanes without a block re-read a valid one
-        float v[2][32];
-        #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int b = bsel[t];
-            const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (b << 5));
+        float g[16], bb[16];
+        {
+            const float4 * gp = reinterpret_cast<const float4 *>(a.ln_g + k0);
+            const float4 * bp = reinterpret_cast<const float4 *>((LNB ? a.ln_b : a.ln_g) + k0);
             #pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[t][4 * i] = f.x; v[t][4 * i + 1] = f.y; v[t][4 * i + 2] = f.z; v[t][4 * i + 3] = f.w; }
+            for (int i = 0; i < 4; i++) {
+                const float4 f = gp[i]; g[4 * i] = f.x; g[4 * i + 1] = f.y; g[4 * i + 2] = f.z; g[4 * i + 3] = f.w;
+                if constexpr (LNB) { const float4 h = bp[i]; bb[4 * i] = h.x; bb[4 * i + 1] = h.y; bb[4 * i + 2] = h.z; bb[4 * i + 3] = h.w; }
+            }
         }
+        // ggml_norm: double sums over the row (bark.cpp:1265-1274)
         double s1 = 0.0;
-        #pragma unroll
-        for (int j = 0; j < 32; j++) { if (own0) s1 += (double) v[0][j]; if (two) s1 += (double) v[1][j]; }
-        s1 = group16_sum(s1);
-        const float mean = (float) (s1 / (double) K);
+        if (mine) {
+            #pragma unroll
+            for (int j = 0; j < 16; j++) s1 += (double) v[j];
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wave] = s1;
+        __syncthreads();
+        const float mean = (float) (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double) K);
         double s2 = 0.0;
         #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            #pragma unroll
-            for (int j = 0; j < 32; j++) { const float u = v[t][j] - mean; v[t][j] = u; if (t == 0 ? own0 : two) s2 += (double) (u * u); }
-        }
-        s2 = group16_sum(s2);
-        const float var = (float) (s2 / (double) K);
+        for (int j = 0; j < 16; j++) { const float u = v[j] - mean; v[j] = u; if (mine) s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wave] = s2;
+        __syncthreads();
+        const float var = (float) (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double) K);
         const float scale = 1.0f / sqrtf(var + 1e-5f);
         #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int b = bsel[t];
-            const float4 * gp = reinterpret_cast<const float4 *>(a.ln_g + (b << 5));
-            const float4 * bp = reinterpret_cast<const float4 *>((LNB ? a.ln_b : a.ln_g) + (b << 5));
-            #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float4 g = gp[i];
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (LNB) bb = bp[i];
-                const float gg[4] = {g.x, g.y, g.z, g.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
-                #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float u = v[t][4 * i + j] * scale;
-                    u = u * gg[j];
-                    if constexpr (LNB) u = u + bv[j];
-                    v[t][4 * i + j] = u;
-                }
-            }
+        for (int j = 0; j < 16; j++) {
+            float u = v[j] * scale;
+            u = u * g[j];
+            if constexpr (LNB) u = u + bb[j];
+            v[j] = u;
         }
+    }
+    {
+        float amax = 0.0f;
         #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            if (t == 0 ? own0 : two) {
-                const int b = c + 16 * t;
-                const Q8Block xq = quantize_q8_block(v[t]);
-                int w[8]; unpack_q4_block(wq[b], w);
-                const int sumi = dot_q4_q8(w, xq.q);
-                const float tb = ((float) sumi * (float) wd[b]) * xq.d;
-                acc = acc + tb;
-            }
-        }
-    } else {
-        for (int b = c; b < nblk; b += 16) {
-            const uint4 wv = wq[b];
-            const float d4 = (float) wd[b];
-            float v[32];
-            const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (b << 5));
+        for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
+        amax = fmaxf(amax, dpp_f32<DPP_XOR1>(amax));           // the other half of the block sits in the neighbouring lane
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        int q[4];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned w = 0;
             #pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
-            const Q8Block xq = quantize_q8_block(v);
-            int w[8]; unpack_q4_block(wv, w);
-            const int sumi = dot_q4_q8(w, xq.q);
-            const float tb = ((float) sumi * d4) * xq.d;
+            for (int j = 0; j < 4; j++) {
+                const int qi = (int) __builtin_roundf(v[4 * i + j] * id);       // round half away from zero, as roundf on the host
+                w |= ((unsigned) qi & 0xFFu) << (8 * j);
+            }
+            q[i] = (int) w;
+        }
+        if (mine) {
+            xq[qb][qh] = make_int4(q[0], q[1], q[2], q[3]);
+            if (qh == 0) xd[qb] = (float) to_half(d);
+        }
+    }
+    __syncthreads();
+
+    float acc = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        const int b = c + 16 * i;
+        if (b < nblk) {
+            const int4 q0 = xq[b][0], q1 = xq[b][1];
+            const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            int w[8]; unpack_q4_block(wv[i], w);
+            const int sumi = dot_q4_q8(w, q);
+            const float tb = ((float) sumi * (float) wdv[i]) * xd[b];
             acc = acc + tb;
         }
     }
@@ -792,9 +821,9 @@ static void launch_linear_q4(hipStream_t s, const LinArgs & a) {
     if (a.batched) { fprintf(stderr, "bark-hip: the lock-step batched decode has no q4_0 kernels yet\n"); abort(); }
     if (a.N == 1) {
         if (!a.x_f32) { fprintf(stderr, "bark-hip: q4_0 GEMV needs an f32 activation row\n"); abort(); }
-        dim3 grid((a.M + 3) / 4), block(64);
+        if (a.K > 4096) { fprintf(stderr, "bark-hip: q4_0 GEMV supports K <= 4096\n"); abort(); }
+        dim3 grid((a.M + 15) / 16), block(256);
         if (a.ln_g) {
-            if (a.K > 1024) { fprintf(stderr, "bark-hip: LayerNorm-fused q4_0 GEMV supports n_embd <= 1024\n"); abort(); }
             if (a.ln_b) hipLaunchKernelGGL((gemv_q4_kernel<true, true>), grid, block, 0, s, a);
             else        hipLaunchKernelGGL((gemv_q4_kernel<true, false>), grid, block, 0, s, a);
         } else hipLaunchKernelGGL((gemv_q4_kernel<false, false>), grid, block, 0, s, a);
