@@ -78,7 +78,7 @@ struct bark_context {
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
     // q4_0 models: activations stay f32 between the products and are quantised to q8_0 rows (xq8 / xd8) in front of each
     bool any_q4 = false;
-    float * att32 = nullptr, * h32 = nullptr, * xd8 = nullptr; int8_t * xq8 = nullptr;
+    float * att32 = nullptr, * h32 = nullptr, * xd8 = nullptr, * xd8T = nullptr; int8_t * xq8 = nullptr;
     int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;

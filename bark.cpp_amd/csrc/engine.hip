@@ -147,6 +147,8 @@ static void init_runtime(bark_context * ctxp) {
         ctx->h32 = dev_alloc<float>(ctx.get(), NE * 4);
         ctx->xq8 = dev_alloc<int8_t>(ctx.get(), NE * 4);
         ctx->xd8 = dev_alloc<float>(ctx.get(), NE * 4 / 32);
+        ctx->xd8T = dev_alloc<float>(ctx.get(), (size_t) (4 * ctx->max_E / 32) * 1024);
+        HIP_OK(hipMemset(ctx->xd8T, 0, (size_t) (4 * ctx->max_E / 32) * 1024 * sizeof(float)));
     }
     size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
     for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
@@ -415,10 +417,10 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         // f16 weights: activations are rounded to f16 rows (xn / att / hbuf); q4_0 weights: f32 rows quantised to q8_0 (xq8 / xd8)
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq8, c->xd8);
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq8, c->xd8, c->xd8T);
         else      launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
         LinArgs a;
-        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq8 = c->xq8; a.xd8 = c->xd8; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq8 = c->xq8; a.xd8 = c->xd8; a.xd8T = c->xd8T; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         launch_linear(s, a);
         AttnPrefillArgs at;
@@ -426,19 +428,19 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
         { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
-        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq8, c->xd8);
+        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq8, c->xd8, c->xd8T);
         LinArgs p;
-        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq8 = c->xq8; p.xd8 = c->xd8; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq8 = c->xq8; p.xd8 = c->xd8; p.xd8T = c->xd8T; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
         launch_linear(s, p);
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq8, c->xd8);
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq8, c->xd8, c->xd8T);
         else      launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
         LinArgs f;
-        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq8 = c->xq8; f.xd8 = c->xd8; f.bias = L.fc_b; f.epi = EPI_GELU;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq8 = c->xq8; f.xd8 = c->xd8; f.xd8T = c->xd8T; f.bias = L.fc_b; f.epi = EPI_GELU;
         f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(s, f);
-        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq8, c->xd8);
+        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq8, c->xd8, c->xd8T);
         LinArgs o;
-        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq8 = c->xq8; o.xd8 = c->xd8; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq8 = c->xq8; o.xd8 = c->xd8; o.xd8T = c->xd8T; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
         launch_linear(s, o);
     }
 }
@@ -684,10 +686,10 @@ void run_fine_forward(bark_context * c, int nn, int n_rows) {
     const int E = m.hp.n_embd;
     launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
     run_layers_rows(c, m, 1024, false);
-    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq8, c->xd8);
+    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq8, c->xd8, c->xd8T);
     else      launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
-    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq8 = c->xq8; a.xd8 = c->xd8; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq8 = c->xq8; a.xd8 = c->xd8; a.xd8T = c->xd8T; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace

@@ -44,6 +44,7 @@ struct LinArgs {
     // quantised to q8_0 blocks inside the kernel, as ggml's mul_mat does for a q4_0 src0
     Q4Mat wq;
     const int8_t * xq8 = nullptr; const float * xd8 = nullptr;   // N > 1: rows already quantised by launch_q8_rows
+    const float * xd8T = nullptr;                                // block-major copy of xd8 ([K/32][1024]) for the i8-MFMA kernel
     const float * bias = nullptr;
     int epi = EPI_LOGITS;
     // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
@@ -81,8 +82,9 @@ void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const Q4Mat *
                        const int32_t * tokens_8x1024, int nn, float * x);
 
 void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats);
-// q8_0 quantisation of N f32 rows of length K (LayerNorm first when ln_g != nullptr): q [N][K] int8, d [N][K/32] f32
-void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d);
+// q8_0 quantisation of N <= 1024 f32 rows of length K (LayerNorm first when ln_g != nullptr): q [N][K] int8, d [N][K/32] f32,
+// dT (optional) the same scales block-major [K/32][1024]
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d, float * dT);
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
 
 // Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
 }
 
 // rows (N > 1): q8_0 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
-struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; };
+struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; float * dT; };
 __global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
     const int lane = threadIdx.x, n = blockIdx.x;
     const int K = a.K, nblk = K >> 5;
@@ -768,13 +768,14 @@ __global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
         qp[0] = make_int4(xq.q[0], xq.q[1], xq.q[2], xq.q[3]);
         qp[1] = make_int4(xq.q[4], xq.q[5], xq.q[6], xq.q[7]);
         a.d[(size_t) n * nblk + b] = xq.d;
+        if (a.dT) a.dT[(size_t) b * 1024 + n] = xq.d;          // block-major copy for the MFMA kernel ([K/32][1024])
     }
 }
 
 // rows (N > 1): NB pre-quantised activation rows per wave share each unpacked weight block.
 // TODO(next round): v_mfma_i32_32x32x32_i8 holds exactly one q4_0 block per instruction; this first version keeps the
 // integer sums on v_dot4 and is bound by L2 re-reads of the weights.
-struct Q4RowsArgs { LinArgs lin; const int8_t * q; const float * d; };
+struct Q4RowsArgs { LinArgs lin; const int8_t * q; const float * d; const float * dT; };
 template <int NB>
 __global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
     const LinArgs & a = qa.lin;
@@ -811,8 +812,105 @@ __global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
     }
 }
 
-void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d) {
-    Q8RowsArgs a{x, N, K, ln_g, ln_b, q, d};
+// rows (N > 1) on the matrix cores: v_mfma_i32_32x32x32_i8 multiplies exactly one q4_0 block (32 weights of 32 output rows,
+// nibbles widened to int8) by one q8_0 block of 32 activation rows - the int32 results are the exact block sums of C1q.
+// Workgroup tile: 64 activation rows x 32 output rows, 8 waves; wave w owns the chains 2 w and 2 w + 1 (blocks 2 w + 16 i
+// and 2 w + 1 + 16 i, ascending), scales every block sum as ((float) sumi * d4) * d8 and adds it to the chain in f32.
+// The weight scale d4 is per lane (the lane's output row), the 16 activation scales of a lane's accumulator rows come
+// from the block-major copy of d8 as four float4 loads.  Chains 2 w and 2 w + 1 meet in registers (tree level xor 1),
+// the eight pair sums of an output in LDS (levels xor 2, 4, 8).
+constexpr int Q4G_TM = 32, Q4G_TN = 64, Q4G_LD = 33;
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512) void gemm_q4_mfma_kernel(const Q4RowsArgs qa) {
+    extern __shared__ float q4g_red[];                         // [8 chain pairs][64 activation rows][33]
+    const LinArgs & a = qa.lin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * Q4G_TM, n0 = blockIdx.y * Q4G_TN;
+    const int K = a.K, nblk = K >> 5;
+    const int li = lane & 31, kh = lane >> 5;
+    const int m = min(m0 + li, a.M - 1);
+    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + (size_t) m * nblk;
+    const half_t * wd = a.wq.d + (size_t) m * nblk;
+    const int8_t * xq[2]; const float * xdT[2];
+    #pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        const int n = min(n0 + 32 * nt + li, a.N - 1);
+        xq[nt] = qa.q + (size_t) n * K + 16 * kh;
+        xdT[nt] = qa.dT + n0 + 32 * nt + 4 * kh;                 // accumulator register r <-> activation row (r & 3) + 8 (r >> 2) + 4 kh
+    }
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+        #pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[ch][nt][r] = 0.0f;
+    const intx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b0 = 2 * wave; b0 < nblk; b0 += 16) {
+        #pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const int b = b0 + ch;
+            if (b < nblk) {                                    // wave-uniform
+                const uint4 w = wq[b];
+                const float d4 = (float) wd[b];
+                intx4 xa[2]; float4 d8[2][4];
+                #pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    xa[nt] = *reinterpret_cast<const intx4 *>(xq[nt] + (b << 5));
+                    #pragma unroll
+                    for (int g = 0; g < 4; g++) d8[nt][g] = *reinterpret_cast<const float4 *>(xdT[nt] + (size_t) b * 1024 + 8 * g);
+                }
+                // lanes 0..31 carry elements 0..15 of the block (low nibbles), lanes 32..63 elements 16..31 (high nibbles)
+                const unsigned wr[4] = {w.x, w.y, w.z, w.w};
+                intx4 wv;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned nib = (wr[i] >> (4 * kh)) & 0x0F0F0F0Fu;
+                    wv[i] = (int) (((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+                }
+                #pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    const intx16 si = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[nt], wv, zero, 0, 0, 0);
+                    #pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float dd[4] = {d8[nt][g].x, d8[nt][g].y, d8[nt][g].z, d8[nt][g].w};
+                        #pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int r = 4 * g + j;
+                            const float tb = ((float) si[r] * d4) * dd[j];
+                            acc[ch][nt][r] = acc[ch][nt][r] + tb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // tree level xor 1 in registers, then the 8 pair sums per output through LDS
+    float * red = q4g_red + (size_t) wave * (Q4G_TN * Q4G_LD);
+    #pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int nl = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            red[nl * Q4G_LD + li] = acc[0][nt][r] + acc[1][nt][r];
+        }
+    __syncthreads();
+    #pragma unroll
+    for (int k = 0; k < (Q4G_TM * Q4G_TN) / 512; k++) {
+        const int o = tid + 512 * k;
+        const int nl = o >> 5, ml = o & 31;
+        float p[8];
+        #pragma unroll
+        for (int c = 0; c < 8; c++) p[c] = q4g_red[(size_t) c * (Q4G_TN * Q4G_LD) + nl * Q4G_LD + ml];
+        const float r = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (n0 + nl < a.N && m0 + ml < a.M) linear_epilogue(a, n0 + nl, m0 + ml, r, 0);
+    }
+}
+
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d, float * dT) {
+    if (N > 1024) { fprintf(stderr, "bark-hip: q8_0 row quantisation handles at most 1024 rows\n"); abort(); }
+    Q8RowsArgs a{x, N, K, ln_g, ln_b, q, d, dT};
     hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
 }
 
@@ -830,8 +928,15 @@ static void launch_linear_q4(hipStream_t s, const LinArgs & a) {
         return;
     }
     if (!a.xq8 || !a.xd8 || a.parity_rows) { fprintf(stderr, "bark-hip: q4_0 row product needs pre-quantised rows\n"); abort(); }
+    static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, kept as the cross-check path
+    if (a.xd8T && !force_rows) {
+        Q4RowsArgs qa{a, a.xq8, a.xd8, a.xd8T};
+        dim3 grid((a.M + Q4G_TM - 1) / Q4G_TM, (a.N + Q4G_TN - 1) / Q4G_TN), block(512);
+        hipLaunchKernelGGL(gemm_q4_mfma_kernel, grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
+        return;
+    }
     constexpr int NB = 8;
-    Q4RowsArgs qa{a, a.xq8, a.xd8};
+    Q4RowsArgs qa{a, a.xq8, a.xd8, nullptr};
     dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
     hipLaunchKernelGGL((gemm_q4_rows_kernel<NB>), grid, block, 0, s, qa);
 }
@@ -1834,6 +1939,8 @@ void init_kernel_attributes() {
                                32 * ATT_LD * (int) sizeof(float));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
 }
 
 }  // namespace barkhip
