@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--n-semantic", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-q4", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N > 1 path on a single GPU (with --backend gloo)")
     a = ap.parse_args()
@@ -171,6 +172,28 @@ def main():
                 bctx.free()
             except Exception as e:      # noqa: BLE001
                 out["batched_8_utterances"] = {"error": str(e)}
+        # BASELINE config 4: the same model quantised to q4_0 by the native bark_model_quantize (reported beside the headline)
+        if world == 1 and not a.no_q4:
+            try:
+                qpath = path[:-4] + "_q4_0.bin"
+                if not os.path.exists(qpath):
+                    assert pkg.load_library().bark_model_quantize(path.encode(), (qpath + ".tmp").encode(), 2)
+                    os.replace(qpath + ".tmp", qpath)
+                qctx = pkg.BarkContext.load_model(qpath, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=a.n_semantic), seed=0)
+                qctx.generate_audio(prompts[0])
+                tq = time.perf_counter(); qa = 0.0
+                for i in range(2):
+                    assert qctx.generate_audio(prompts[1 + i]); qa += qctx.stats()["n_samples"] / 24000.0
+                dtq = time.perf_counter() - tq
+                dus, dbytes = qctx.time_decode_step(0, 640, 300)
+                fus, flops = qctx.time_fine_pass(6)
+                out["q4_0"] = {"rtf": qa / dtq, "ms_per_prompt": dtq * 500.0, "file_MB": os.path.getsize(qpath) / 1e6,
+                               "decode_step_us": dus, "decode_step_GB/s": dbytes / (dus * 1e-6) / 1e9,
+                               "fine_pass_us": fus, "fine_pass_equiv_TFLOP/s": flops / (fus * 1e-6) / 1e12,
+                               "note": "q4_0 x q8_0 block products: v_dot4 GEMV (decode), v_mfma_i32_32x32x32_i8 (prefill / fine); bit-exact vs the oracle"}
+                qctx.free()
+            except Exception as e:      # noqa: BLE001
+                out["q4_0"] = {"error": str(e)}
         if not a.no_cpu_baseline and world == 1:
             from oracle.pyoracle import Oracle
             cores = min(os.cpu_count() or 4, 8)
