@@ -39,11 +39,12 @@ bool read_record(Cursor & c, std::string & name, TensorRef & t, std::string & er
     const uint8_t * nm = c.take((size_t) name_len);
     if (!c.ok) { err = "truncated tensor name"; return false; }
     name.assign((const char *) nm, (size_t) name_len);
-    if (t.ttype < 0 || t.ttype > 2) {
-        err = "tensor '" + name + "' has ggml type " + std::to_string(t.ttype) + ": only f32, f16 and q4_0 are supported";
+    const QuantFormat * qf = quant_format_by_type(t.ttype);
+    if (t.ttype != 0 && t.ttype != 1 && !qf) {
+        err = "tensor '" + name + "' has ggml type " + std::to_string(t.ttype) + ": only f32, f16, q4_0, q4_1, q5_0, q5_1 and q8_0 are supported";
         return false;
     }
-    if (t.ttype == 2 && (t.ne[0] % 32) != 0) { err = "q4_0 tensor '" + name + "' has a row length that is not a multiple of 32"; return false; }
+    if (qf && (t.ne[0] % 32) != 0) { err = std::string(qf->name) + " tensor '" + name + "' has a row length that is not a multiple of 32"; return false; }
     t.data = c.take(t.nbytes());
     if (!c.ok) { err = "truncated data of tensor '" + name + "'"; return false; }
     return true;
@@ -85,8 +86,8 @@ bool ModelFile::open(const char * path, std::string & err) {
         if (!c.ok) { err = std::string("truncated hparams of ") + kNames[g]; return false; }
         // bark.cpp:711,727,2254 - quantised files carry 2000 + ggml_ftype
         // (GGML_QNT_VERSION_FACTOR = 1000; ggml_ftype 0 f32, 1 f16, 2 mostly q4_0)
-        if (hp.ftype < 0 || hp.ftype % 1000 > 2) {
-            err = std::string(kNames[g]) + ": model ftype " + std::to_string(hp.ftype) + " is not supported (f32, f16 and q4_0 only)";
+        if (hp.ftype < 0 || (hp.ftype % 1000 > 1 && !quant_format_by_ftype(hp.ftype % 1000))) {
+            err = std::string(kNames[g]) + ": model ftype " + std::to_string(hp.ftype) + " is not supported (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0)";
             return false;
         }
         if (hp.n_layer <= 0 || hp.n_layer > 128 || hp.n_head <= 0 || hp.n_embd <= 0 || hp.n_embd % hp.n_head != 0 ||

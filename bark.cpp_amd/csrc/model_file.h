@@ -9,6 +9,8 @@
 //
 // The file is mmapped; TensorRef::data points into the mapping (possibly unaligned).
 #pragma once
+#include "quant_formats.h"
+
 #include <cstdint>
 #include <map>
 #include <string>
@@ -17,12 +19,15 @@
 namespace barkhip {
 
 struct TensorRef {
-    int32_t ttype = 0;                  // 0 f32, 1 f16, 2 q4_0 (18-byte blocks of 32: f16 scale + 16 nibble bytes)
+    int32_t ttype = 0;                  // ggml_type: 0 f32, 1 f16, or one of the block formats of quant_formats.h
     int32_t n_dims = 0;
     int64_t ne[4] = {1, 1, 1, 1};       // ne[0] innermost
     const uint8_t * data = nullptr;
     int64_t nelements() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
-    size_t  nbytes() const { return ttype == 2 ? (size_t) (nelements() / 32) * 18 : (size_t) nelements() * (ttype == 1 ? 2 : 4); }
+    size_t  nbytes() const {
+        if (const QuantFormat * q = quant_format_by_type(ttype)) return (size_t) (nelements() / 32) * (size_t) q->block_bytes;
+        return (size_t) nelements() * (ttype == 1 ? 2 : 4);
+    }
 };
 
 struct GptHparams {   // bark.cpp:700-709 (file order)

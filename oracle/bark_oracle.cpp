@@ -84,7 +84,7 @@ static inline uint16_t ld_u16(const uint8_t * p, size_t i) { uint16_t v; memcpy(
 // model file (layout: convert.py:59-110,202-322 ; bark.cpp:664-727,995-1068)
 // ------------------------------------------------------------------------------------
 struct Tensor {
-    int      ttype = 0;            // 0 f32, 1 f16, 2 q4_0
+    int      ttype = 0;            // ggml_type: 0 f32, 1 f16, 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0
     int      n_dims = 0;
     int64_t  ne[4] = {1, 1, 1, 1}; // ne[0] innermost
     const uint8_t * data = nullptr;  // into the file mapping; NOT necessarily aligned
@@ -103,6 +103,34 @@ struct Reader {
     }
 };
 
+// ggml block formats of quantised files (block_q4_0 ... block_q8_0, 32 weights per block):
+//   type 2 q4_0: f16 d | 16 B nibbles             w_j = (n_j - 8) d            18 bytes
+//   type 3 q4_1: f16 d | f16 m | 16 B nibbles     w_j = n_j d + m              20 bytes
+//   type 6 q5_0: f16 d | u32 qh | 16 B nibbles    w_j = ((n_j | h_j << 4) - 16) d   22 bytes
+//   type 7 q5_1: f16 d | f16 m | u32 qh | nibbles w_j = (n_j | h_j << 4) d + m      24 bytes
+//   type 8 q8_0: f16 d | 32 int8                  w_j = q_j d                  34 bytes
+// nibble byte i = element i (low) and i + 16 (high); bit j of qh = fifth bit of element j.
+static int qblock_bytes(int ttype) {
+    switch (ttype) { case 2: return 18; case 3: return 20; case 6: return 22; case 7: return 24; case 8: return 34; default: return 0; }
+}
+// the 32 integer levels of a block and its (d, m)
+static void qblock_unpack(int ttype, const uint8_t * blk, int (&q)[32], float & d, float & m) {
+    d = h2f(ld_u16(blk, 0)); m = 0.0f;
+    const bool has_m = ttype == 3 || ttype == 7, has_h = ttype == 6 || ttype == 7;
+    if (has_m) m = h2f(ld_u16(blk, 1));
+    if (ttype == 8) { for (int j = 0; j < 32; j++) q[j] = (int8_t) blk[2 + j]; return; }
+    uint32_t qh = 0;
+    const uint8_t * p = blk + 2 + (has_m ? 2 : 0);
+    if (has_h) { memcpy(&qh, p, 4); p += 4; }
+    for (int j = 0; j < 16; j++) {
+        int lo = p[j] & 0x0F, hi = p[j] >> 4;
+        if (has_h) { lo |= (int) ((qh >> j) & 1u) << 4; hi |= (int) ((qh >> (j + 16)) & 1u) << 4; }
+        if (ttype == 2) { lo -= 8; hi -= 8; }
+        if (ttype == 6) { lo -= 16; hi -= 16; }
+        q[j] = lo; q[j + 16] = hi;
+    }
+}
+
 static bool read_tensor_record(Reader & r, std::string & name, Tensor & t) {
     t = Tensor();
     t.n_dims = r.get<int32_t>();
@@ -113,12 +141,11 @@ static bool read_tensor_record(Reader & r, std::string & name, Tensor & t) {
     const uint8_t * nm = r.skip(len);
     if (!r.ok) return false;
     name.assign((const char *) nm, len);
-    if (t.ttype != 0 && t.ttype != 1 && t.ttype != 2) {
-        fprintf(stderr, "oracle: tensor '%s' has type %d; only f32 / f16 / q4_0 files are restated\n", name.c_str(), t.ttype);
+    if (t.ttype != 0 && t.ttype != 1 && !qblock_bytes(t.ttype)) {
+        fprintf(stderr, "oracle: tensor '%s' has type %d; only f32 / f16 / q4_0 / q4_1 / q5_0 / q5_1 / q8_0 files are restated\n", name.c_str(), t.ttype);
         return false;
     }
-    // q4_0: 32 weights per 18-byte block {f16 d; 16 nibble bytes}  (ggml block_q4_0)
-    size_t bytes = t.ttype == 2 ? (size_t) t.nelements() / 32 * 18 : (size_t) t.nelements() * (t.ttype == 1 ? 2 : 4);
+    size_t bytes = qblock_bytes(t.ttype) ? (size_t) t.nelements() / 32 * (size_t) qblock_bytes(t.ttype) : (size_t) t.nelements() * (t.ttype == 1 ? 2 : 4);
     t.data = r.skip(bytes);
     return r.ok;
 }
@@ -170,11 +197,12 @@ static void canon_image_f32(const float * src, int K, float * dst) {
 // Weight matrices are re-imaged once at load time (CanonW); f16 weights stay f16 (exact).
 struct CanonW {
     int M = 0, K = 0, Kp = 0; bool f16 = false;
-    const uint8_t * q4 = nullptr;                       // q4_0 weights stay in file order: [M][K/32] blocks of 18 bytes
+    const uint8_t * q4 = nullptr;                       // quantised weights stay in file order: [M][K/32] blocks
+    int qtype = 0;                                      // their ggml_type (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0)
     uint8_t * data = nullptr; size_t bytes = 0;         // [M][Kp] in chain-major order
     CanonW() = default;
     CanonW(const CanonW &) = delete; CanonW & operator=(const CanonW &) = delete;
-    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), q4(o.q4), data(o.data), bytes(o.bytes) { o.data = nullptr; }
+    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), q4(o.q4), qtype(o.qtype), data(o.data), bytes(o.bytes) { o.data = nullptr; }
     ~CanonW() { if (data) munmap(data, bytes); }
     void build(const uint8_t * src, bool src_f16, int M_, int K_) {
         M = M_; K = K_; Kp = canon_kp(K); f16 = src_f16;
@@ -237,9 +265,12 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
     m.n_out = r.get<int32_t>(); m.n_lm_heads = r.get<int32_t>(); m.n_wtes = r.get<int32_t>();
     m.ftype = r.get<int32_t>();
     if (!r.ok) return false;
-    if ((m.ftype % 1000) > 2) {   // bark.cpp:711,727,2254: quantised files carry 2000 + ggml_ftype; f32 (0), f16 (1), q4_0 (2) are restated
-        fprintf(stderr, "oracle: ftype %d is not restated\n", m.ftype);
-        return false;
+    {   // bark.cpp:711,727,2254: quantised files carry 2000 + ggml_ftype; restated: f32 (0), f16 (1), q4_0 (2), q4_1 (3), q8_0 (7), q5_0 (8), q5_1 (9)
+        const int ft = m.ftype % 1000;
+        if (!(ft == 0 || ft == 1 || ft == 2 || ft == 3 || ft == 7 || ft == 8 || ft == 9)) {
+            fprintf(stderr, "oracle: ftype %d is not restated\n", m.ftype);
+            return false;
+        }
     }
     if (m.n_layer <= 0 || m.n_layer > 256 || m.n_embd <= 0 || m.n_head <= 0 || m.n_embd % m.n_head) return false;
     m.layers.resize(m.n_layer); m.wtes.resize(m.n_wtes); m.lm_heads.resize(m.n_lm_heads);
@@ -268,7 +299,7 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
     };
     auto needw = [&](const std::string & n, CanonW & out, int64_t ne0, int64_t ne1) {
         Tensor t; if (!need(n, t, ne0, ne1)) return false;
-        if (t.ttype == 2) { out.M = (int) ne1; out.K = (int) ne0; out.q4 = t.data; return ne0 % 32 == 0; }
+        if (qblock_bytes(t.ttype)) { out.M = (int) ne1; out.K = (int) ne0; out.q4 = t.data; out.qtype = t.ttype; return ne0 % 32 == 0; }
         out.build(t.data, t.ttype == 1, (int) ne1, (int) ne0); return true;
     };
     const int E = m.n_embd;
@@ -453,34 +484,45 @@ static void softmax_row(float * s, int n) {
 }
 
 // C[n*ldc + m] = C1-dot(W[m], B[n])   (B rows: f32, already holding f16-rounded values where ggml rounds)
-// ggml's q4_0 x q8_0 product (ggml_vec_dot_q4_0_q8_0; the f32 activation row is quantised to q8_0 blocks by mul_mat,
-// SURVEY.md A.4 item 1): per 32-element block  sumi = sum (nibble - 8) * q8 (exact int32),  t = ((float) sumi * d4) * d8.
+// ggml's quantised products (ggml_vec_dot_q4_0_q8_0, _q4_1_q8_1, _q5_0_q8_0, _q5_1_q8_1, _q8_0_q8_0): mul_mat first quantises
+// the f32 activation row to q8_0 / q8_1 blocks: d = amax / 127, q = roundf(x / d), d stored as f16,
+// and for q8_1 also s = f16(d * sum q) with the unrounded d.  Per 32-element block, sumi = sum w_int * q8 (exact int32) and
+//   q4_0:        t = ((float) sumi * dw) * dx
+//   q5_0, q8_0:  t = (dw * dx) * (float) sumi
+//   q4_1, q5_1:  t = (dw * dx) * (float) sumi + mw * sx
 // Canonical order C1q: block b belongs to chain (b mod 16), chains add their t in ascending b from +0, then the C1 tree.
-struct Q8Row { std::vector<int8_t> q; std::vector<float> d; };
-static void quantize_row_q8_0(const float * x, int K, Q8Row & r) {
-    r.q.resize((size_t) K); r.d.resize((size_t) K / 32);
+struct Q8Row { std::vector<int8_t> q; std::vector<float> d, s; };
+static void quantize_row_q8(const float * x, int K, Q8Row & r) {
+    r.q.resize((size_t) K); r.d.resize((size_t) K / 32); r.s.resize((size_t) K / 32);
     for (int b = 0; b < K / 32; b++) {
         float amax = 0.0f;
         for (int j = 0; j < 32; j++) amax = std::max(amax, fabsf(x[b * 32 + j]));
         const float d = amax / 127.0f;                       // amax / ((1 << 7) - 1)
         const float id = d ? 1.0f / d : 0.0f;
         r.d[(size_t) b] = round_h(d);                        // the block scale is stored as f16
-        for (int j = 0; j < 32; j++) r.q[(size_t) b * 32 + j] = (int8_t) roundf(x[b * 32 + j] * id);
+        int sum = 0;
+        for (int j = 0; j < 32; j++) { const int8_t q = (int8_t) roundf(x[b * 32 + j] * id); r.q[(size_t) b * 32 + j] = q; sum += q; }
+        r.s[(size_t) b] = round_h((float) sum * d);          // q8_1: y.s = FP16(sum * d)
     }
 }
-static float dot_q4_0_q8_0(const uint8_t * wrow, const Q8Row & x, int K) {
+static float dot_q_q8(int qtype, const uint8_t * wrow, const Q8Row & x, int K) {
     float acc[16];
     for (float & a : acc) a = 0.0f;
+    const int bb = qblock_bytes(qtype);
     for (int b = 0; b < K / 32; b++) {
-        const uint8_t * blk = wrow + (size_t) b * 18;
-        const float d4 = h2f(ld_u16(blk, 0));
+        int w[32]; float dw, mw;
+        qblock_unpack(qtype, wrow + (size_t) b * bb, w, dw, mw);
         const int8_t * q8 = x.q.data() + (size_t) b * 32;
         int sumi = 0;
-        for (int j = 0; j < 16; j++) {
-            sumi += ((int) (blk[2 + j] & 0x0F) - 8) * q8[j];
-            sumi += ((int) (blk[2 + j] >> 4) - 8) * q8[j + 16];
+        for (int j = 0; j < 32; j++) sumi += w[j] * q8[j];
+        const float dx = x.d[(size_t) b];
+        float t;
+        if (qtype == 2) t = ((float) sumi * dw) * dx;
+        else {
+            const float dd = dw * dx;
+            t = dd * (float) sumi;
+            if (qtype == 3 || qtype == 7) { const float ms = mw * x.s[(size_t) b]; t = t + ms; }
         }
-        const float t = ((float) sumi * d4) * x.d[(size_t) b];
         acc[b & 15] = acc[b & 15] + t;
     }
     for (int st = 1; st < 16; st <<= 1) for (int c = 0; c < 16; c += 2 * st) acc[c] = acc[c] + acc[c + st];
@@ -489,11 +531,11 @@ static float dot_q4_0_q8_0(const uint8_t * wrow, const Q8Row & x, int K) {
 static void gemm_q4(const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
     std::vector<Q8Row> rows((size_t) N);
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
-    for (int n = 0; n < N; n++) quantize_row_q8_0(B + (size_t) n * ldb, K, rows[(size_t) n]);
-    const size_t rb = (size_t) K / 32 * 18;
+    for (int n = 0; n < N; n++) quantize_row_q8(B + (size_t) n * ldb, K, rows[(size_t) n]);
+    const size_t rb = (size_t) K / 32 * (size_t) qblock_bytes(W.qtype);
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
     for (int m = 0; m < M; m++)
-        for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_q4_0_q8_0(W.q4 + (size_t) m * rb, rows[(size_t) n], K);
+        for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_q_q8(W.qtype, W.q4 + (size_t) m * rb, rows[(size_t) n], K);
 }
 
 static void gemm_w(Oracle & o, const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
@@ -625,15 +667,14 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
 }
 
 static void embed_row(const Tensor & wte, int id, float * out, int E) {
-    if (wte.ttype == 2) {
-        const uint8_t * row = wte.data + (size_t) id * (E / 32) * 18;
+    if (const int bb = qblock_bytes(wte.ttype)) {
+        // ggml_get_rows dequantises the row: w = q * d (+ m)
+        const uint8_t * row = wte.data + (size_t) id * (E / 32) * bb;
+        const bool has_m = wte.ttype == 3 || wte.ttype == 7;
         for (int b = 0; b < E / 32; b++) {
-            const uint8_t * blk = row + (size_t) b * 18;
-            const float d = h2f(ld_u16(blk, 0));
-            for (int j = 0; j < 16; j++) {
-                out[b * 32 + j] = (float) ((int) (blk[2 + j] & 0x0F) - 8) * d;
-                out[b * 32 + j + 16] = (float) ((int) (blk[2 + j] >> 4) - 8) * d;
-            }
+            int q[32]; float d, m;
+            qblock_unpack(wte.ttype, row + (size_t) b * bb, q, d, m);
+            for (int j = 0; j < 32; j++) { const float v = (float) q[j] * d; out[b * 32 + j] = has_m ? v + m : v; }
         }
         return;
     }
@@ -1137,8 +1178,14 @@ void orc_test_attention(const float * q, const float * kc, const float * vc, int
 }
 // y = C1q dot of one q4_0 row (K/32 blocks of 18 bytes) with the f32 row x (quantised to q8_0 as mul_mat does)
 float orc_test_q4dot(const uint8_t * blocks, const float * x, int K) {
-    Q8Row r; quantize_row_q8_0(x, K, r);
-    return dot_q4_0_q8_0(blocks, r, K);
+    Q8Row r; quantize_row_q8(x, K, r);
+    return dot_q_q8(2, blocks, r, K);
+}
+// the same for any restated block format (qtype = ggml_type of the weight row)
+float orc_test_qdot(int qtype, const uint8_t * blocks, const float * x, int K) {
+    if (!qblock_bytes(qtype)) return NAN;
+    Q8Row r; quantize_row_q8(x, K, r);
+    return dot_q_q8(qtype, blocks, r, K);
 }
 void orc_test_layer_norm(const float * x, float * y, int E, const float * g, const float * b) { layer_norm_row(x, y, E, g, b); }
 

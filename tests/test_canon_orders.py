@@ -159,3 +159,53 @@ def test_c1q_q4_0_times_q8_0_dot(lib, K):
         t = np.float32(np.float32(np.float32(sumi) * np.float32(d4[b])) * d8)
         acc[b % 16] = add32(acc[b % 16], t)
     assert got == tree16(acc)
+
+
+@pytest.mark.parametrize("fmt", ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0"])
+def test_c1q_all_block_formats(lib, fmt):
+    """Every restated ggml block format x q8_0 / q8_1 activations: integer levels decoded from the bytes independently of
+    the oracle, block terms and chains in numpy float32."""
+    from tests.test_quantize import FORMATS, _blocks
+    K = 640                                                   # 20 blocks: chains 0..3 hold two blocks, the rest one
+    rng = np.random.default_rng(len(fmt) * 131 + ord(fmt[1]) + ord(fmt[3]))
+    w = (rng.standard_normal(K) * 0.05 + 0.01).astype(np.float32)
+    x = rng.standard_normal(K).astype(np.float32)
+    _, ttype, nb = FORMATS[fmt]
+    blocks = np.ascontiguousarray(_blocks(fmt, w[None, :]).astype(np.uint8))
+    assert blocks.shape == (K // 32, nb)
+    lib.orc_test_qdot.restype = C.c_float
+    lib.orc_test_qdot.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    got = np.float32(lib.orc_test_qdot(ttype, blocks.ctypes.data, x.ctypes.data, K))
+    f32 = np.float32
+    acc = [f32(0.0)] * 16
+    for b in range(K // 32):
+        blk = blocks[b]
+        dw = f32(blk[0:2].copy().view(np.float16)[0]); pos = 2
+        mw = f32(0.0)
+        if fmt in ("q4_1", "q5_1"):
+            mw = f32(blk[2:4].copy().view(np.float16)[0]); pos = 4
+        if fmt == "q8_0":
+            wq = [int(v) for v in blk[2:34].copy().view(np.int8)]
+        else:
+            qh = 0
+            if fmt in ("q5_0", "q5_1"):
+                qh = int(blk[pos:pos + 4].copy().view(np.uint32)[0]); pos += 4
+            qs = blk[pos:pos + 16]
+            wq = [int(qs[j] & 15) | (((qh >> j) & 1) << 4) for j in range(16)] + [int(qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4) for j in range(16)]
+            wq = [v - {"q4_0": 8, "q5_0": 16}.get(fmt, 0) for v in wq]
+        xb = x[32 * b:32 * b + 32]
+        amax = f32(np.max(np.abs(xb)))
+        d = f32(amax / f32(127.0))
+        inv = f32(1.0) / d if d != 0 else f32(0.0)
+        q8 = [int(math.copysign(math.floor(abs(float(f32(v * inv))) + 0.5), float(v))) for v in xb]     # roundf: half away from zero
+        dx = f32(np.float16(d))
+        sx = f32(np.float16(f32(f32(sum(q8)) * d)))
+        sumi = sum(a * c for a, c in zip(wq, q8))
+        if fmt == "q4_0":
+            t = f32(f32(f32(sumi) * dw) * dx)
+        else:
+            t = f32(f32(dw * dx) * f32(sumi))
+            if fmt in ("q4_1", "q5_1"):
+                t = add32(t, f32(mw * sx))
+        acc[b % 16] = add32(acc[b % 16], t)
+    assert got == tree16(acc)
