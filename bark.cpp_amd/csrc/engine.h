@@ -23,14 +23,14 @@ struct GptModel {
     GptHparams hp;
     const half_t * wte[8] = {};
     const half_t * lm_head[8] = {};
-    // q4_0 model files (bark_model_quantize output): every weight matrix is a Q4Mat instead of an f16 pointer
+    // quantised model files (bark_model_quantize output): every weight matrix is a QMat instead of an f16 pointer
     bool q4 = false;
-    Q4Mat wte_q[8], lm_head_q[8];
+    QMat wte_q[8], lm_head_q[8];
     const float * wpe = nullptr, * lnf_g = nullptr, * lnf_b = nullptr;
     struct Layer {
         const float * ln1_g = nullptr, * ln1_b = nullptr, * ln2_g = nullptr, * ln2_b = nullptr;
         const half_t * attn_w = nullptr, * proj_w = nullptr, * fc_w = nullptr, * mproj_w = nullptr;
-        Q4Mat attn_q, proj_q, fc_q, mproj_q;
+        QMat attn_q, proj_q, fc_q, mproj_q;
         const float * attn_b = nullptr, * proj_b = nullptr, * fc_b = nullptr, * mproj_b = nullptr;
     };
     std::vector<Layer> layers;
@@ -76,9 +76,9 @@ struct bark_context {
     // GPT scratch
     float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
-    // q4_0 models: activations stay f32 between the products and are quantised to q8_0 rows (xq8 / xd8) in front of each
+    // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;
-    float * att32 = nullptr, * h32 = nullptr, * xd8 = nullptr, * xd8T = nullptr; int8_t * xq8 = nullptr;
+    float * att32 = nullptr, * h32 = nullptr; barkhip::Q8Scratch xq;
     int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;

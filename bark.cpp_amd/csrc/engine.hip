@@ -55,17 +55,23 @@ const TensorRef & need(const std::map<std::string, TensorRef> & m, const std::st
     if (ne0 > 0 && (t.ne[0] != ne0 || (ne1 > 0 && t.ne[1] != ne1)))       // shape check on ne[0], ne[1] (bark.cpp:1034)
         throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
     if (t.ttype != ttype)
-        throw std::runtime_error("tensor '" + name + "' is " + (t.ttype == 2 ? "q4_0" : t.ttype ? "f16" : "f32") + "; this engine needs the f16 model file (convert.py --use-f16) or its q4_0 quantisation");
+        throw std::runtime_error("tensor '" + name + "' is " + (quant_format_by_type(t.ttype) ? quant_format_by_type(t.ttype)->name : t.ttype ? "f16" : "f32") +
+                                 "; this engine needs the f16 model file (convert.py --use-f16) or a bark_model_quantize output of it");
     return t;
 }
-// a weight matrix: f16, or q4_0 (uploaded later as a Q4Mat)
+// a weight matrix: f16, or q4_0 (uploaded later as a QMat)
 const TensorRef & need_w(const std::map<std::string, TensorRef> & m, const std::string & name, int64_t ne0, int64_t ne1) {
     auto it = m.find(name);
     if (it == m.end()) throw std::runtime_error("missing tensor '" + name + "'");
-    return need(m, name, it->second.ttype == 2 ? 2 : 1, ne0, ne1);
+    return need(m, name, quant_format_by_type(it->second.ttype) ? it->second.ttype : 1, ne0, ne1);
 }
-Q4Mat q4_rows(const Q4Mat & w, size_t row0, int K) {
-    Q4Mat r; r.d = w.d + row0 * (size_t) (K / 32); r.qs = w.qs + row0 * (size_t) (K / 32) * 16; return r;
+QMat q4_rows(const QMat & w, size_t row0, int K) {
+    QMat r = w;
+    const size_t nb = row0 * (size_t) (K / 32);
+    r.d = w.d + nb; r.qs = w.qs + nb * (size_t) quant_formats()[w.qt].qs_bytes;
+    if (w.m) r.m = w.m + nb;
+    if (w.qh) r.qh = w.qh + nb;
+    return r;
 }
 const TensorRef * maybe(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0) {
     auto it = m.find(name);
@@ -145,10 +151,14 @@ static void init_runtime(bark_context * ctxp) {
     if (ctx->any_q4) {
         ctx->att32 = dev_alloc<float>(ctx.get(), NE);
         ctx->h32 = dev_alloc<float>(ctx.get(), NE * 4);
-        ctx->xq8 = dev_alloc<int8_t>(ctx.get(), NE * 4);
-        ctx->xd8 = dev_alloc<float>(ctx.get(), NE * 4 / 32);
-        ctx->xd8T = dev_alloc<float>(ctx.get(), (size_t) (4 * ctx->max_E / 32) * 1024);
-        HIP_OK(hipMemset(ctx->xd8T, 0, (size_t) (4 * ctx->max_E / 32) * 1024 * sizeof(float)));
+        const size_t nT = (size_t) (4 * ctx->max_E / 32) * 1024;
+        ctx->xq.q = dev_alloc<int8_t>(ctx.get(), NE * 4);
+        ctx->xq.d = dev_alloc<float>(ctx.get(), NE * 4 / 32);
+        ctx->xq.s = dev_alloc<float>(ctx.get(), NE * 4 / 32);
+        ctx->xq.dT = dev_alloc<float>(ctx.get(), nT);
+        ctx->xq.sT = dev_alloc<float>(ctx.get(), nT);
+        HIP_OK(hipMemset(ctx->xq.dT, 0, nT * sizeof(float)));
+        HIP_OK(hipMemset(ctx->xq.sT, 0, nT * sizeof(float)));
     }
     size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
     for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
@@ -201,12 +211,12 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     struct Fix { const void ** dst; size_t off; };
     std::vector<Fix> fixes;
     auto place = [&](const TensorRef & t, const void ** dst) { fixes.push_back({dst, plan.add(t)}); };
-    struct Q4Job { const TensorRef * t; Q4Mat * dst; };
+    struct Q4Job { const TensorRef * t; QMat * dst; };
     std::vector<Q4Job> q4_jobs;
     int n_w16 = 0, n_wq4 = 0;
     GptModel * cur_model = nullptr;
-    auto place_w = [&](const TensorRef & t, const half_t ** dst16, Q4Mat * dstq) {
-        if (t.ttype == 2) { q4_jobs.push_back({&t, dstq}); n_wq4++; }
+    auto place_w = [&](const TensorRef & t, const half_t ** dst16, QMat * dstq) {
+        if (quant_format_by_type(t.ttype)) { q4_jobs.push_back({&t, dstq}); n_wq4++; }
         else { place(t, (const void **) dst16); n_w16++; }
         (void) cur_model;
     };
@@ -244,7 +254,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             if (auto * t = maybe(T, p + "/mlp/c_proj/b", 0, E)) place(*t, (const void **) &L.mproj_b);
         }
         // bark_model_quantize converts every matrix of a model or none (bark.cpp:2277-2289)
-        if (n_w16 && n_wq4) throw std::runtime_error("model mixes f16 and q4_0 weight matrices");
+        if (n_w16 && n_wq4) throw std::runtime_error("model mixes f16 and quantised weight matrices");
         m.q4 = n_wq4 > 0;
         ctx->any_q4 = ctx->any_q4 || m.q4;
         ctx->max_E = std::max(ctx->max_E, E);
@@ -318,18 +328,32 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     }
     for (const auto & f : fixes) *f.dst = (const uint8_t *) ctx->weights->slab + f.off;
     for (const auto & j : q4_jobs) {
-        // q4_0 blocks (f16 d + 16 bytes, 18-byte stride) -> separate scale and nibble arrays: 16-byte aligned vector loads
+        // ggml blocks (f16 d [| f16 m] [| u32 qh] | level bytes) -> one device array per field: aligned vector loads of the levels
+        const QuantFormat & qf = *quant_format_by_type(j.t->ttype);
         const size_t nb = (size_t) j.t->nelements() / 32;
-        std::vector<uint16_t> d(nb);
-        std::vector<uint8_t> qs(nb * 16);
-        for (size_t b = 0; b < nb; b++) { memcpy(&d[b], j.t->data + b * 18, 2); memcpy(&qs[b * 16], j.t->data + b * 18 + 2, 16); }
-        void * dd = nullptr, * dq = nullptr;
-        HIP_OK(hipMalloc(&dd, nb * 2)); ctx->weights->extra.push_back(dd);
-        HIP_OK(hipMalloc(&dq, nb * 16)); ctx->weights->extra.push_back(dq);
-        HIP_OK(hipMemcpy(dd, d.data(), nb * 2, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(dq, qs.data(), nb * 16, hipMemcpyHostToDevice));
-        j.dst->d = (const half_t *) dd; j.dst->qs = (const uint8_t *) dq;
-        ctx->weight_bytes += nb * 18;
+        std::vector<uint16_t> d(nb), mn(qf.has_min ? nb : 0);
+        std::vector<uint32_t> qh(qf.has_high_bits ? nb : 0);
+        std::vector<uint8_t> qs(nb * (size_t) qf.qs_bytes);
+        for (size_t b = 0; b < nb; b++) {
+            const uint8_t * blk = j.t->data + b * (size_t) qf.block_bytes;
+            size_t pos = 0;
+            memcpy(&d[b], blk, 2); pos = 2;
+            if (qf.has_min) { memcpy(&mn[b], blk + pos, 2); pos += 2; }
+            if (qf.has_high_bits) { memcpy(&qh[b], blk + pos, 4); pos += 4; }
+            memcpy(&qs[b * (size_t) qf.qs_bytes], blk + pos, (size_t) qf.qs_bytes);
+        }
+        auto upload = [&](const void * src, size_t bytes) -> void * {
+            void * p = nullptr;
+            HIP_OK(hipMalloc(&p, bytes)); ctx->weights->extra.push_back(p);
+            HIP_OK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+            return p;
+        };
+        j.dst->qt = qf.id;
+        j.dst->d = (const half_t *) upload(d.data(), nb * 2);
+        j.dst->qs = (const uint8_t *) upload(qs.data(), qs.size());
+        if (qf.has_min) j.dst->m = (const half_t *) upload(mn.data(), nb * 2);
+        if (qf.has_high_bits) j.dst->qh = (const uint32_t *) upload(qh.data(), nb * 4);
+        ctx->weight_bytes += nb * (size_t) qf.block_bytes;
     }
     {
         // f32 copies of the codec's conv weights (19 MB of f16 in the file): exact, and wave-uniform f32 weights become
@@ -417,10 +441,10 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         // f16 weights: activations are rounded to f16 rows (xn / att / hbuf); q4_0 weights: f32 rows quantised to q8_0 (xq8 / xd8)
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq8, c->xd8, c->xd8T);
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq);
         else      launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
         LinArgs a;
-        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq8 = c->xq8; a.xd8 = c->xd8; a.xd8T = c->xd8T; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         launch_linear(s, a);
         AttnPrefillArgs at;
@@ -428,19 +452,19 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
         { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
-        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq8, c->xd8, c->xd8T);
+        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
-        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq8 = c->xq8; p.xd8 = c->xd8; p.xd8T = c->xd8T; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
         launch_linear(s, p);
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq8, c->xd8, c->xd8T);
+        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq);
         else      launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
         LinArgs f;
-        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq8 = c->xq8; f.xd8 = c->xd8; f.xd8T = c->xd8T; f.bias = L.fc_b; f.epi = EPI_GELU;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq = c->xq; f.bias = L.fc_b; f.epi = EPI_GELU;
         f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(s, f);
-        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq8, c->xd8, c->xd8T);
+        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq);
         LinArgs o;
-        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq8 = c->xq8; o.xd8 = c->xd8; o.xd8T = c->xd8T; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq = c->xq; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
         launch_linear(s, o);
     }
 }
@@ -686,10 +710,10 @@ void run_fine_forward(bark_context * c, int nn, int n_rows) {
     const int E = m.hp.n_embd;
     launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
     run_layers_rows(c, m, 1024, false);
-    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq8, c->xd8, c->xd8T);
+    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq);
     else      launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
-    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq8 = c->xq8; a.xd8 = c->xd8; a.xd8T = c->xd8T; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace

@@ -5,6 +5,8 @@
 // token ids are bit-identical.  All code is built with -ffp-contract=off; fused multiply-adds are
 // written explicitly (fmaf / MFMA).
 #pragma once
+#include "quant_formats.h"
+
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -25,9 +27,16 @@ struct StepState {
     float   pad1;
 };
 
-// ggml Q4_0 matrix, re-laid out at load time: scales [M][K/32] f16 and nibbles [M][K/32][16 bytes]
-// (low nibble of byte j = element j of the block, high nibble = element j + 16)
-struct Q4Mat { const half_t * d = nullptr; const uint8_t * qs = nullptr; };
+// A ggml block-quantised matrix (quant_formats.h), re-laid out at load time into one array per field: scales d [M][K/32]
+// f16, minima m (q4_1 / q5_1), fifth bits qh (q5_0 / q5_1) and the level bytes qs [M][K/32][16] ([..][32] for q8_0;
+// low nibble of byte j = element j of the block, high nibble = element j + 16)
+struct QMat {
+    const half_t * d = nullptr; const uint8_t * qs = nullptr; const half_t * m = nullptr; const uint32_t * qh = nullptr;
+    int qt = 0;                           // QuantId
+};
+// q8 image of N <= 1024 activation rows: levels q [N][K] int8, scales d and s = f16(d * sum q) as [N][K/32] and block-major
+// [K/32][1024] (the i8-MFMA kernel reads 16 consecutive rows of one block)
+struct Q8Scratch { int8_t * q = nullptr; float * d = nullptr, * dT = nullptr, * s = nullptr, * sT = nullptr; };
 
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
@@ -40,11 +49,11 @@ struct LinArgs {
     // ... or (decode GEMV only) one f32 row normalised in the kernel prologue (LayerNorm fused)
     const float * x_f32 = nullptr; const float * ln_g = nullptr; const float * ln_b = nullptr;
     const float * ln_stats = nullptr;     // batched decode: {mean, 1/sqrt(var+eps)} per row from ln_stats_kernel (else computed in the kernel)
-    // Q4_0 weights (wq.qs != nullptr): the input rows are f32 (x_f32 with ld K, LayerNorm applied when ln_g != nullptr) and are
-    // quantised to q8_0 blocks inside the kernel, as ggml's mul_mat does for a q4_0 src0
-    Q4Mat wq;
-    const int8_t * xq8 = nullptr; const float * xd8 = nullptr;   // N > 1: rows already quantised by launch_q8_rows
-    const float * xd8T = nullptr;                                // block-major copy of xd8 ([K/32][1024]) for the i8-MFMA kernel
+    // quantised weights (wq.qs != nullptr): the input row is f32 (x_f32, LayerNorm applied when ln_g != nullptr) and is
+    // quantised to q8 blocks inside the kernel, as ggml's mul_mat does for a quantised src0; N > 1: rows already quantised
+    // by launch_q8_rows into xq
+    QMat wq;
+    Q8Scratch xq;
     const float * bias = nullptr;
     int epi = EPI_LOGITS;
     // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
@@ -69,7 +78,7 @@ void launch_linear(hipStream_t s, const LinArgs & a);
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024;
-    Q4Mat wte_q;                           // q4_0 embedding table (rows are dequantised, ggml_get_rows)
+    QMat wte_q;                           // q4_0 embedding table (rows are dequantised, ggml_get_rows)
     const int32_t * tokens = nullptr;      // n_tokens ids (prefill) - ignored when st != nullptr
     int n_rows = 1; int merge = 0;         // merge: 513 ids -> 257 rows
     int pos0 = 0;
@@ -78,13 +87,12 @@ struct EmbedArgs {
 };
 void launch_embed_causal(hipStream_t s, const EmbedArgs & a);
 // fine: x[i] = sum_{c<=nn} wte_c[tok[c][i]] + wpe[i]                   (bark.cpp:1450-1472)
-void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const Q4Mat * wte_q, const float * wpe, int E, int n_in,
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const QMat * wte_q, const float * wpe, int E, int n_in,
                        const int32_t * tokens_8x1024, int nn, float * x);
 
 void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats);
-// q8_0 quantisation of N <= 1024 f32 rows of length K (LayerNorm first when ln_g != nullptr): q [N][K] int8, d [N][K/32] f32,
-// dT (optional) the same scales block-major [K/32][1024]
-void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d, float * dT);
+// q8 quantisation of N <= 1024 f32 rows of length K (LayerNorm first when ln_g != nullptr)
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, const Q8Scratch & out);
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
 
 // Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.
@@ -123,7 +131,7 @@ struct SampleArgs {
     int nbatch = 1; int ld_logits = 0; int out_stride = 0;   // batched decode: slot b reads logits + b*ld_logits, writes out_tokens + b*out_stride, x + b*E
     // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
-    Q4Mat wte_q;
+    QMat wte_q;
 };
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]

@@ -84,14 +84,20 @@ DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
     return __builtin_bit_cast(half_t, lut[bits]);
 }
 
-// one element of an embedding row: f16 table, or q4_0 table dequantised as ggml_get_rows does ((nibble - 8) * d)
-DEVINL float wte_elem(const half_t * wte, const Q4Mat & q, int E, int tok, int e) {
+// one element of an embedding row: f16 table, or a quantised table dequantised as ggml_get_rows does (level * d (+ m))
+DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e) {
     if (!q.qs) return (float) wte[(size_t) tok * E + e];
     const size_t blk = (size_t) tok * (E >> 5) + (e >> 5);
     const int j = e & 31;
+    const float d = (float) q.d[blk];
+    if (q.qt == QT_Q8_0) return (float) (int) reinterpret_cast<const int8_t *>(q.qs)[blk * 32 + j] * d;
     const uint8_t byte = q.qs[blk * 16 + (j & 15)];
-    const int nib = j < 16 ? (byte & 0x0F) : (byte >> 4);
-    return (float) (nib - 8) * (float) q.d[blk];
+    int lev = j < 16 ? (byte & 0x0F) : (byte >> 4);
+    if (q.qh) lev |= (int) ((q.qh[blk] >> j) & 1u) << 4;
+    if (q.qt == QT_Q4_0) lev -= 8;
+    if (q.qt == QT_Q5_0) lev -= 16;
+    const float v = (float) lev * d;
+    return q.m ? v + (float) q.m[blk] : v;
 }
 
 // K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
@@ -563,46 +569,63 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Q4_0 weights (BASELINE config 4; ggml_vec_dot_q4_0_q8_0 as restated by the oracle's C1q order).
-// The activation row is quantised to q8_0 blocks of 32 (d = amax / 127, q = roundf(x / d), d stored
-// as f16), every block product is an exact integer sum scaled as ((float) sumi * d4) * d8, block b
-// belongs to chain b mod 16, chains are plain float adds in ascending block order and meet in the
-// C1 tree.  One wave = 4 output rows x 16 lanes, lane c = chain c: a lane only ever touches the
-// blocks c, c + 16, ... of both operands, so quantisation and the integer dot product are lane-local
-// (v_dot4_i32_i8); nothing goes through LDS.
+// Quantised weights (ggml block formats q4_0 - BASELINE config 4 - q4_1, q5_0, q5_1, q8_0; quant_formats.h), computed as
+// ggml's vec_dot_q*_q8_* restated by the oracle's C1q order: the activation row is quantised to q8 blocks of 32
+// (d = amax / 127, q = roundf(x / d), d stored as f16, s = f16(d * sum q) for the formats with a minimum), every block
+// product is an exact integer sum, scaled per format (block_term), block b belongs to chain b mod 16, chains are plain float
+// adds in ascending block order and meet in the C1 tree.  Weight levels are widened to int8 in registers (unpack_raw) so that
+// one code path - v_dot4_i32_i8 for decode, v_mfma_i32_32x32x32_i8 for rows - serves all five formats.
 // ------------------------------------------------------------------------------------------------
-struct Q8Block { int q[8]; float d; };      // 32 int8 values (element 4 i + j in byte j of q[i]) and the f16-rounded scale
-
-DEVINL Q8Block quantize_q8_block(const float (&v)[32]) {
-    float amax = 0.0f;
-    #pragma unroll
-    for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
-    const float d = amax / 127.0f;
-    const float id = d != 0.0f ? 1.0f / d : 0.0f;
-    Q8Block o;
-    #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        unsigned w = 0;
-        #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float t = v[4 * i + j] * id;
-            const int qi = (int) __builtin_roundf(t);                // round half away from zero, as roundf on the host
-            w |= ((unsigned) qi & 0xFFu) << (8 * j);
-        }
-        o.q[i] = (int) w;
-    }
-    o.d = (float) to_half(d);
-    return o;
+template <int QT> struct QTraits {
+    static constexpr bool has_m = QT == QT_Q4_1 || QT == QT_Q5_1;
+    static constexpr bool has_h = QT == QT_Q5_0 || QT == QT_Q5_1;
+    static constexpr bool wide = QT == QT_Q8_0;                // 32 bytes of levels per block instead of 16
+};
+template <int QT> struct RawBlock { uint4 qs, qs2; unsigned qh; half_t d, m; };
+template <int QT> DEVINL RawBlock<QT> load_raw(const QMat & q, size_t idx) {
+    RawBlock<QT> r;
+    if constexpr (QTraits<QT>::wide) { const uint4 * p = reinterpret_cast<const uint4 *>(q.qs) + 2 * idx; r.qs = p[0]; r.qs2 = p[1]; }
+    else r.qs = reinterpret_cast<const uint4 *>(q.qs)[idx];
+    if constexpr (QTraits<QT>::has_h) r.qh = q.qh[idx];
+    r.d = q.d[idx];
+    if constexpr (QTraits<QT>::has_m) r.m = q.m[idx];
+    return r;
 }
-// nibbles of one q4_0 block -> eight dwords of int8 values (n - 8): dwords 0..3 = elements 0..15, 4..7 = elements 16..31
-DEVINL void unpack_q4_block(const uint4 w, int (&o)[8]) {
-    const unsigned r[4] = {w.x, w.y, w.z, w.w};
+// four bits b3 b2 b1 b0 -> bit 4 of bytes 3..0
+DEVINL unsigned spread_fifth_bits(unsigned b) { return ((b * 0x00204081u) & 0x01010101u) << 4; }
+// per-byte v - k for bytes v < 128, k < 128, without borrows between bytes: set bit 7, subtract, flip bit 7 back
+DEVINL int bytes_minus(unsigned v, unsigned k4) { return (int) (((v | 0x80808080u) - k4) ^ 0x80808080u); }
+// half == 0: elements 0..15 of the block, half == 1: elements 16..31, as four dwords of int8 levels
+template <int QT> DEVINL void unpack_half(const RawBlock<QT> & r, int half, int (&o)[4]) {
+    if constexpr (QTraits<QT>::wide) {
+        const uint4 v = half ? r.qs2 : r.qs;
+        o[0] = (int) v.x; o[1] = (int) v.y; o[2] = (int) v.z; o[3] = (int) v.w;
+    } else {
+        const unsigned w[4] = {r.qs.x, r.qs.y, r.qs.z, r.qs.w};
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned v = (w[i] >> (4 * half)) & 0x0F0F0F0Fu;
+            if constexpr (QTraits<QT>::has_h) v |= spread_fifth_bits((r.qh >> (16 * half + 4 * i)) & 0xFu);
+            if constexpr (QT == QT_Q4_0) o[i] = bytes_minus(v, 0x08080808u);
+            else if constexpr (QT == QT_Q5_0) o[i] = bytes_minus(v, 0x10101010u);
+            else o[i] = (int) v;
+        }
+    }
+}
+template <int QT> DEVINL void unpack_raw(const RawBlock<QT> & r, int (&o)[8]) {
+    int lo[4], hi[4];
+    unpack_half<QT>(r, 0, lo); unpack_half<QT>(r, 1, hi);
     #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned lo = r[i] & 0x0F0F0F0Fu, hi = (r[i] >> 4) & 0x0F0F0F0Fu;
-        // per-byte (n - 8) without borrows: set bit 7, subtract 8, flip bit 7 back
-        o[i]     = (int) (((lo | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
-        o[4 + i] = (int) (((hi | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
+    for (int i = 0; i < 4; i++) { o[i] = lo[i]; o[4 + i] = hi[i]; }
+}
+// ggml's per-block scaling (oracle: dot_q_q8)
+template <int QT> DEVINL float block_term(int sumi, float dw, float mw, float dx, float sx) {
+    if constexpr (QT == QT_Q4_0) return ((float) sumi * dw) * dx;
+    else {
+        const float dd = dw * dx;
+        float t = dd * (float) sumi;
+        if constexpr (QTraits<QT>::has_m) { const float ms = mw * sx; t = t + ms; }
+        return t;
     }
 }
 DEVINL int dot_q4_q8(const int (&w)[8], const int (&q)[8]) {
@@ -611,19 +634,35 @@ DEVINL int dot_q4_q8(const int (&w)[8], const int (&q)[8]) {
     for (int i = 0; i < 8; i++) s = __builtin_amdgcn_sdot4(w[i], q[i], s, false);
     return s;
 }
+// NV f32 values -> NV/4 dwords of int8 levels q = roundf(v * id); returns sum q
+template <int NV> DEVINL int quantize_levels(const float (&v)[NV], float id, int (&q)[NV / 4]) {
+    int sum = 0;
+    #pragma unroll
+    for (int i = 0; i < NV / 4; i++) {
+        unsigned w = 0;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int qi = (int) __builtin_roundf(v[4 * i + j] * id);       // round half away from zero, as roundf on the host
+            sum += qi;
+            w |= ((unsigned) qi & 0xFFu) << (8 * j);
+        }
+        q[i] = (int) w;
+    }
+    return sum;
+}
 
 // decode (N = 1): x is an f32 row, optionally LayerNorm-ed first.  A 256-thread workgroup owns 16 output rows:
-//   1. every lane requests the weight blocks of its chain (up to 8 x 18 bytes) before anything else,
-//   2. the q8_0 quantisation of x (~8 VALU ops per element) is spread over the workgroup - two threads per block of 32,
-//      block maximum through one DPP exchange - and published in LDS once for the 16 rows,
+//   1. every lane requests the weight blocks of its chain (up to 8) before anything else,
+//   2. the q8 quantisation of x (~8 VALU ops per element) is spread over the workgroup - two threads per block of 32,
+//      block maximum / level sum through one DPP exchange - and published in LDS once for the 16 rows,
 //   3. wave w dots rows 4 w .. 4 w + 3: lane c of a row walks the blocks c, c + 16, ... (chain c of C1q).
 // The first version quantised inside every 16-lane group (each lane its own blocks): 1500 VALU instructions per wave
-// for K = 3072, 8.0 us per launch; this one measures about half of that.
-template <bool LN, bool LNB>
-__global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
+// for K = 3072, 8.0 us per launch; this one measures about half of that (quantised files).
+template <int QT, bool LN, bool LNB>
+__global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
     constexpr int MAXB = 8;                                    // blocks per chain: K <= 4096
-    __shared__ int4 xq[128][2];                                // q8 values of block b: elements 0..15 and 16..31
-    __shared__ float xd[128];
+    __shared__ int4 xq[128][2];                                // q8 levels of block b: elements 0..15 and 16..31
+    __shared__ float xd[128], xs[128];
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
@@ -632,17 +671,15 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;
     const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
-    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + wrow;
-    const half_t * wd = a.wq.d + wrow;
-    uint4 wv[MAXB]; half_t wdv[MAXB];
+    RawBlock<QT> wb[MAXB];
     #pragma unroll
     for (int i = 0; i < MAXB; i++) {
         const int b = c + 16 * i;
-        if (b < nblk) { wv[i] = wq[b]; wdv[i] = wd[b]; }
+        if (b < nblk) wb[i] = load_raw<QT>(a.wq, wrow + b);
     }
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
 
-    // ---- x -> q8_0: thread t quantises elements [16 (t & 1), +16) of block t >> 1
+    // ---- x -> q8: thread t quantises elements [16 (t & 1), +16) of block t >> 1
     const int qb = tid >> 1, qh = tid & 1;
     const bool mine = qb < nblk;
     const int k0 = mine ? (qb << 5) + (qh << 4) : 0;
@@ -697,19 +734,11 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
         const float d = amax / 127.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
         int q[4];
-        #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            unsigned w = 0;
-            #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int qi = (int) __builtin_roundf(v[4 * i + j] * id);       // round half away from zero, as roundf on the host
-                w |= ((unsigned) qi & 0xFFu) << (8 * j);
-            }
-            q[i] = (int) w;
-        }
+        int sum = quantize_levels<16>(v, id, q);
+        sum += __builtin_amdgcn_update_dpp(0, sum, DPP_XOR1, 0xF, 0xF, false);
         if (mine) {
             xq[qb][qh] = make_int4(q[0], q[1], q[2], q[3]);
-            if (qh == 0) xd[qb] = (float) to_half(d);
+            if (qh == 0) { xd[qb] = (float) to_half(d); xs[qb] = (float) to_half((float) sum * d); }
         }
     }
     __syncthreads();
@@ -721,9 +750,9 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
         if (b < nblk) {
             const int4 q0 = xq[b][0], q1 = xq[b][1];
             const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            int w[8]; unpack_q4_block(wv[i], w);
+            int w[8]; unpack_raw<QT>(wb[i], w);
             const int sumi = dot_q4_q8(w, q);
-            const float tb = ((float) sumi * (float) wdv[i]) * xd[b];
+            const float tb = block_term<QT>(sumi, (float) wb[i].d, QTraits<QT>::has_m ? (float) wb[i].m : 0.0f, xd[b], xs[b]);
             acc = acc + tb;
         }
     }
@@ -731,8 +760,8 @@ __global__ __launch_bounds__(256) void gemv_q4_kernel(const LinArgs a) {
     if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
 }
 
-// rows (N > 1): q8_0 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
-struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; float * dT; };
+// rows (N > 1): q8 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
+struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; float * dT; float * s; float * sT; };
 __global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
     const int lane = threadIdx.x, n = blockIdx.x;
     const int K = a.K, nblk = K >> 5;
@@ -763,21 +792,30 @@ __global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
                 v[j] = u;
             }
         }
-        const Q8Block xq = quantize_q8_block(v);
+        float amax = 0.0f;
+        #pragma unroll
+        for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        int q[8];
+        const int sum = quantize_levels<32>(v, id, q);
         int4 * qp = reinterpret_cast<int4 *>(a.q + (size_t) n * K + (b << 5));
-        qp[0] = make_int4(xq.q[0], xq.q[1], xq.q[2], xq.q[3]);
-        qp[1] = make_int4(xq.q[4], xq.q[5], xq.q[6], xq.q[7]);
-        a.d[(size_t) n * nblk + b] = xq.d;
-        if (a.dT) a.dT[(size_t) b * 1024 + n] = xq.d;          // block-major copy for the MFMA kernel ([K/32][1024])
+        qp[0] = make_int4(q[0], q[1], q[2], q[3]);
+        qp[1] = make_int4(q[4], q[5], q[6], q[7]);
+        const float dh = (float) to_half(d), sh = (float) to_half((float) sum * d);
+        a.d[(size_t) n * nblk + b] = dh;
+        a.s[(size_t) n * nblk + b] = sh;
+        // block-major copies for the MFMA kernel ([K/32][1024])
+        a.dT[(size_t) b * 1024 + n] = dh;
+        a.sT[(size_t) b * 1024 + n] = sh;
     }
 }
 
-// rows (N > 1): NB pre-quantised activation rows per wave share each unpacked weight block.
-// TODO(next round): v_mfma_i32_32x32x32_i8 holds exactly one q4_0 block per instruction; this first version keeps the
-// integer sums on v_dot4 and is bound by L2 re-reads of the weights.
-struct Q4RowsArgs { LinArgs lin; const int8_t * q; const float * d; const float * dT; };
-template <int NB>
-__global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
+// rows (N > 1), v_dot4 version: NB pre-quantised activation rows per wave share each unpacked weight block.  Kept as the
+// cross-check path of the MFMA kernel (BARK_HIP_Q4_ROWS); bound by L2 re-reads of the weights.
+struct QRowsArgs { LinArgs lin; const int8_t * q; const float * d, * dT, * s, * sT; };
+template <int QT, int NB>
+__global__ __launch_bounds__(64) void gemm_q_rows_kernel(const QRowsArgs qa) {
     const LinArgs & a = qa.lin;
     const int lane = threadIdx.x;
     const int c = lane & 15, rg = lane >> 4;
@@ -786,14 +824,13 @@ __global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
     const int K = a.K, nblk = K >> 5;
     const bool live = m < a.M;
     const size_t wrow = (size_t) (live ? m : 0) * nblk;
-    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + wrow;
-    const half_t * wd = a.wq.d + wrow;
     float acc[NB];
     #pragma unroll
     for (int i = 0; i < NB; i++) acc[i] = 0.0f;
     for (int b = c; b < nblk; b += 16) {
-        int w[8]; unpack_q4_block(wq[b], w);
-        const float d4 = (float) wd[b];
+        const RawBlock<QT> wb = load_raw<QT>(a.wq, wrow + b);
+        int w[8]; unpack_raw<QT>(wb, w);
+        const float dw = (float) wb.d, mw = QTraits<QT>::has_m ? (float) wb.m : 0.0f;
         #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int n = min(n0 + i, a.N - 1);
@@ -801,7 +838,7 @@ __global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
             const int4 q0 = qp[0], q1 = qp[1];
             const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
             const int sumi = dot_q4_q8(w, q);
-            const float tb = ((float) sumi * d4) * qa.d[(size_t) n * nblk + b];
+            const float tb = block_term<QT>(sumi, dw, mw, qa.d[(size_t) n * nblk + b], QTraits<QT>::has_m ? qa.s[(size_t) n * nblk + b] : 0.0f);
             acc[i] = acc[i] + tb;
         }
     }
@@ -812,17 +849,18 @@ __global__ __launch_bounds__(64) void gemm_q4_rows_kernel(const Q4RowsArgs qa) {
     }
 }
 
-// rows (N > 1) on the matrix cores: v_mfma_i32_32x32x32_i8 multiplies exactly one q4_0 block (32 weights of 32 output rows,
-// nibbles widened to int8) by one q8_0 block of 32 activation rows - the int32 results are the exact block sums of C1q.
+// rows (N > 1) on the matrix cores: v_mfma_i32_32x32x32_i8 multiplies exactly one weight block (32 levels of 32 output rows,
+// widened to int8) by one q8 block of 32 activation rows - the int32 results are the exact block sums of C1q.
 // Workgroup tile: 64 activation rows x 32 output rows, 8 waves; wave w owns the chains 2 w and 2 w + 1 (blocks 2 w + 16 i
-// and 2 w + 1 + 16 i, ascending), scales every block sum as ((float) sumi * d4) * d8 and adds it to the chain in f32.
-// The weight scale d4 is per lane (the lane's output row), the 16 activation scales of a lane's accumulator rows come
-// from the block-major copy of d8 as four float4 loads.  Chains 2 w and 2 w + 1 meet in registers (tree level xor 1),
+// and 2 w + 1 + 16 i, ascending), scales every block sum per format (block_term) and adds it to the chain in f32.
+// The weight scale (and minimum) is per lane (the lane's output row), the 16 activation scales of a lane's accumulator rows
+// come from the block-major copies of d8 / s8 as float4 loads.  Chains 2 w and 2 w + 1 meet in registers (tree level xor 1),
 // the eight pair sums of an output in LDS (levels xor 2, 4, 8).
 constexpr int Q4G_TM = 32, Q4G_TN = 64, Q4G_LD = 33;
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef int intx16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(512) void gemm_q4_mfma_kernel(const Q4RowsArgs qa) {
+template <int QT>
+__global__ __launch_bounds__(512) void gemm_q_mfma_kernel(const QRowsArgs qa) {
     extern __shared__ float q4g_red[];                         // [8 chain pairs][64 activation rows][33]
     const LinArgs & a = qa.lin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -830,14 +868,14 @@ __global__ __launch_bounds__(512) void gemm_q4_mfma_kernel(const Q4RowsArgs qa) 
     const int K = a.K, nblk = K >> 5;
     const int li = lane & 31, kh = lane >> 5;
     const int m = min(m0 + li, a.M - 1);
-    const uint4 * wq = reinterpret_cast<const uint4 *>(a.wq.qs) + (size_t) m * nblk;
-    const half_t * wd = a.wq.d + (size_t) m * nblk;
-    const int8_t * xq[2]; const float * xdT[2];
+    const size_t wrow = (size_t) m * nblk;
+    const int8_t * xq[2]; const float * xdT[2], * xsT[2];
     #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
         const int n = min(n0 + 32 * nt + li, a.N - 1);
         xq[nt] = qa.q + (size_t) n * K + 16 * kh;
         xdT[nt] = qa.dT + n0 + 32 * nt + 4 * kh;                 // accumulator register r <-> activation row (r & 3) + 8 (r >> 2) + 4 kh
+        xsT[nt] = qa.sT + n0 + 32 * nt + 4 * kh;
     }
     floatx16 acc[2][2];
     #pragma unroll
@@ -852,33 +890,36 @@ __global__ __launch_bounds__(512) void gemm_q4_mfma_kernel(const Q4RowsArgs qa) 
         for (int ch = 0; ch < 2; ch++) {
             const int b = b0 + ch;
             if (b < nblk) {                                    // wave-uniform
-                const uint4 w = wq[b];
-                const float d4 = (float) wd[b];
-                intx4 xa[2]; float4 d8[2][4];
+                const RawBlock<QT> wb = load_raw<QT>(a.wq, wrow + b);
+                intx4 xa[2]; float4 d8[2][4], s8[2][4];
                 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
                     xa[nt] = *reinterpret_cast<const intx4 *>(xq[nt] + (b << 5));
                     #pragma unroll
-                    for (int g = 0; g < 4; g++) d8[nt][g] = *reinterpret_cast<const float4 *>(xdT[nt] + (size_t) b * 1024 + 8 * g);
+                    for (int g = 0; g < 4; g++) {
+                        d8[nt][g] = *reinterpret_cast<const float4 *>(xdT[nt] + (size_t) b * 1024 + 8 * g);
+                        if constexpr (QTraits<QT>::has_m) s8[nt][g] = *reinterpret_cast<const float4 *>(xsT[nt] + (size_t) b * 1024 + 8 * g);
+                    }
                 }
-                // lanes 0..31 carry elements 0..15 of the block (low nibbles), lanes 32..63 elements 16..31 (high nibbles)
-                const unsigned wr[4] = {w.x, w.y, w.z, w.w};
+                // lanes 0..31 carry elements 0..15 of the block, lanes 32..63 elements 16..31
+                int wlo[4], whi[4];
+                unpack_half<QT>(wb, 0, wlo); unpack_half<QT>(wb, 1, whi);
                 intx4 wv;
                 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const unsigned nib = (wr[i] >> (4 * kh)) & 0x0F0F0F0Fu;
-                    wv[i] = (int) (((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u);
-                }
+                for (int i = 0; i < 4; i++) wv[i] = kh ? whi[i] : wlo[i];
+                const float dw = (float) wb.d, mw = QTraits<QT>::has_m ? (float) wb.m : 0.0f;
                 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
                     const intx16 si = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[nt], wv, zero, 0, 0, 0);
                     #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const float dd[4] = {d8[nt][g].x, d8[nt][g].y, d8[nt][g].z, d8[nt][g].w};
+                        float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if constexpr (QTraits<QT>::has_m) { ss[0] = s8[nt][g].x; ss[1] = s8[nt][g].y; ss[2] = s8[nt][g].z; ss[3] = s8[nt][g].w; }
                         #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const int r = 4 * g + j;
-                            const float tb = ((float) si[r] * d4) * dd[j];
+                            const float tb = block_term<QT>(si[r], dw, mw, dd[j], ss[j]);
                             acc[ch][nt][r] = acc[ch][nt][r] + tb;
                         }
                     }
@@ -908,41 +949,56 @@ __global__ __launch_bounds__(512) void gemm_q4_mfma_kernel(const Q4RowsArgs qa) 
     }
 }
 
-void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, int8_t * q, float * d, float * dT) {
-    if (N > 1024) { fprintf(stderr, "bark-hip: q8_0 row quantisation handles at most 1024 rows\n"); abort(); }
-    Q8RowsArgs a{x, N, K, ln_g, ln_b, q, d, dT};
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, const Q8Scratch & o) {
+    if (N > 1024) { fprintf(stderr, "bark-hip: q8 row quantisation handles at most 1024 rows\n"); abort(); }
+    Q8RowsArgs a{x, N, K, ln_g, ln_b, o.q, o.d, o.dT, o.s, o.sT};
     hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
 }
 
-static void launch_linear_q4(hipStream_t s, const LinArgs & a) {
-    if ((a.K & 31) != 0) { fprintf(stderr, "bark-hip: q4_0 rows must be a multiple of 32 long\n"); abort(); }
-    if (a.batched) { fprintf(stderr, "bark-hip: the lock-step batched decode has no q4_0 kernels yet\n"); abort(); }
+template <int QT>
+static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
     if (a.N == 1) {
-        if (!a.x_f32) { fprintf(stderr, "bark-hip: q4_0 GEMV needs an f32 activation row\n"); abort(); }
-        if (a.K > 4096) { fprintf(stderr, "bark-hip: q4_0 GEMV supports K <= 4096\n"); abort(); }
         dim3 grid((a.M + 15) / 16), block(256);
         if (a.ln_g) {
-            if (a.ln_b) hipLaunchKernelGGL((gemv_q4_kernel<true, true>), grid, block, 0, s, a);
-            else        hipLaunchKernelGGL((gemv_q4_kernel<true, false>), grid, block, 0, s, a);
-        } else hipLaunchKernelGGL((gemv_q4_kernel<false, false>), grid, block, 0, s, a);
+            if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_q_kernel<QT, true, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((gemv_q_kernel<QT, false, false>), grid, block, 0, s, a);
         return;
     }
-    if (!a.xq8 || !a.xd8 || a.parity_rows) { fprintf(stderr, "bark-hip: q4_0 row product needs pre-quantised rows\n"); abort(); }
-    static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, kept as the cross-check path
-    if (a.xd8T && !force_rows) {
-        Q4RowsArgs qa{a, a.xq8, a.xd8, a.xd8T};
+    static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, the cross-check path
+    const QRowsArgs qa{a, a.xq.q, a.xq.d, a.xq.dT, a.xq.s, a.xq.sT};
+    if (!force_rows) {
+        static const bool attr = [] {
+            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
+            return true;
+        }();
+        (void) attr;
         dim3 grid((a.M + Q4G_TM - 1) / Q4G_TM, (a.N + Q4G_TN - 1) / Q4G_TN), block(512);
-        hipLaunchKernelGGL(gemm_q4_mfma_kernel, grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
+        hipLaunchKernelGGL((gemm_q_mfma_kernel<QT>), grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
         return;
     }
     constexpr int NB = 8;
-    Q4RowsArgs qa{a, a.xq8, a.xd8, nullptr};
     dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
-    hipLaunchKernelGGL((gemm_q4_rows_kernel<NB>), grid, block, 0, s, qa);
+    hipLaunchKernelGGL((gemm_q_rows_kernel<QT, NB>), grid, block, 0, s, qa);
+}
+static void launch_linear_q(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 31) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: quantised rows must be a multiple of 32 and at most 4096 long\n"); abort(); }
+    if (a.batched) { fprintf(stderr, "bark-hip: the lock-step batched decode has no kernels for quantised weights yet\n"); abort(); }
+    if (a.N == 1 && !a.x_f32) { fprintf(stderr, "bark-hip: quantised GEMV needs an f32 activation row\n"); abort(); }
+    if (a.N > 1 && (!a.xq.q || a.parity_rows)) { fprintf(stderr, "bark-hip: quantised row product needs pre-quantised rows\n"); abort(); }
+    switch (a.wq.qt) {
+        case QT_Q4_0: launch_linear_qt<QT_Q4_0>(s, a); break;
+        case QT_Q4_1: launch_linear_qt<QT_Q4_1>(s, a); break;
+        case QT_Q5_0: launch_linear_qt<QT_Q5_0>(s, a); break;
+        case QT_Q5_1: launch_linear_qt<QT_Q5_1>(s, a); break;
+        case QT_Q8_0: launch_linear_qt<QT_Q8_0>(s, a); break;
+        default: fprintf(stderr, "bark-hip: unknown weight block format %d\n", a.wq.qt); abort();
+    }
 }
 
 void launch_linear(hipStream_t s, const LinArgs & a) {
-    if (a.wq.qs) { launch_linear_q4(s, a); return; }
+    if (a.wq.qs) { launch_linear_q(s, a); return; }
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
     if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
     const int nblk = a.K >> 7;
@@ -1011,7 +1067,7 @@ void launch_embed_causal(hipStream_t s, const EmbedArgs & a) {
     hipLaunchKernelGGL(embed_causal_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
 }
 
-struct FineEmbedArgs { const half_t * wte[8]; Q4Mat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
+struct FineEmbedArgs { const half_t * wte[8]; QMat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
 __global__ void embed_fine_kernel(const FineEmbedArgs a) {
     const int i = blockIdx.x;
     float * out = a.x + (size_t) i * a.E;
@@ -1026,7 +1082,7 @@ __global__ void embed_fine_kernel(const FineEmbedArgs a) {
         out[e] = v + pe[e];
     }
 }
-void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const Q4Mat * wte_q, const float * wpe, int E, int n_in,
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const QMat * wte_q, const float * wpe, int E, int n_in,
                        const int32_t * tokens_8x1024, int nn, float * x) {
     FineEmbedArgs a; for (int i = 0; i < 8; i++) { a.wte[i] = wte[i]; a.wte_q[i] = wte_q[i]; }
     a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens_8x1024; a.nn = nn; a.x = x;
@@ -1939,8 +1995,6 @@ void init_kernel_attributes() {
                                32 * ATT_LD * (int) sizeof(float));
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
 }
 
 }  // namespace barkhip

@@ -48,16 +48,25 @@ def mini_oracle(mini_model):
     o.close()
 
 
-def _quantized(src: str) -> str:
-    """bark_model_quantize (native writer, no GPU needed) -> <src>_q4_0.bin next to the f16 file, made once."""
-    dst = src[:-4] + "_q4_0.bin"
+GGML_FTYPE = {"q4_0": 2, "q4_1": 3, "q8_0": 7, "q5_0": 8, "q5_1": 9}     # enum ggml_ftype (include/ggml.h)
+
+
+def _quantized(src: str, fmt: str = "q4_0") -> str:
+    """bark_model_quantize (native writer, no GPU needed) -> <src>_<fmt>.bin next to the f16 file, made once."""
+    dst = src[:-4] + "_%s.bin" % fmt
     if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
         from bark_amd_loader import load_package
         lib = load_package().load_library()
         tmp = dst + ".tmp%d" % os.getpid()
-        assert lib.bark_model_quantize(src.encode(), tmp.encode(), 2)          # GGML_FTYPE_MOSTLY_Q4_0
+        assert lib.bark_model_quantize(src.encode(), tmp.encode(), GGML_FTYPE[fmt])
         os.replace(tmp, dst)
     return dst
+
+
+@pytest.fixture(scope="session")
+def quantized_model():
+    """factory: quantized_model(path_of_f16_file, "q5_1") -> path of the quantised file"""
+    return _quantized
 
 
 @pytest.fixture(scope="session")
