@@ -91,3 +91,22 @@ def test_reference_example_main_compiles_and_links_unmodified(pkg, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     h = subprocess.run([str(exe), "-h"], capture_output=True, text=True)
     assert "usage" in (h.stdout + h.stderr).lower()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "examples", "quantize")), reason="reference checkout not present")
+def test_reference_example_quantize_runs_unmodified(pkg, toy_model, tmp_path):
+    """examples/quantize/main.cpp drives bark_model_quantize (bark.h:229-232); all five of its types must be written."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "quantize"
+    cmd = [hipcc, "-std=c++17", "-O1", "-I", INC, os.path.join(REF, "examples", "quantize", "main.cpp"),
+           "-L", os.path.dirname(pkg.library_path()), "-lbark", "-Wl,-rpath," + os.path.dirname(pkg.library_path()), "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    from tests.test_quantize import FORMATS, parse_quantized
+    for fmt, (ftype, ttype, _) in FORMATS.items():
+        dst = tmp_path / f"toy_{fmt}.bin"
+        q = subprocess.run([str(exe), toy_model, str(dst), fmt], capture_output=True, text=True)
+        assert q.returncode == 0, q.stderr[-2000:]
+        secs, _ = parse_quantized(str(dst))
+        assert secs[0][0][9] == 2000 + ftype
+        assert secs[2][1]["model/h0/mlp/c_fc/w"][0] == ttype
