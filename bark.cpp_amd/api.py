@@ -260,7 +260,7 @@ class BarkContext:
 
     def fine(self, coarse_Tx2) -> np.ndarray:
         co = _i32(coarse_Tx2).reshape(-1, 2)
-        out = np.zeros((1024, 8), np.int32)
+        out = np.zeros((max(len(co), 1), 8), np.int32)
         T = self._lib.bark_hip_fine(self._h, co.ctypes.data, len(co), out.ctypes.data)
         if T < 0:
             raise RuntimeError("bark_hip_fine failed")
@@ -300,7 +300,7 @@ class BarkContext:
                 continue
             d = {"pcm": np.ctypeslib.as_array(p, shape=(ns,)).copy() if ns else np.zeros(0, np.float32)}
             for stage, (name, w) in enumerate((("semantic", 1), ("coarse", 2), ("fine", 8))):
-                buf = np.zeros(8192, np.int32)
+                buf = np.zeros(32768, np.int32)
                 k = self._lib.bark_hip_batch_tokens(self._h, i, stage, buf.ctypes.data, buf.size)
                 d[name] = buf[:max(k, 0)].copy().reshape(-1, w) if w > 1 else buf[:max(k, 0)].copy()
             out.append(d)
@@ -327,13 +327,13 @@ class BarkContext:
         return out[:max(n, 0)].copy()
 
     def coarse_tokens(self) -> np.ndarray:
-        out = np.zeros((2048, 2), np.int32)
-        n = self._lib.bark_hip_get_coarse_tokens(self._h, out.ctypes.data, 2048)
+        out = np.zeros((4096, 2), np.int32)
+        n = self._lib.bark_hip_get_coarse_tokens(self._h, out.ctypes.data, 4096)
         return out[:max(n, 0)].copy()
 
     def fine_tokens(self) -> np.ndarray:
-        out = np.zeros((1024, 8), np.int32)
-        n = self._lib.bark_hip_get_fine_tokens(self._h, out.ctypes.data, 1024)
+        out = np.zeros((4096, 8), np.int32)
+        n = self._lib.bark_hip_get_fine_tokens(self._h, out.ctypes.data, 4096)
         return out[:max(n, 0)].copy()
 
     def stats(self) -> dict:

@@ -912,8 +912,8 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// fine stage: bark_eval_fine_encoder (bark.cpp:1961-2059).  T > 1024 is rejected: the reference's
-// windowing is undefined there.
+// fine stage: bark_eval_fine_encoder (bark.cpp:1961-2059).  T > 1024: sliding windows of 1024 frames with a hop of 512,
+// as in the algorithm the reference was ported from (its own indexing is undefined there).
 // ---------------------------------------------------------------------------------------------------
 std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & coarse) {
     HIP_OK(hipSetDevice(c->device));
@@ -922,65 +922,82 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
     const int nc = p.n_coarse_codebooks, nf = p.n_fine_codebooks, cs = p.codebook_size;
     if (nc != 2 || nf != 8 || cs != 1024) throw std::runtime_error("fine: only 2 -> 8 codebooks of 1024 entries are supported");
     const int T = (int) coarse.size() / nc;
-    if (T <= 0 || T > 1024) throw std::runtime_error("fine: number of frames must be in 1..1024");
+    if (T <= 0 || T > 8192) throw std::runtime_error("fine: number of frames must be in 1..8192");
     for (int32_t v : coarse) if (v < 0 || v >= cs) throw std::runtime_error("fine: coarse code out of range");
-    // codebook-major window [8][1024]: coarse rows, channels 2..7 and the time padding filled with `cs` (bark.cpp:1983-2013)
-    std::vector<int32_t> buf((size_t) 8 * 1024, cs);
-    for (int t = 0; t < T; t++) for (int ch = 0; ch < nc; ch++) buf[(size_t) ch * 1024 + t] = coarse[(size_t) t * nc + ch];
-    upload_tokens(c, buf.data(), buf.size());
+    // in_arr [L][8]: coarse rows, channels 2..7 and the time padding filled with `cs` (bark.cpp:1983-1996)
+    const int L = std::max(T, 1024);
+    std::vector<int32_t> in_arr((size_t) L * 8, cs);
+    for (int t = 0; t < T; t++) for (int ch = 0; ch < nc; ch++) in_arr[(size_t) t * 8 + ch] = coarse[(size_t) t * nc + ch];
+    const int n_loops = std::max(0, (int) ceilf((float) (L - 1024) / 512.f)) + 1;          // bark.cpp:1998
     const bool greedy = p.fine_temp == 0.0f;
     const bool device_multinomial = !greedy && !c->host_sampling;
-    if (device_multinomial) upload_uniforms(c, (nf - nc) * 1024);
     StepState st = fresh_state();
     set_state(c, st);
-    // one window (T <= 1024  =>  n_loops == 1, start_idx == 0, rel_start_fill_idx == 0)
-    for (int nn = nc; nn < nf; nn++) {
-        progress(c, FINE, 100 * (nn - nc + 1) / (nf - nc));
-        if (greedy || device_multinomial) {
-            // one pass = embed -> 12 layers -> head -> per-row pick, captured once per codebook as a hipGraph
-            auto enqueue = [&] {
-                run_fine_forward(c, nn, cs);               // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
-                if (greedy) launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, c->d_tokens + (size_t) nn * 1024, 1, c->d_state);
-                else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024,
-                                                    c->d_tokens + (size_t) nn * 1024, 1);
-            };
-            if (c->use_graph) {
-                hipGraphExec_t & g = c->fine_graphs[nn];
-                if (!g) {
-                    hipGraph_t graph = nullptr;
-                    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                    try { enqueue(); }
-                    catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
-                    HIP_OK(hipStreamEndCapture(c->stream, &graph));
-                    HIP_OK(hipGraphInstantiate(&g, graph, nullptr, nullptr, 0));
-                    (void) hipGraphDestroy(graph);
+    std::vector<int32_t> buf((size_t) 8 * 1024);
+    for (int n = 0; n < n_loops; n++) {
+        // window n (bark.cpp:2002-2013).  T <= 1024: one window, start_idx == 0, rel == 0.  For longer inputs the reference
+        // stores its samples at [rel + i] and runs out of the buffer (undefined behaviour); this engine and
+        // the oracle implement the algorithm it was ported from (suno-ai/bark generate_fine): all 1024 positions are sampled
+        // (the random stream advances as in the reference) and positions >= rel keep their sample.
+        const int start_idx = std::min(n * 512, L - 1024);
+        const int start_fill_idx = std::min(n * 512, L - 512);
+        const int rel = start_fill_idx - start_idx;
+        for (int ch = 0; ch < 8; ch++) for (int j = 0; j < 1024; j++) buf[(size_t) ch * 1024 + j] = in_arr[(size_t) (start_idx + j) * 8 + ch];
+        upload_tokens(c, buf.data(), buf.size());
+        if (device_multinomial) upload_uniforms(c, (nf - nc) * 1024);
+        for (int nn = nc; nn < nf; nn++) {
+            progress(c, FINE, 100 * (n * (nf - nc) + (nn - nc + 1)) / (n_loops * (nf - nc)));
+            // rel > 0 (only the last windows of a long input): picks go to a scratch row, then positions >= rel are copied in
+            int32_t * pick_dst = rel == 0 ? c->d_tokens + (size_t) nn * 1024 : c->d_out_tokens;
+            if (greedy || device_multinomial) {
+                // one pass = embed -> 12 layers -> head -> per-row pick, captured once per codebook as a hipGraph
+                auto enqueue = [&] {
+                    run_fine_forward(c, nn, cs);               // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
+                    if (greedy) launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, pick_dst, 1, c->d_state);
+                    else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024, pick_dst, 1);
+                };
+                if (c->use_graph && rel == 0) {
+                    hipGraphExec_t & g = c->fine_graphs[nn];
+                    if (!g) {
+                        hipGraph_t graph = nullptr;
+                        HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                        try { enqueue(); }
+                        catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+                        HIP_OK(hipStreamEndCapture(c->stream, &graph));
+                        HIP_OK(hipGraphInstantiate(&g, graph, nullptr, nullptr, 0));
+                        (void) hipGraphDestroy(graph);
+                    }
+                    HIP_OK(hipGraphLaunch(g, c->stream));
+                    c->stats.graph_replays++;
+                } else {
+                    enqueue();
                 }
-                HIP_OK(hipGraphLaunch(g, c->stream));
-                c->stats.graph_replays++;
+                if (rel > 0)
+                    HIP_OK(hipMemcpyAsync(c->d_tokens + (size_t) nn * 1024 + rel, c->d_out_tokens + rel, (size_t) (1024 - rel) * 4, hipMemcpyDeviceToDevice, c->stream));
             } else {
-                enqueue();
+                const int n_out = m.hp.n_out_vocab;
+                run_fine_forward(c, nn, n_out);
+                std::vector<float> l = fetch_logits(c, (size_t) 1024 * n_out);
+                std::vector<int32_t> ch(1024);
+                for (int i = 0; i < 1024; i++) {
+                    std::vector<float> relv(l.begin() + (size_t) i * n_out, l.begin() + (size_t) i * n_out + cs);
+                    ch[(size_t) i] = sample_host(relv, c->rng, p.fine_temp, nullptr);
+                }
+                HIP_OK(hipMemcpyAsync(c->d_tokens + (size_t) nn * 1024 + rel, ch.data() + rel, (size_t) (1024 - rel) * 4, hipMemcpyHostToDevice, c->stream));
+                HIP_OK(hipStreamSynchronize(c->stream));
             }
-        } else {
-            const int n_out = m.hp.n_out_vocab;
-            run_fine_forward(c, nn, n_out);
-            std::vector<float> l = fetch_logits(c, (size_t) 1024 * n_out);
-            std::vector<int32_t> ch(1024);
-            for (int i = 0; i < 1024; i++) {
-                std::vector<float> rel(l.begin() + (size_t) i * n_out, l.begin() + (size_t) i * n_out + cs);
-                ch[(size_t) i] = sample_host(rel, c->rng, p.fine_temp, nullptr);
-            }
-            HIP_OK(hipMemcpyAsync(c->d_tokens + (size_t) nn * 1024, ch.data(), 1024 * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_OK(hipStreamSynchronize(c->stream));
+            c->stats.n_sample_fine += 1024;
         }
-        c->stats.n_sample_fine += 1024;
+        if (device_multinomial) consume_uniforms(c, (nf - nc) * 1024);
+        HIP_OK(hipMemcpyAsync(buf.data(), c->d_tokens, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (int nn = nc; nn < nf; nn++)                                                     // bark.cpp:2041-2046
+            for (int j = 0; j < cs - rel; j++) in_arr[(size_t) (start_fill_idx + j) * 8 + nn] = buf[(size_t) nn * 1024 + rel + j];
     }
-    if (device_multinomial) consume_uniforms(c, (nf - nc) * 1024);
-    HIP_OK(hipMemcpyAsync(buf.data(), c->d_tokens, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
     const StepState cur = get_state(c);
     c->stats.n_near_tie += cur.near_tie;
-    std::vector<int32_t> res((size_t) T * 8);
-    for (int t = 0; t < T; t++) for (int ch = 0; ch < 8; ch++) res[(size_t) t * 8 + ch] = buf[(size_t) ch * 1024 + t];
-    return res;
+    in_arr.resize((size_t) T * 8);                                                           // strip the time padding
+    return in_arr;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -943,7 +943,7 @@ static bool fine_stage(Oracle & o, const Params & p, const std::vector<int32_t> 
     const int64_t t0 = now_us();
     const int nc = p.n_coarse_codebooks, nf = p.n_fine_codebooks, cs = p.codebook_size;
     const int T = (int) coarse.size() / nc;
-    if (T <= 0 || T > 1024 || nf != 8) return false;
+    if (T <= 0 || nf != 8) return false;
     std::vector<std::vector<int32_t>> in_arr;
     for (int i = 0; i < T; i++) {
         std::vector<int32_t> row(coarse.begin() + i * nc, coarse.begin() + (i + 1) * nc);
@@ -965,7 +965,12 @@ static bool fine_stage(Oracle & o, const Params & p, const std::vector<int32_t> 
             for (int i = 0; i < 1024; i++) {
                 std::vector<float> relevant(logits.begin() + (size_t) i * m.n_out, logits.begin() + (size_t) i * m.n_out + cs);
                 int32_t next = gpt_sample(relevant, o.rng, p.fine_temp, nullptr, m);
-                in_buffer[nn * 1024 + rel + i] = next;
+                // The reference stores at [rel + i] (bark.cpp:2037), which for T > 1024 (rel > 0) runs into the next codebook's
+                // row and past the end of the buffer (undefined behaviour).  Restated as the algorithm it was
+                // ported from (suno-ai/bark generation.py, generate_fine: in_buffer[rel:, nn] = preds[rel:]): every position is
+                // sampled - the random stream advances exactly as in the reference - and positions >= rel keep their sample.
+                // For T <= 1024 (rel == 0) both readings coincide.
+                if (i >= rel) in_buffer[nn * 1024 + i] = next;
             }
         }
         for (int nn = nc; nn < nf; nn++) for (int j = 0; j < cs - rel; j++) in_arr[start_fill_idx + j][nn] = in_buffer[nn * 1024 + rel + j];

@@ -148,7 +148,7 @@ class Oracle:
 
     def fine(self, coarse_Tx2, p: OrcParams) -> np.ndarray:
         co = _i32(coarse_Tx2).reshape(-1, 2)
-        out = np.zeros((1024, 8), np.int32)
+        out = np.zeros((max(len(co), 1), 8), np.int32)
         T = self.lib.orc_fine(self.h, C.byref(p), co.ctypes.data, len(co), out.ctypes.data, self.n_threads)
         if T < 0:
             raise RuntimeError("oracle fine stage failed")
@@ -174,9 +174,9 @@ class Oracle:
 
     def generate(self, text: str, p: OrcParams) -> dict:
         sem = np.zeros(1024, np.int32)
-        co = np.zeros((1024, 2), np.int32)
-        fi = np.zeros((1024, 8), np.int32)
-        pcm = np.zeros(1024 * 320, np.float32)
+        co = np.zeros((4096, 2), np.int32)
+        fi = np.zeros((4096, 8), np.int32)
+        pcm = np.zeros(4096 * 320, np.float32)
         res = OrcResult()
         rc = self.lib.orc_generate(self.h, C.byref(p), text.encode("utf-8"), sem.ctypes.data, co.ctypes.data,
                                    fi.ctypes.data, pcm.ctypes.data, C.byref(res), self.n_threads)
