@@ -172,6 +172,18 @@ def main():
                 bctx.free()
             except Exception as e:      # noqa: BLE001
                 out["batched_8_utterances"] = {"error": str(e)}
+        # the reference's default step cap (n_steps_text_encoder = 768, bark.cpp:2212): 1154 frames = 15.4 s per prompt, two fine windows
+        if world == 1:
+            try:
+                ctx.set_params(pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=768))
+                ctx.generate_audio(prompts[3])
+                t7 = time.perf_counter(); assert ctx.generate_audio(prompts[4]); d7 = time.perf_counter() - t7
+                s7 = ctx.stats()
+                out["default_cap_768_steps"] = {"rtf": s7["n_samples"] / 24000.0 / d7, "ms_per_prompt": d7 * 1e3, "audio_s": s7["n_samples"] / 24000.0,
+                                                "n_frames": s7["n_frames"]}
+                ctx.set_params(pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=a.n_semantic))
+            except Exception as e:      # noqa: BLE001
+                out["default_cap_768_steps"] = {"error": str(e)}
         # BASELINE config 4: the same model quantised to q4_0 by the native bark_model_quantize (reported beside the headline)
         if world == 1 and not a.no_q4:
             try:
