@@ -67,7 +67,7 @@ EXPORTS = [
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
-    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
+    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
 
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_generate_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
+    lib.bark_hip_generate_batch_seeded.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint32)]
     lib.bark_hip_batch_audio.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float))]
     lib.bark_hip_batch_tokens.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     lib.bark_hip_clone_context.restype = vp
@@ -284,11 +285,15 @@ class BarkContext:
             raise RuntimeError("bark_hip_codec_tap failed")
         return out[:n].copy()
 
-    def generate_batch(self, texts) -> list:
-        """In-engine batching (bark_hip_generate_batch): returns one dict per utterance (or None if it failed)."""
+    def generate_batch(self, texts, seeds=None) -> list:
+        """In-engine batching (bark_hip_generate_batch[_seeded]): returns one dict per utterance (or None if it failed)."""
         n = len(texts)
         ts = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
-        good = self._lib.bark_hip_generate_batch(self._h, ts, n)
+        if seeds is None:
+            good = self._lib.bark_hip_generate_batch(self._h, ts, n)
+        else:
+            assert len(seeds) == n
+            good = self._lib.bark_hip_generate_batch_seeded(self._h, ts, n, (C.c_uint32 * n)(*[int(v) for v in seeds]))
         if good < 0:
             raise RuntimeError("bark_hip_generate_batch failed")
         out = []

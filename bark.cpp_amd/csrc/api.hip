@@ -215,7 +215,12 @@ int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * cons
 int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n) {
     if (!bctx || !texts || n <= 0) return -1;
     for (int i = 0; i < n; i++) if (!texts[i]) return -1;
-    return guarded("bark_hip_generate_batch", -1, [&] { return engine_generate_batch(bctx, texts, n); });
+    return guarded("bark_hip_generate_batch", -1, [&] { return engine_generate_batch(bctx, texts, n, nullptr); });
+}
+int bark_hip_generate_batch_seeded(struct bark_context * bctx, const char * const * texts, int n, const uint32_t * seeds) {
+    if (!bctx || !texts || !seeds || n <= 0) return -1;
+    for (int i = 0; i < n; i++) if (!texts[i]) return -1;
+    return guarded("bark_hip_generate_batch_seeded", -1, [&] { return engine_generate_batch(bctx, texts, n, seeds); });
 }
 int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data) {
     if (!bctx || i < 0 || i >= (int) bctx->batch_results.size() || !bctx->batch_results[(size_t) i].ok) return -1;

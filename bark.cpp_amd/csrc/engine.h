@@ -103,6 +103,7 @@ struct bark_context {
         float * kc[2] = {nullptr, nullptr}, * vc[2] = {nullptr, nullptr}; size_t slot_stride[2] = {0, 0};
         float * x = nullptr, * q = nullptr, * logits = nullptr; barkhip::half_t * att = nullptr, * h = nullptr;
         barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr; float * ln_stats = nullptr;
+        double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
         hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
     } batch;
@@ -135,7 +136,8 @@ std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> 
 // tap_stage >= 0: *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
 std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap);
 bool engine_generate(bark_context * ctx, const char * text);
-int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n);     // greedy only; returns #ok
+// seeds: one std::mt19937 seed per utterance (temp > 0); nullptr: drawn from the context's generator, in order.  Returns #ok
+int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n, const uint32_t * seeds);
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);

@@ -1193,6 +1193,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.ln_stats = dev_alloc<float>(c, (size_t) B * 2);
     bb.out_tokens = dev_alloc<int32_t>(c, (size_t) B * 2048);
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
+    bb.u = dev_alloc<double>(c, (size_t) B * 8192);
     bb.cap = B;
 }
 
@@ -1255,6 +1256,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     sa.logits = bb.logits; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
     sa.token_base = s.token_base; sa.n_past_add = 1; sa.out_tokens = bb.out_tokens; sa.eos_trace = s.mode == 0 ? bb.eos_trace : nullptr;
     sa.st = bb.state; sa.nbatch = B; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
+    sa.temp = s.temp; sa.u = bb.u; sa.u_stride = 8192;
     sa.wte = m.wte[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x;
     launch_sample_greedy(st, sa);
 }
@@ -1286,7 +1288,7 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
     const size_t E = (size_t) c->gpt[s.which].hp.n_embd;
     for (int g = 0; g < 2; g++) { v.kc[g] += v.slot_stride[g] * (size_t) b; v.vc[g] += v.slot_stride[g] * (size_t) b; }
     v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
-    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b;
+    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b; v.u += (size_t) b * 8192;
     v.graph[0] = v.graph[1] = nullptr;
     return v;
 }
@@ -1296,6 +1298,16 @@ void embed_slot(bark_context * c, const StageCfg & s, int b) {
     e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1;
     e.st = c->batch.state + b; e.x = c->batch.x + (size_t) b * m.hp.n_embd;
     launch_embed_causal(c->stream, e);
+}
+
+// temp > 0: the next `n` uniform draws of a slot's own generator, taken from a COPY as in upload_uniforms()
+void upload_slot_uniforms(bark_context * c, int slot, const std::mt19937 & rng, int n) {
+    if (n > 8192) throw std::runtime_error("too many samples in one stage");
+    std::mt19937 tmp = rng;
+    std::vector<double> u((size_t) std::max(n, 1));
+    for (auto & v : u) v = std::generate_canonical<double, 53>(tmp);
+    HIP_OK(hipMemcpyAsync(c->batch.u + (size_t) slot * 8192, u.data(), (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
 }
 
 // prompt of one slot through the model (single-utterance kernels, the slot's own cache), first sample of the slot
@@ -1318,23 +1330,31 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
     sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
     sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
+    sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
     sa.wte = m.wte[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot * m.hp.n_embd;
     launch_sample_greedy(c->stream, sa);
 }
 
 }  // namespace
 
-int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
+int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds) {
     HIP_OK(hipSetDevice(c->device));
     const bark_context_params & p = c->params;
     if (n <= 0 || n > 32) throw std::runtime_error("generate_batch: batch size must be in 1..32");
     c->batch_results.assign((size_t) n, bark_context::BatchResult());
-    if (p.temp != 0.0f || p.fine_temp != 0.0f || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_q4) {
-        // sampled decoding and q4_0 models keep one utterance in flight: fall back to the sequential loop
+    // one generator per utterance (bark.cpp:1179 seeds one per context): utterance i of a batch is what a fresh context with
+    // seed seeds[i] would generate.  Without explicit seeds they are drawn from the context's generator, in order.
+    std::vector<std::mt19937> slot_rng((size_t) n);
+    for (int i = 0; i < n; i++) slot_rng[(size_t) i] = std::mt19937(seeds ? seeds[i] : (uint32_t) c->rng());
+    const bool sampled = p.temp != 0.0f;
+    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_q4) {
+        // host-side sampling and quantised models keep one utterance in flight: fall back to the sequential loop
         int good = 0;
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];
-            r.ok = engine_generate(c, texts[i]);
+            std::swap(c->rng, slot_rng[(size_t) i]);
+            try { r.ok = engine_generate(c, texts[i]); } catch (...) { std::swap(c->rng, slot_rng[(size_t) i]); throw; }
+            std::swap(c->rng, slot_rng[(size_t) i]);
             if (r.ok) { r.semantic = c->semantic_tokens; r.coarse = c->coarse_tokens; r.fine = c->fine_tokens; r.audio = c->audio; good++; }
         }
         return good;
@@ -1359,6 +1379,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
         pp.block_size = m.hp.block_size; pp.text_encoding_offset = p.text_encoding_offset; pp.text_pad_token = p.text_pad_token;
         pp.semantic_pad_token = p.semantic_pad_token; pp.semantic_infer_token = p.semantic_infer_token;
         if (n_steps > 0) {
+            if (sampled) for (int b = 0; b < B; b++) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps);
             for (int b = 0; b < B; b++) batch_prefill_and_sample(c, s, b, build_semantic_prompt(c->vocab, pp, texts[b], true), true, 0);
             int issued = 1;
             std::vector<StepState> st;
@@ -1375,7 +1396,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
                 auto & out = c->batch_results[(size_t) b].semantic;
                 out.resize((size_t) keep);
                 if (keep) HIP_OK(hipMemcpy(out.data(), bb.out_tokens + (size_t) b * 2048, (size_t) keep * 4, hipMemcpyDeviceToHost));
-                c->stats.n_sample_semantic += std::min(issued, st[(size_t) b].eos_step == INT32_MAX ? issued : st[(size_t) b].eos_step + 1);
+                const int n_used = std::min(issued, st[(size_t) b].eos_step == INT32_MAX ? issued : st[(size_t) b].eos_step + 1);
+                c->stats.n_sample_semantic += n_used;
+                if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_used);      // as consume_uniforms()
                 c->stats.n_near_tie += st[(size_t) b].near_tie;
             }
         }
@@ -1399,6 +1422,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
             if (sem.empty()) continue;
             n_steps[(size_t) b] = (int) (floorf(sem.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);
             max_windows = std::max(max_windows, (int) ceilf((float) n_steps[(size_t) b] / p.sliding_window_size));
+            if (sampled) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps[(size_t) b]);          // indexed by the slot's step_idx
         }
         std::vector<std::vector<int32_t>> cached((size_t) B);          // per slot: ids whose K/V rows are in its cache
         static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
@@ -1473,6 +1497,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
             progress(c, COARSE, 100 * (w + 1) / std::max(1, max_windows));
         }
         for (int b = 0; b < B; b++) {
+            if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_steps[(size_t) b]);
             auto & res = c->batch_results[(size_t) b].coarse;
             const auto & out = coarse_out[(size_t) b];
             for (size_t i = 0; i + 1 < out.size(); i += 2) {
@@ -1489,7 +1514,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n) {
         bark_context::BatchResult & r = c->batch_results[(size_t) b];
         if (r.coarse.empty()) continue;
         t = now_us();
-        r.fine = engine_fine(c, r.coarse);
+        std::swap(c->rng, slot_rng[(size_t) b]);                        // the fine stage draws from the utterance's generator
+        try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, slot_rng[(size_t) b]); throw; }
+        std::swap(c->rng, slot_rng[(size_t) b]);
         c->stats.t_fine_us += now_us() - t;
         const int T = (int) r.fine.size() / 8;
         std::vector<int32_t> codes((size_t) 8 * T);

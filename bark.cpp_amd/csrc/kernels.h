@@ -124,6 +124,7 @@ struct SampleArgs {
     int mode = 0;                          // 0 semantic (stop rule on eos token / eos_p), 1 coarse
     float temp = 0.0f;                     // 0: greedy (gpt_argmax_sample); > 0: multinomial with the uniform draws u[st->step]
     const double * u = nullptr;
+    int u_stride = 0;                      // batched decode: slot b reads u + b * u_stride
     float min_eos_p = 0.2f; int eos_token = 10000;
     int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)

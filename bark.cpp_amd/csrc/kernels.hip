@@ -1830,7 +1830,7 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     const float * logits = a.logits + (size_t) slot * a.ld_logits;
     StepState * st = a.st + slot;
     const int step = st->step;
-    const double u = a.u[step];
+    const double u = a.u[(size_t) slot * a.u_stride + step];
     constexpr int CH = 12;                                      // thread t owns the contiguous ids [t*CH, t*CH+CH): up to 12288 logits
     float pv[CH];
     float mx = -INFINITY;

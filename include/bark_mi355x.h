@@ -79,10 +79,13 @@ BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const ch
 
 /* In-engine batching: n utterances (n <= 32) advance in lock step through the semantic and coarse decode loops of ONE
  * context, so every decode kernel reads the weights once per step for all of them; prefill, fine passes and the codec
- * run per utterance.  Greedy parameters only (temp == fine_temp == 0); otherwise the call degrades to a sequential
- * loop.  Per-utterance results are bit-identical to bark_generate_audio.  The first call fixes the batch capacity.
+ * run per utterance.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context.  With temp > 0 every
+ * utterance has its own std::mt19937 (the reference seeds one per context, bark.cpp:1179): utterance i is what a context
+ * loaded with seed seeds[i] would generate; the unseeded call draws those seeds from the context's generator, in order.
+ * Quantised models and BARK_HIP_HOST_SAMPLING degrade to a sequential loop.  The first call fixes the batch capacity.
  * Returns the number of utterances that produced audio.  Results: bark_hip_batch_audio / bark_hip_batch_tokens. */
 BARK_API int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n);
+BARK_API int bark_hip_generate_batch_seeded(struct bark_context * bctx, const char * const * texts, int n, const uint32_t * seeds);
 /* audio of utterance i of the last batch: returns the sample count (-1 on error), *data points into the context */
 BARK_API int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data);
 /* token stream of utterance i: stage 0 semantic, 1 coarse [T][2], 2 fine [T][8]; returns the id count or -1 */
