@@ -1194,6 +1194,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.out_tokens = dev_alloc<int32_t>(c, (size_t) B * 2048);
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
     bb.u = dev_alloc<double>(c, (size_t) B * 8192);
+    if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.cap = B;
 }
 
@@ -1217,39 +1218,40 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     const size_t slot = bb.slot_stride[s.which];
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
     // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
-    const bool hoist = B >= 24;
+    const bool hoist = B >= 24 && !m.q4;
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
         if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs a;
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
-        a.W = L.attn_w; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
         launch_linear(st, a);
         AttnDecodeArgs at;
         at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
-        at.nbatch = B; at.kv_slot_stride = slot;
+        at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
         launch_attn_decode_part(st, at, 4);
         LinArgs p;
         p.batched = 1; p.nbatch = B;
-        p.W = L.proj_w; p.M = E; p.K = E; p.N = 1; p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
         launch_linear(st, p);
         if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
-        f.W = L.fc_w; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
-        f.epi = EPI_GELU; f.out_h = bb.h; f.lut = c->d_gelu_lut;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
+        f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(st, f);
         LinArgs o;
         o.batched = 1; o.nbatch = B;
-        o.W = L.mproj_w; o.M = E; o.K = 4 * E; o.N = 1; o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
         launch_linear(st, o);
     }
     if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
     LinArgs h;
     h.batched = 1; h.nbatch = B; h.ln_stats = hoist ? bb.ln_stats : nullptr;
-    h.W = m.lm_head[0] + (size_t) s.lm_row0 * E; h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b;
+    if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, E); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * E;
+    h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
     launch_linear(st, h);
     SampleArgs sa;
@@ -1257,7 +1259,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     sa.token_base = s.token_base; sa.n_past_add = 1; sa.out_tokens = bb.out_tokens; sa.eos_trace = s.mode == 0 ? bb.eos_trace : nullptr;
     sa.st = bb.state; sa.nbatch = B; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
     sa.temp = s.temp; sa.u = bb.u; sa.u_stride = 8192;
-    sa.wte = m.wte[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x;
+    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x;
     launch_sample_greedy(st, sa);
 }
 
@@ -1288,6 +1290,7 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
     const size_t E = (size_t) c->gpt[s.which].hp.n_embd;
     for (int g = 0; g < 2; g++) { v.kc[g] += v.slot_stride[g] * (size_t) b; v.vc[g] += v.slot_stride[g] * (size_t) b; }
     v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
+    if (v.att32) { v.att32 += E * b; v.h32 += 4 * E * b; }
     v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b; v.u += (size_t) b * 8192;
     v.graph[0] = v.graph[1] = nullptr;
     return v;
@@ -1295,7 +1298,7 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
 void embed_slot(bark_context * c, const StageCfg & s, int b) {
     GptModel & m = c->gpt[s.which];
     EmbedArgs e;
-    e.wte = m.wte[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1;
+    e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1;
     e.st = c->batch.state + b; e.x = c->batch.x + (size_t) b * m.hp.n_embd;
     launch_embed_causal(c->stream, e);
 }
@@ -1322,7 +1325,8 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     float * kb = bb.kc[s.which] + bb.slot_stride[s.which] * (size_t) slot, * vb = bb.vc[s.which] + bb.slot_stride[s.which] * (size_t) slot;
     const int N = run_prefill(c, m, (int) ids.size() - L, merge, kb, vb, L);
     LinArgs h;
-    h.W = m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd; h.M = s.lm_rows; h.K = m.hp.n_embd; h.N = 1;
+    if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, m.hp.n_embd); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd;
+    h.M = s.lm_rows; h.K = m.hp.n_embd; h.N = 1;
     h.x_f32 = c->x + (size_t) (N - 1) * m.hp.n_embd; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
     h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
     launch_linear(c->stream, h);
@@ -1331,7 +1335,7 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
     sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
     sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
-    sa.wte = m.wte[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot * m.hp.n_embd;
+    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot * m.hp.n_embd;
     launch_sample_greedy(c->stream, sa);
 }
 
@@ -1347,8 +1351,8 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     std::vector<std::mt19937> slot_rng((size_t) n);
     for (int i = 0; i < n; i++) slot_rng[(size_t) i] = std::mt19937(seeds ? seeds[i] : (uint32_t) c->rng());
     const bool sampled = p.temp != 0.0f;
-    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_q4) {
-        // host-side sampling and quantised models keep one utterance in flight: fall back to the sequential loop
+    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd) {
+        // host-side sampling keeps one utterance in flight: fall back to the sequential loop
         int good = 0;
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];

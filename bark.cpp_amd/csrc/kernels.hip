@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
     const int c = lane & 15, rg = lane >> 4;
     const int m = blockIdx.x * 16 + wave * 4 + rg;
     const int K = a.K, nblk = K >> 5;
+    const int slot = a.batched ? blockIdx.y : 0;              // lock-step batch: one sequence per grid.y (own x row, state, KV cache)
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;
     const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
         const int b = c + 16 * i;
         if (b < nblk) wb[i] = load_raw<QT>(a.wq, wrow + b);
     }
-    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, row_off);
 
     // ---- x -> q8: thread t quantises elements [16 (t & 1), +16) of block t >> 1
     const int qb = tid >> 1, qh = tid & 1;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
     const int k0 = mine ? (qb << 5) + (qh << 4) : 0;
     float v[16];
     {
-        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + k0);
+        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (size_t) slot * K + k0);
         #pragma unroll
         for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
     }
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
         }
     }
     acc = wave_xor_add16(acc);
-    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    if (live && c == 0) linear_epilogue_pre(a, slot, m, acc, pre);
 }
 
 // rows (N > 1): q8 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
@@ -958,7 +959,10 @@ void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * 
 template <int QT>
 static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
     if (a.N == 1) {
-        dim3 grid((a.M + 15) / 16), block(256);
+        // lock-step batch: grid.y walks the sequences; grid.x rounded up to a multiple of 8 so that every grid.y of a row group
+        // lands on the same XCD and re-reads the weight blocks from its L2
+        const int gx = (a.M + 15) / 16;
+        dim3 grid(a.batched ? (gx + 7) / 8 * 8 : gx, a.batched ? a.nbatch : 1), block(256);
         if (a.ln_g) {
             if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, true, true>), grid, block, 0, s, a);
             else        hipLaunchKernelGGL((gemv_q_kernel<QT, true, false>), grid, block, 0, s, a);
@@ -984,7 +988,7 @@ static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
 }
 static void launch_linear_q(hipStream_t s, const LinArgs & a) {
     if ((a.K & 31) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: quantised rows must be a multiple of 32 and at most 4096 long\n"); abort(); }
-    if (a.batched) { fprintf(stderr, "bark-hip: the lock-step batched decode has no kernels for quantised weights yet\n"); abort(); }
+    if (a.batched && (a.N != 1 || a.ln_stats)) { fprintf(stderr, "bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics\n"); abort(); }
     if (a.N == 1 && !a.x_f32) { fprintf(stderr, "bark-hip: quantised GEMV needs an f32 activation row\n"); abort(); }
     if (a.N > 1 && (!a.xq.q || a.parity_rows)) { fprintf(stderr, "bark-hip: quantised row product needs pre-quantised rows\n"); abort(); }
     switch (a.wq.qt) {

@@ -82,7 +82,7 @@ BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const ch
  * run per utterance.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context.  With temp > 0 every
  * utterance has its own std::mt19937 (the reference seeds one per context, bark.cpp:1179): utterance i is what a context
  * loaded with seed seeds[i] would generate; the unseeded call draws those seeds from the context's generator, in order.
- * Quantised models and BARK_HIP_HOST_SAMPLING degrade to a sequential loop.  The first call fixes the batch capacity.
+ * BARK_HIP_HOST_SAMPLING degrades the call to a sequential loop.  The first call fixes the batch capacity.
  * Returns the number of utterances that produced audio.  Results: bark_hip_batch_audio / bark_hip_batch_tokens. */
 BARK_API int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n);
 BARK_API int bark_hip_generate_batch_seeded(struct bark_context * bctx, const char * const * texts, int n, const uint32_t * seeds);
