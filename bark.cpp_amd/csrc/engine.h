@@ -24,7 +24,8 @@ struct GptModel {
     const half_t * wte[8] = {};
     const half_t * lm_head[8] = {};
     // quantised model files (bark_model_quantize output): every weight matrix is a QMat instead of an f16 pointer
-    bool q4 = false;
+    bool q4 = false;                                    // activations stay f32 (quantised or f32 weights)
+    bool w32 = false;                                   // f32 weights (QMat with qt == QT_F32)
     QMat wte_q[8], lm_head_q[8];
     const float * wpe = nullptr, * lnf_g = nullptr, * lnf_b = nullptr;
     struct Layer {
@@ -79,6 +80,7 @@ struct bark_context {
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;
     float * att32 = nullptr, * h32 = nullptr; barkhip::Q8Scratch xq;
+    bool any_w32 = false; float * xn32 = nullptr;       // f32 model files: LayerNorm-ed rows without f16 rounding
     int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;

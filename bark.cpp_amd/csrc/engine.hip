@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <stdexcept>
 
 using namespace barkhip;
@@ -56,17 +57,18 @@ const TensorRef & need(const std::map<std::string, TensorRef> & m, const std::st
         throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
     if (t.ttype != ttype)
         throw std::runtime_error("tensor '" + name + "' is " + (quant_format_by_type(t.ttype) ? quant_format_by_type(t.ttype)->name : t.ttype ? "f16" : "f32") +
-                                 "; this engine needs the f16 model file (convert.py --use-f16) or a bark_model_quantize output of it");
+                                 ", expected " + (ttype == 1 ? "f16" : ttype == 0 ? "f32" : "another type"));
     return t;
 }
 // a weight matrix: f16, or q4_0 (uploaded later as a QMat)
 const TensorRef & need_w(const std::map<std::string, TensorRef> & m, const std::string & name, int64_t ne0, int64_t ne1) {
     auto it = m.find(name);
     if (it == m.end()) throw std::runtime_error("missing tensor '" + name + "'");
-    return need(m, name, quant_format_by_type(it->second.ttype) ? it->second.ttype : 1, ne0, ne1);
+    return need(m, name, it->second.ttype, ne0, ne1);                      // f32, f16 or a block format: all accepted
 }
 QMat q4_rows(const QMat & w, size_t row0, int K) {
     QMat r = w;
+    if (w.qt == QT_F32) { r.qs = w.qs + row0 * (size_t) K * 4; return r; }
     const size_t nb = row0 * (size_t) (K / 32);
     r.d = w.d + nb; r.qs = w.qs + nb * (size_t) quant_formats()[w.qt].qs_bytes;
     if (w.m) r.m = w.m + nb;
@@ -159,6 +161,7 @@ static void init_runtime(bark_context * ctxp) {
         ctx->xq.sT = dev_alloc<float>(ctx.get(), nT);
         HIP_OK(hipMemset(ctx->xq.dT, 0, nT * sizeof(float)));
         HIP_OK(hipMemset(ctx->xq.sT, 0, nT * sizeof(float)));
+        if (ctx->any_w32) ctx->xn32 = dev_alloc<float>(ctx.get(), NE);
     }
     size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
     for (int g = 0; g < 2; g++) n_logits = std::max(n_logits, (size_t) ctx->gpt[g].hp.n_out_vocab);
@@ -213,10 +216,11 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     auto place = [&](const TensorRef & t, const void ** dst) { fixes.push_back({dst, plan.add(t)}); };
     struct Q4Job { const TensorRef * t; QMat * dst; };
     std::vector<Q4Job> q4_jobs;
-    int n_w16 = 0, n_wq4 = 0;
+    int n_w16 = 0, n_wq4 = 0, n_w32 = 0;
     GptModel * cur_model = nullptr;
     auto place_w = [&](const TensorRef & t, const half_t ** dst16, QMat * dstq) {
         if (quant_format_by_type(t.ttype)) { q4_jobs.push_back({&t, dstq}); n_wq4++; }
+        else if (t.ttype == 0) { place(t, (const void **) &dstq->qs); dstq->qt = QT_F32; n_w32++; }       // f32 file: plain f32 rows behind the QMat handle
         else { place(t, (const void **) dst16); n_w16++; }
         (void) cur_model;
     };
@@ -231,7 +235,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         if (m.hp.block_size != 1024) throw std::runtime_error("block_size must be 1024");
         if (m.hp.n_wtes > 8 || m.hp.n_lm_heads > 8 || m.hp.n_layer > 64) throw std::runtime_error("unsupported GPT shape");
         m.layers.resize((size_t) m.hp.n_layer);
-        n_w16 = n_wq4 = 0;
+        n_w16 = n_wq4 = n_w32 = 0;
         for (int i = 0; i < m.hp.n_wtes; i++) place_w(need_w(T, "model/wte/" + std::to_string(i), E, m.hp.n_in_vocab), &m.wte[i], &m.wte_q[i]);
         for (int i = 0; i < m.hp.n_lm_heads; i++) place_w(need_w(T, "model/lm_head/" + std::to_string(i), E, m.hp.n_out_vocab), &m.lm_head[i], &m.lm_head_q[i]);
         place(need(T, "model/wpe", 0, E, m.hp.block_size), (const void **) &m.wpe);
@@ -254,9 +258,11 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             if (auto * t = maybe(T, p + "/mlp/c_proj/b", 0, E)) place(*t, (const void **) &L.mproj_b);
         }
         // bark_model_quantize converts every matrix of a model or none (bark.cpp:2277-2289)
-        if (n_w16 && n_wq4) throw std::runtime_error("model mixes f16 and quantised weight matrices");
-        m.q4 = n_wq4 > 0;
+        if ((n_w16 > 0) + (n_wq4 > 0) + (n_w32 > 0) > 1) throw std::runtime_error("model mixes f32 / f16 / quantised weight matrices");
+        m.w32 = n_w32 > 0;
+        m.q4 = n_wq4 > 0 || m.w32;                        // both keep the activations in f32 between the products
         ctx->any_q4 = ctx->any_q4 || m.q4;
+        ctx->any_w32 = ctx->any_w32 || m.w32;
         ctx->max_E = std::max(ctx->max_E, E);
         ctx->max_H = std::max(ctx->max_H, m.hp.n_head);
     }
@@ -265,10 +271,27 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     // ---- codec -------------------------------------------------------------------------------------
     CodecModel & cm = ctx->codec;
     cm.hp = mf.codec_hp;
+    // f32 codec weights (convert.py without --use-f16) are rounded to f16 here and then run in the f16-weight arithmetic, like
+    // the oracle: conv kernels meet an f16 im2col in ggml's mul_mat anyway; for the LSTM matrices it is a stated simplification
+    std::map<std::string, TensorRef> codec_w16;
+    std::deque<std::vector<uint16_t>> codec_w16_store;
+    auto codec_weight = [&](const std::string & name, int64_t ne0, int64_t ne1) -> const TensorRef & {
+        auto it = mf.codec.find(name);
+        if (it == mf.codec.end()) throw std::runtime_error("missing tensor '" + name + "'");
+        if (it->second.ttype != 0) return need(mf.codec, name, 1, ne0, ne1);
+        auto have = codec_w16.find(name);
+        if (have != codec_w16.end()) return have->second;
+        const TensorRef & t = need(mf.codec, name, 0, ne0, ne1);
+        codec_w16_store.emplace_back((size_t) t.nelements());
+        std::vector<uint16_t> & h = codec_w16_store.back();
+        for (size_t i = 0; i < h.size(); i++) { float f; memcpy(&f, t.data + 4 * i, 4); h[i] = __builtin_bit_cast(uint16_t, (_Float16) f); }
+        TensorRef r = t; r.ttype = 1; r.data = (const uint8_t *) h.data();
+        return codec_w16[name] = r;
+    };
     {
         const auto & T = mf.codec;
         auto conv = [&](const std::string & p, CodecModel::Conv & cv) {
-            const TensorRef & w = need(T, p + ".weight", 1, 0, 0);
+            const TensorRef & w = codec_weight(p + ".weight", 0, 0);
             cv.k = (int) w.ne[0]; cv.cin = (int) w.ne[1]; cv.cout = (int) w.ne[2];
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
@@ -276,7 +299,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             place(b, (const void **) &cv.b);
         };
         auto convt = [&](const std::string & p, CodecModel::ConvT & cv, int stride) {
-            const TensorRef & w = need(T, p + ".weight", 1, 0, 0);
+            const TensorRef & w = codec_weight(p + ".weight", 0, 0);
             cv.k = (int) w.ne[0]; cv.cout = (int) w.ne[1]; cv.cin = (int) w.ne[2]; cv.stride = stride;
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
@@ -288,8 +311,8 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         if (cm.D % 128 != 0) throw std::runtime_error("codec LSTM width must be a multiple of 128");
         for (int l = 0; l < 2; l++) {
             const std::string s = std::to_string(l);
-            place(need(T, "decoder.model.1.lstm.weight_ih_l" + s, 1, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_ih);
-            place(need(T, "decoder.model.1.lstm.weight_hh_l" + s, 1, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_hh);
+            place(codec_weight("decoder.model.1.lstm.weight_ih_l" + s, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_ih);
+            place(codec_weight("decoder.model.1.lstm.weight_hh_l" + s, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_hh);
             place(need(T, "decoder.model.1.lstm.bias_ih_l" + s, 0, 4 * cm.D, 0), (const void **) &cm.lstm[l].b_ih);
             place(need(T, "decoder.model.1.lstm.bias_hh_l" + s, 0, 4 * cm.D, 0), (const void **) &cm.lstm[l].b_hh);
         }
@@ -367,7 +390,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             HIP_OK(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
             return d;
         };
-        auto cw = [&](const std::string & p) { return widen(need(mf.codec, p + ".weight", 1, 0, 0)); };
+        auto cw = [&](const std::string & p) { return widen(codec_weight(p + ".weight", 0, 0)); };
         cm.init.w32 = cw("decoder.model.0.conv.conv");
         for (int i = 0; i < 4; i++) {
             const int idx = 3 + 3 * i;
@@ -416,7 +439,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     ctx->codec = src->codec;
     ctx->device = src->device; ctx->use_graph = src->use_graph;
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
-    ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4;
+    ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4; ctx->any_w32 = src->any_w32;
     HIP_OK(hipStreamCreate(&ctx->stream));
     init_runtime(ctx.get());
     ctx->description = src->description + " (clone)";
@@ -428,6 +451,12 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
+// bytes per weight of the model's matrices: f16 2, f32 4, block formats block_bytes / 32
+double weight_bytes_per_element(const GptModel & m) {
+    if (m.w32) return 4.0;
+    if (m.q4) return quant_formats()[m.layers[0].attn_q.qt].block_bytes / 32.0;
+    return 2.0;
+}
 float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride * (size_t) l; }
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
 
@@ -441,10 +470,11 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         // f16 weights: activations are rounded to f16 rows (xn / att / hbuf); q4_0 weights: f32 rows quantised to q8_0 (xq8 / xd8)
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq);
-        else      launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
+        if (m.w32)     launch_ln_rows_f32(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn32);
+        else if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq);
+        else           launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
         LinArgs a;
-        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         launch_linear(s, a);
         AttnPrefillArgs at;
@@ -452,19 +482,20 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
         { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
         launch_attn_prefill(s, at);
-        if (m.q4) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
+        if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
-        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; if (m.w32) p.x_f32 = c->att32; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
         launch_linear(s, p);
-        if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq);
-        else      launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
+        if (m.w32)     launch_ln_rows_f32(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn32);
+        else if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq);
+        else           launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
         LinArgs f;
-        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq = c->xq; f.bias = L.fc_b; f.epi = EPI_GELU;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq = c->xq; if (m.w32) f.x_f32 = c->xn32; f.bias = L.fc_b; f.epi = EPI_GELU;
         f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         launch_linear(s, f);
-        if (m.q4) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq);
+        if (m.q4 && !m.w32) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq);
         LinArgs o;
-        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq = c->xq; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq = c->xq; if (m.w32) o.x_f32 = c->h32; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
         launch_linear(s, o);
     }
 }
@@ -710,10 +741,11 @@ void run_fine_forward(bark_context * c, int nn, int n_rows) {
     const int E = m.hp.n_embd;
     launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
     run_layers_rows(c, m, 1024, false);
-    if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq);
-    else      launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
+    if (m.w32)     launch_ln_rows_f32(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn32);
+    else if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq);
+    else           launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
-    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace
@@ -1351,8 +1383,8 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     std::vector<std::mt19937> slot_rng((size_t) n);
     for (int i = 0; i < n; i++) slot_rng[(size_t) i] = std::mt19937(seeds ? seeds[i] : (uint32_t) c->rng());
     const bool sampled = p.temp != 0.0f;
-    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd) {
-        // host-side sampling keeps one utterance in flight: fall back to the sequential loop
+    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) {
+        // host-side sampling and f32 model files keep one utterance in flight: fall back to the sequential loop
         int good = 0;
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];
@@ -1568,7 +1600,7 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     if (bytes_per_step) {
         const double E = m.hp.n_embd, L = m.hp.n_layer;
         // f16 weights of all layers + evaluated LM-head rows + f32 K and V rows read
-        const double wb = m.q4 ? 18.0 / 32.0 : 2.0;      // bytes per weight: f16, or q4_0 blocks (18 bytes per 32 weights)
+        const double wb = weight_bytes_per_element(m);
         *bytes_per_step = L * 12.0 * E * E * wb + (double) s.lm_rows * E * wb + 2.0 * ctxlen * E * L * 4.0;
     }
     return (double) ms * 1000.0 / std::max(1, iters);
@@ -1643,7 +1675,7 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
     if (bytes_per_launch) {
         const double Ed = E;
         const double w = op == 0 ? 3 * Ed * Ed : op == 1 ? Ed * Ed : 4 * Ed * Ed;
-        *bytes_per_launch = w * (m.q4 ? 18.0 / 32.0 : 2.0);          // f16 (or q4_0) weight matrix; vectors are < 1 % of it
+        *bytes_per_launch = w * weight_bytes_per_element(m);          // the weight matrix; vectors are < 1 % of it
     }
     return (double) ms * 1000.0 / std::max(1, iters);
 }

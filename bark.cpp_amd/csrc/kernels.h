@@ -32,7 +32,7 @@ struct StepState {
 // low nibble of byte j = element j of the block, high nibble = element j + 16)
 struct QMat {
     const half_t * d = nullptr; const uint8_t * qs = nullptr; const half_t * m = nullptr; const uint32_t * qh = nullptr;
-    int qt = 0;                           // QuantId
+    int qt = 0;                           // QuantId; QT_F32: qs points at plain f32 weights [M][K] (f32 model files), d / m / qh unused
 };
 // q8 image of N <= 1024 activation rows: levels q [N][K] int8, scales d and s = f16(d * sum q) as [N][K/32] and block-major
 // [K/32][1024] (the i8-MFMA kernel reads 16 consecutive rows of one block)
@@ -94,6 +94,7 @@ void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats
 // q8 quantisation of N <= 1024 f32 rows of length K (LayerNorm first when ln_g != nullptr)
 void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, const Q8Scratch & out);
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out);
+void launch_ln_rows_f32(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, float * out);   // no f16 rounding (f32 weights)
 
 // Single-query attention over the KV cache (decode step): q [E] f32, ctx = st->n_past + 1 keys.
 struct AttnDecodeArgs {

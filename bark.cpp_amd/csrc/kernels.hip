@@ -87,6 +87,7 @@ DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
 // one element of an embedding row: f16 table, or a quantised table dequantised as ggml_get_rows does (level * d (+ m))
 DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e) {
     if (!q.qs) return (float) wte[(size_t) tok * E + e];
+    if (q.qt == QT_F32) return reinterpret_cast<const float *>(q.qs)[(size_t) tok * E + e];
     const size_t blk = (size_t) tok * (E >> 5) + (e >> 5);
     const int j = e & 31;
     const float d = (float) q.d[blk];
@@ -1001,7 +1002,126 @@ static void launch_linear_q(hipStream_t s, const LinArgs & a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f32 weights (model files converted without --use-f16).  ggml converts the activation only when the weight type asks for
+// it, so both operands are f32 here; the summation order is C1 unchanged (8-element chunks, chunk q -> chain q mod 16, fmaf).
+// These are plain kernels - the format is a compatibility path, not a tuned one: decode stages the (LayerNorm-ed) row in
+// LDS once per 16 output rows, rows (N > 1) re-read the weights from L2 for every eight activation rows.
+// ------------------------------------------------------------------------------------------------
+template <bool LN, bool LNB>
+__global__ __launch_bounds__(256) void gemv_w32_kernel(const LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[4096];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 16 + wave * 4 + rg;
+    const int K = a.K, nchunk = K >> 3;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const float * wrow = reinterpret_cast<const float *>(a.wq.qs) + (size_t) (row_off + (live ? m : 0)) * K;
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    // ---- stage x: thread t owns elements [16 t, 16 t + 16)
+    const bool mine = 16 * tid < K;
+    const int k0 = mine ? 16 * tid : 0;
+    float v[16];
+    {
+        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + k0);
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    }
+    if constexpr (LN) {
+        double s1 = 0.0;
+        if (mine) {
+            #pragma unroll
+            for (int j = 0; j < 16; j++) s1 += (double) v[j];
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wave] = s1;
+        __syncthreads();
+        const float mean = (float) (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double) K);
+        double s2 = 0.0;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) { const float u = v[j] - mean; v[j] = u; if (mine) s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wave] = s2;
+        __syncthreads();
+        const float var = (float) (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double) K);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float u = v[j] * scale;
+            u = u * a.ln_g[k0 + j];
+            if constexpr (LNB) u = u + a.ln_b[k0 + j];
+            v[j] = u;
+        }
+    }
+    if (mine) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(xs + k0 + 4 * i) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    #pragma unroll 4
+    for (int q = c; q < nchunk; q += 16) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow + (q << 3)), w1 = *reinterpret_cast<const float4 *>(wrow + (q << 3) + 4);
+        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (q << 3)), x1 = *reinterpret_cast<const float4 *>(xs + (q << 3) + 4);
+        acc = fmaf(w0.x, x0.x, acc); acc = fmaf(w0.y, x0.y, acc); acc = fmaf(w0.z, x0.z, acc); acc = fmaf(w0.w, x0.w, acc);
+        acc = fmaf(w1.x, x1.x, acc); acc = fmaf(w1.y, x1.y, acc); acc = fmaf(w1.z, x1.z, acc); acc = fmaf(w1.w, x1.w, acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+}
+// rows (N > 1): x_f32 holds N rows of length K (already LayerNorm-ed where the operator has one)
+template <int NB>
+__global__ __launch_bounds__(64) void gemm_w32_rows_kernel(const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int n0 = blockIdx.y * NB;
+    const int K = a.K, nchunk = K >> 3;
+    const bool live = m < a.M;
+    const float * wrow = reinterpret_cast<const float *>(a.wq.qs) + (size_t) (live ? m : 0) * K;
+    float acc[NB];
+    #pragma unroll
+    for (int i = 0; i < NB; i++) acc[i] = 0.0f;
+    for (int q = c; q < nchunk; q += 16) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow + (q << 3)), w1 = *reinterpret_cast<const float4 *>(wrow + (q << 3) + 4);
+        #pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int n = min(n0 + i, a.N - 1);
+            const float * xr = a.x_f32 + (size_t) n * K + (q << 3);
+            const float4 x0 = *reinterpret_cast<const float4 *>(xr), x1 = *reinterpret_cast<const float4 *>(xr + 4);
+            float r = acc[i];
+            r = fmaf(w0.x, x0.x, r); r = fmaf(w0.y, x0.y, r); r = fmaf(w0.z, x0.z, r); r = fmaf(w0.w, x0.w, r);
+            r = fmaf(w1.x, x1.x, r); r = fmaf(w1.y, x1.y, r); r = fmaf(w1.z, x1.z, r); r = fmaf(w1.w, x1.w, r);
+            acc[i] = r;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const float r = wave_xor_add16(acc[i]);
+        if (live && c == 0 && n0 + i < a.N) linear_epilogue(a, n0 + i, m, r, 0);
+    }
+}
+static void launch_linear_w32(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in f32 linear op\n", a.K); abort(); }
+    if (a.batched || !a.x_f32) { fprintf(stderr, "bark-hip: f32-weight products take f32 rows, one sequence at a time\n"); abort(); }
+    if (a.N == 1) {
+        dim3 grid((a.M + 15) / 16), block(256);
+        if (a.ln_g) {
+            if (a.ln_b) hipLaunchKernelGGL((gemv_w32_kernel<true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_w32_kernel<true, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((gemv_w32_kernel<false, false>), grid, block, 0, s, a);
+        return;
+    }
+    if (a.ln_g || a.parity_rows) { fprintf(stderr, "bark-hip: f32 row product needs LayerNorm-ed rows\n"); abort(); }
+    constexpr int NB = 8;
+    dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
+    hipLaunchKernelGGL((gemm_w32_rows_kernel<NB>), grid, block, 0, s, a);
+}
+
 void launch_linear(hipStream_t s, const LinArgs & a) {
+    if (a.wq.qs && a.wq.qt == QT_F32) { launch_linear_w32(s, a); return; }
     if (a.wq.qs) { launch_linear_q(s, a); return; }
     if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
     if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
@@ -1136,6 +1256,32 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float * x, int N, i
 }
 void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats) {
     hipLaunchKernelGGL(ln_stats_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, stats);
+}
+// the same LayerNorm without the f16 rounding of the result: input of products with f32 weights
+__global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float * x, int N, int E, const float * g, const float * b, float * out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    float * o = out + (size_t) row * E;
+    for (int e = lane; e < E; e += 64) {
+        float v = (xr[e] - mean) * scale;
+        v = v * g[e];
+        if (b) v = v + b[e];
+        o[e] = v;
+    }
+}
+void launch_ln_rows_f32(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, float * out) {
+    hipLaunchKernelGGL(ln_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);
 }
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
     hipLaunchKernelGGL(ln_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);

@@ -14,7 +14,8 @@
 
 namespace barkhip {
 
-enum QuantId : int { QT_Q4_0 = 0, QT_Q4_1 = 1, QT_Q5_0 = 2, QT_Q5_1 = 3, QT_Q8_0 = 4, QT_COUNT = 5 };
+enum QuantId : int { QT_Q4_0 = 0, QT_Q4_1 = 1, QT_Q5_0 = 2, QT_Q5_1 = 3, QT_Q8_0 = 4, QT_COUNT = 5,
+                     QT_F32 = 16 };      // not a block format: plain f32 weights (f32 model files) travelling through the same QMat handle
 
 struct QuantFormat {
     int id; int ggml_type; int ggml_ftype; int block_bytes; bool has_min; bool has_high_bits; int qs_bytes; const char * name;

@@ -355,22 +355,39 @@ static bool load_codec(Reader & r, Codec & c) {
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s\n", n.c_str()); return false; }
         out = to_f32(it->second); return true;
     };
+    // f32 codec files (convert.py without --use-f16): the decoder of this restatement (and of the engine) runs in the f16-weight
+    // arithmetic - conv kernels meet an f16 im2col in ggml's mul_mat, which converts the f32 operand to f16 anyway; for the LSTM
+    // matrices the same rounding is a stated simplification (the un-vendored encodec.cpp cannot be consulted).
+    auto f16_bits = [](const Tensor & t) {
+        std::vector<uint16_t> h((size_t) t.nelements());
+        for (size_t i = 0; i < h.size(); i++) h[i] = f2h(ld_f32(t.data, i));
+        return h;
+    };
     auto getw = [&](const std::string & n, CanonW & out) {
         auto it = tens.find(n);
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s\n", n.c_str()); return false; }
+        if (it->second.ttype == 0) {
+            const std::vector<uint16_t> h = f16_bits(it->second);
+            out.build((const uint8_t *) h.data(), true, (int) it->second.ne[1], (int) it->second.ne[0]); return true;
+        }
         out.build(it->second.data, it->second.ttype == 1, (int) it->second.ne[1], (int) it->second.ne[0]); return true;
+    };
+    auto getcw = [&](const std::string & n, std::vector<float> & out) {          // conv / convtr kernels
+        if (!get(n, out)) return false;
+        if (tens.find(n)->second.ttype == 0) for (float & v : out) v = round_h(v);
+        return true;
     };
     auto conv = [&](const std::string & p, Conv & cv) {
         auto it = tens.find(p + ".weight");
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s.weight\n", p.c_str()); return false; }
         cv.k = (int) it->second.ne[0]; cv.cin = (int) it->second.ne[1]; cv.cout = (int) it->second.ne[2];
-        return get(p + ".weight", cv.w) && get(p + ".bias", cv.b) && (int) cv.b.size() == cv.cout;
+        return getcw(p + ".weight", cv.w) && get(p + ".bias", cv.b) && (int) cv.b.size() == cv.cout;
     };
     auto convt = [&](const std::string & p, ConvT & cv, int stride) {
         auto it = tens.find(p + ".weight");
         if (it == tens.end()) { fprintf(stderr, "oracle: missing codec tensor %s.weight\n", p.c_str()); return false; }
         cv.k = (int) it->second.ne[0]; cv.cout = (int) it->second.ne[1]; cv.cin = (int) it->second.ne[2]; cv.stride = stride;
-        return get(p + ".weight", cv.w) && get(p + ".bias", cv.b) && (int) cv.b.size() == cv.cout;
+        return getcw(p + ".weight", cv.w) && get(p + ".bias", cv.b) && (int) cv.b.size() == cv.cout;
     };
     bool ok = conv("decoder.model.0.conv.conv", c.init);
     for (int l = 0; l < 2 && ok; l++) {
@@ -628,7 +645,7 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
     float * xn = o.xn.p, * qkv = o.qkv.p, * att = o.att.p, * fc = o.fc.p, * tmp = o.tmp.p;
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln1_g.data(), L.ln1_b.empty() ? nullptr : L.ln1_b.data());
-    if (!L.attn_w.q4) round_rows(o, xn, (size_t) N * E);     // f16 weights: activation -> f16; q4_0 weights: activation -> q8_0 inside the product
+    if (L.attn_w.f16) round_rows(o, xn, (size_t) N * E);     // f16 weights: activation -> f16; quantised weights: activation -> q8 inside the product; f32 weights: f32 x f32
     gemm_w(o, L.attn_w, xn, E, qkv, 3 * E, 3 * E, N, E, nth);
     add_bias_rows(qkv, 3 * E, N, 3 * E, L.attn_b);
 
@@ -650,17 +667,17 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
         attention(o, qkv, 3 * E, kc, vc, att, N, N, 0, false, E, H, nth);
     }
 
-    if (!L.proj_w.q4) round_rows(o, att, (size_t) N * E);
+    if (L.proj_w.f16) round_rows(o, att, (size_t) N * E);
     gemm_w(o, L.proj_w, att, E, tmp, E, E, N, E, nth);
     add_bias_rows(tmp, E, N, E, L.proj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpL  (bark.cpp:1352)
 
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln2_g.data(), L.ln2_b.empty() ? nullptr : L.ln2_b.data());
-    if (!L.fc_w.q4) round_rows(o, xn, (size_t) N * E);
+    if (L.fc_w.f16) round_rows(o, xn, (size_t) N * E);
     gemm_w(o, L.fc_w, xn, E, fc, 4 * E, 4 * E, N, E, nth);
     add_bias_rows(fc, 4 * E, N, 4 * E, L.fc_b);
     for (size_t i = 0; i < (size_t) N * 4 * E; i++) fc[i] = gelu_apply(o, fc[i]);
-    if (!L.mproj_w.q4) round_rows(o, fc, (size_t) N * 4 * E);
+    if (L.mproj_w.f16) round_rows(o, fc, (size_t) N * 4 * E);
     gemm_w(o, L.mproj_w, fc, 4 * E, tmp, E, E, N, 4 * E, nth);
     add_bias_rows(tmp, E, N, E, L.mproj_b);
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpFF (bark.cpp:1388)
@@ -715,7 +732,7 @@ static bool gpt_eval(Oracle & o, Gpt & m, const int32_t * tokens, int n_tokens, 
     // final norm + LM head on the last row only (bark.cpp:1391-1405)
     std::vector<float> last(E);
     layer_norm_row(x + (size_t) (N - 1) * E, last.data(), E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
-    if (!m.lm_heads[0].q4) round_rows(o, last.data(), E);
+    if (m.lm_heads[0].f16) round_rows(o, last.data(), E);
     gemm_w(o, m.lm_heads[0], last.data(), E, logits, m.n_out, m.n_out, 1, E, nth);
     *n_past += N;
     m.t_predict_us += now_us() - t0;
@@ -747,7 +764,7 @@ static bool fine_eval(Oracle & o, const int32_t * tokens, int nn, float * logits
     for (int il = 0; il < m.n_layer; il++) block_forward(o, m, il, x, N, 0, false, nth);
     o.xn.ensure((size_t) N * E);
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, o.xn.p + (size_t) i * E, E, m.lnf_g.data(), m.lnf_b.empty() ? nullptr : m.lnf_b.data());
-    if (!m.lm_heads[nn - 1].q4) round_rows(o, o.xn.p, (size_t) N * E);
+    if (m.lm_heads[nn - 1].f16) round_rows(o, o.xn.p, (size_t) N * E);
     gemm_w(o, m.lm_heads[nn - 1], o.xn.p, E, logits, m.n_out, m.n_out, N, E, nth);   // lm_heads[codebook_idx - n_codes_given]
     m.t_predict_us += now_us() - t0;
     return true;

@@ -98,3 +98,15 @@ def mini_q4_oracle(mini_q4_model):
     o = Oracle(mini_q4_model, n_threads=4)
     yield o
     o.close()
+
+
+@pytest.fixture(scope="session")
+def toy_f32_model(toy_model):
+    """the same synthetic draws written as an f32 file (convert.py without --use-f16: every tensor f32, codec included)"""
+    from tools.make_synth_model import write_model
+    dst = os.path.join(os.path.dirname(toy_model), "bark_toy_s0_f32.bin")
+    if not os.path.exists(dst):
+        tmp = dst + ".tmp%d" % os.getpid()
+        write_model(tmp, "toy", 0, use_f16=False)
+        os.replace(tmp, dst)
+    return dst

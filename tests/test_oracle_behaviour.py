@@ -85,3 +85,19 @@ def test_fine_stage_windows_beyond_1024_frames(toy_oracle):
     assert np.array_equal(full[:512], head[:512])
     assert full[:, 2:].min() >= 0 and full[:, 2:].max() < 1024
     assert not np.array_equal(full[512:1024], head[512:1024])          # window 1 saw different context
+
+
+def test_f32_model_file_is_restated(toy_f32_model, toy_oracle):
+    """f32 files: no activation rounding in front of f32 weights, so the logits differ (slightly) from the f16 file's."""
+    from oracle.pyoracle import Oracle
+    o = Oracle(toy_f32_model, n_threads=4)
+    try:
+        assert o.hparams(0)["ftype"] == 0 and o.hparams(2)["n_wtes"] == 8
+        toks = np.arange(40, dtype=np.int32) * 37 % 10000
+        a, _ = o.gpt_eval(1, toks, 0, False)
+        b, _ = toy_oracle.gpt_eval(1, toks, 0, False)
+        assert not np.array_equal(a, b) and np.corrcoef(a, b)[0, 1] > 0.9999
+        r = o.generate("hello", o.params(n_steps_text_encoder=8))
+        assert r["n_frames"] == 12 and np.all(np.isfinite(r["pcm"]))
+    finally:
+        o.close()
