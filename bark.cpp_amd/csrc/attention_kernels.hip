@@ -1,0 +1,604 @@
+// attention_kernels.hip - attention over the f32 KV cache: single-query decode kernels (orders C2 / C4 / C5 on VALU) and the
+// multi-query prefill / fine kernels (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
+#include "device_utils.h"
+
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+
+namespace barkhip {
+
+// ------------------------------------------------------------------------------------------------
+// decode attention, two launches so that the key stream is spread over the whole chip:
+//   attn_scores_kernel : one wave per 64 keys and head (grid P/64 x H); lane = key, C2 = one fmaf chain
+//                        over d; the K cache is d-quad major, so a wave's 16-byte loads are contiguous.
+//   attn_mix_kernel    : one workgroup (16 waves) per head: softmax statistics over the score row
+//                        (max, e = (float) exp((double)(s - max)), double sum), then wave c owns chain c
+//                        of C5 (keys c, c+16, ...), lane = d; the 16 chains meet in LDS (tree order).
+// Every load is issued before the arithmetic that needs the previous one.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_scores_kernel(const AttnDecodeArgs a) {
+    const int h = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    const int P = a.P;
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + j;     // j < P: always inside the cache
+    float4 kv[16];
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    const int ctx = a.st->n_past + 1;
+    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
+    float acc = 0.0f;
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) {
+        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
+        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
+        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
+        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
+    }
+    const float sc = acc * 0.125f;                                       // 1/sqrt(64), bark.cpp:1318
+    if (j < ctx) a.scores[(size_t) h * P + j] = sc;
+    // row maximum for the softmax, kept exactly with an integer atomic (a.hmax[h] is reset by attn_mix_kernel)
+    const float wmax = wave_max(j < ctx ? sc : -INFINITY);
+    if (threadIdx.x == 0 && blockIdx.x * 64 < ctx) atomicMax(a.hmax + h, f32_ordered(wmax));
+}
+
+__global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ double red_d[16];
+    __shared__ float part[16][64];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const int ctx = a.st->n_past + 1;
+    const float sraw = a.scores[(size_t) h * P + tid];                // tid < P; garbage beyond ctx is masked below
+    const float mx = f32_unordered(a.hmax[h]);
+    const float * vp = a.vc + (size_t) h * P * 64 + lane;
+    float vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (wave + 16 * (16 * g + i)) * 64];   // row < P
+        }
+    }
+    float e = 0.0f;
+    if (tid < ctx) e = (float) exp((double) (sraw - mx));
+    es[tid] = e;
+    const double wsum = wave_sum((double) e);
+    if (lane == 0) red_d[wave] = wsum;
+    __syncthreads();
+    if (tid == 0) a.hmax[h] = 0u;                                      // below every encoded float: ready for the next layer
+    double sum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) sum += red_d[i];
+    const float inv = (float) (1.0 / sum);
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) { const int j = wave + 16 * (16 * g + i); if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc); }
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        if (a.att32) a.att32[h * 64 + tid] = p[0]; else a.att[h * 64 + tid] = to_half(p[0]);
+    }
+}
+// ------------------------------------------------------------------------------------------------
+// Fused decode attention: ONE launch, one 256-thread workgroup (4 waves, one per SIMD, up to 512
+// registers each) per head.  With a 1.7 us launch floor a second launch costs more than pulling the
+// head's K rows through the same CU, so scores, softmax and mix share a kernel:
+//   scores : thread t owns keys t, t+256, t+512, t+768 (C2: one fmaf chain over d per key)
+//   softmax: row max / double sum through LDS (two barriers)
+//   mix    : wave w, 16-lane group g own chain c = 4w+g of C5; lane&15 owns 4 adjacent dims (float4 V
+//            loads, so one instruction covers four keys); the 16 chains meet in LDS (tree order)
+// K is loaded two 256-key groups ahead, every V row group of the live context is requested before the
+// first arithmetic instruction.
+// ------------------------------------------------------------------------------------------------
+template <int G> DEVINL void load_k_group(float4 (&kv)[16], const float4 * kp, int P) {
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P + 256 * G];
+}
+DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) {
+    float acc = 0.0f;
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) {
+        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
+        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
+        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
+        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
+    }
+    return acc * 0.125f;                                      // 1/sqrt(64), bark.cpp:1318
+}
+__global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    __shared__ float part[16][64];
+    const int h = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const int E = a.H * 64;
+    const float * __restrict__ qh = a.q + (size_t) slot * E + h * 64;            // wave-uniform: scalar loads
+    const float * kc = a.kc + (size_t) slot * a.kv_slot_stride, * vc = a.vc + (size_t) slot * a.kv_slot_stride;
+    const float4 * kp = reinterpret_cast<const float4 *>(kc) + (size_t) h * 16 * P + tid;
+    const int chain = 4 * wave + (lane >> 4), d4 = lane & 15;
+    const float4 * vp = reinterpret_cast<const float4 *>(vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;   // row `chain`, dims 4*d4..
+    float4 k0[16], k1[16];
+    load_k_group<0>(k0, kp, P);                                // keys 0..255: always inside the cache
+    const int ctx = a.st[slot].n_past + 1;
+    if (ctx > 256) load_k_group<1>(k1, kp, P);
+    float4 vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 256];     // key chain + 16*(16g+i): 16 rows = 256 float4
+        }
+    }
+    float s[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    { const float v = score_chain(k0, qh); if (tid < ctx) s[0] = v; }
+    if (ctx > 512) load_k_group<2>(k0, kp, P);
+    if (ctx > 256) { const float v = score_chain(k1, qh); if (tid + 256 < ctx) s[1] = v; }
+    if (ctx > 768) load_k_group<3>(k1, kp, P);
+    if (ctx > 512) { const float v = score_chain(k0, qh); if (tid + 512 < ctx) s[2] = v; }
+    if (ctx > 768) { const float v = score_chain(k1, qh); if (tid + 768 < ctx) s[3] = v; }
+    float mx = wave_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = tid + 256 * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    const float inv = (float) (1.0 / sum);
+    float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int j = chain + 16 * (16 * g + i);
+                if (j < ctx) {
+                    const float p = es[j] * inv;               // p = e * (float)(1/sum), as ggml_soft_max scales in place
+                    const float4 v = vv[16 * g + i];
+                    acc.x = fmaf(v.x, p, acc.x); acc.y = fmaf(v.y, p, acc.y); acc.z = fmaf(v.z, p, acc.z); acc.w = fmaf(v.w, p, acc.w);
+                }
+            }
+        }
+    }
+    *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        if (a.att32) a.att32[(size_t) slot * E + h * 64 + tid] = p[0]; else a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention spread over ATTN_SPLIT workgroups per head, without any cross-workgroup traffic.
+// One CU streams a head's K and V rows at only ~40-65 GB/s (attn_fused_kernel: two dependent load
+// rounds, 512 B per key), and 12 heads leave 244 CUs idle for the longest kernel of the step.
+// Workgroup (h, s) scores ALL keys of head h (every workgroup repeats the C2 chains and the softmax
+// statistics in the same order, so all of them hold identical bits) but mixes only the value dims
+// [16 s, 16 s + 16) - with all 16 C5 chains, so the tree is local.  Per workgroup that is 256 + 64
+// instead of 512 bytes per key, all of them requested up front (one memory round trip; the
+// workgroup's four waves sit alone on their SIMDs, so ~350 VGPRs per lane are available).
+// A variant that also split the keys and exchanged scores through agent-scope atomics measured
+// 10.7 us vs 8.2 us fused at ctx 641: each cross-XCD hop costs ~2 us.
+// ------------------------------------------------------------------------------------------------
+constexpr int ATTN_SPLIT = 4;
+__global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    __shared__ float part[16][16];
+    const int h = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float * __restrict__ qh = a.q + h * 64;
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+    const int chain = tid >> 4, d = tid & 15;
+    const float * vp = a.vc + ((size_t) h * P + chain) * 64 + 16 * s + d;        // key `chain`, value dim 16 s + d
+    const int ctx = a.st->n_past + 1;
+    float4 k0[16], k1[16], k2[16], k3[16];
+    load_k_group<0>(k0, kp, P);
+    if (ctx > 256) load_k_group<1>(k1, kp, P);
+    if (ctx > 512) load_k_group<2>(k2, kp, P);
+    if (ctx > 768) load_k_group<3>(k3, kp, P);
+    float vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];     // key chain + 16 (16 g + i)
+        }
+    }
+    float sv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    { const float v = score_chain(k0, qh); if (tid < ctx) sv[0] = v; }
+    if (ctx > 256) { const float v = score_chain(k1, qh); if (tid + 256 < ctx) sv[1] = v; }
+    if (ctx > 512) { const float v = score_chain(k2, qh); if (tid + 512 < ctx) sv[2] = v; }
+    if (ctx > 768) { const float v = score_chain(k3, qh); if (tid + 768 < ctx) sv[3] = v; }
+    float mx = wave_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = tid + 256 * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (sv[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    const float inv = (float) (1.0 / sum);
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int j = chain + 16 * (16 * g + i);
+                if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc);
+            }
+        }
+    }
+    part[chain][d] = acc;
+    __syncthreads();
+    if (tid < 16) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        const int o = h * 64 + 16 * s + tid;
+        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
+    }
+}
+
+void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
+    if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
+    if (parts == 5) {
+        if (a.nbatch != 1 || a.P != 1024) { fprintf(stderr, "bark-hip: value-sliced decode attention needs one sequence and block_size 1024\n"); abort(); }
+        hipLaunchKernelGGL(attn_dslice_kernel, dim3(a.H, ATTN_SPLIT), dim3(256), 0, s, a);
+        return;
+    }
+    if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
+    if (parts & 2) hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
+}
+void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
+    static const bool split = getenv("BARK_HIP_ATTN_SPLIT") != nullptr;      // two-launch variant kept for A/B timing
+    static const bool one_wg = getenv("BARK_HIP_ATTN_ONE_WG") != nullptr;    // one workgroup per head (A/B timing)
+    if (split) { launch_attn_decode_part(s, a, 3); return; }
+    // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
+    const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
+    launch_attn_decode_part(s, a, can_split ? 5 : 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prefill / fine attention (materialised scores): S = scale * Q K^T on the f32 matrix cores (C2 = one
+// MFMA accumulator chain over d), row softmax, O = P V on the f32 matrix cores (C5: 16 chains in
+// 8 waves x 2 accumulator sets, LDS tree).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_qk_kernel(const AttnPrefillArgs a) {
+    // workgroup tile 128 queries x 128 keys; wave (wi, wj) owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles, so every
+    // 16-byte operand load feeds four MFMAs
+    const int h = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int ctx = a.n_past + a.N;
+    if (j0 >= ctx) return;
+    if (a.causal && j0 > a.n_past + i0 + 127) return;       // tile entirely masked
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wi = w >> 1, wj = w & 1;
+    const float4 * qp[2]; const float4 * kp[2];
+    #pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int irow = min(i0 + wi * 64 + t * 32 + l31, a.N - 1);
+        const int jrow = min(j0 + wj * 64 + t * 32 + l31, ctx - 1);
+        qp[t] = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
+        kp[t] = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
+    }
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    #pragma unroll 4
+    for (int dq = 0; dq < 16; dq++) {
+        float4 qv[2], kv[2];
+        #pragma unroll
+        for (int t = 0; t < 2; t++) { qv[t] = qp[t][dq]; kv[t] = kp[t][(size_t) dq * a.P]; }
+        // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].y : qv[i].x, half ? kv[j].y : kv[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].w : qv[i].z, half ? kv[j].w : kv[j].z, acc[i][j], 0, 0, 0);
+            }
+    }
+    // A operand = Q (accumulator rows = queries i), B operand = K (accumulator cols = keys j: coalesced stores)
+    #pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+        #pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wi * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int j = j0 + wj * 64 + tj * 32 + l31;
+                if (i < a.N && j < ctx) a.scores[((size_t) h * a.N + i) * a.P + j] = acc[ti][tj][r] * 0.125f;    // 1/sqrt(64), bark.cpp:1318
+            }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const AttnPrefillArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);     // row = h * N + i
+    if (row >= a.H * a.N) return;
+    const int i = row % a.N;
+    const int ctx = a.n_past + a.N;
+    const int valid = a.causal ? min(ctx, a.n_past + i + 1) : ctx;
+    float * s = a.scores + (size_t) row * a.P;
+    float mx = -INFINITY;
+    for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
+    mx = wave_max(mx);
+    double sum = 0.0;
+    for (int j = lane; j < valid; j += 64) { const float e = (float) exp((double) (s[j] - mx)); s[j] = e; sum += (double) e; }
+    sum = wave_sum(sum);
+    const float inv = (float) (1.0 / sum);
+    for (int j = lane; j < valid; j += 64) s[j] = s[j] * inv;
+    const int ctx32 = min((ctx + 31) & ~31, a.P);
+    for (int j = valid + lane; j < ctx32; j += 64) s[j] = 0.0f;          // masked keys: p == 0
+}
+
+__global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
+    __shared__ float part[8][32][64];
+    const int h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctx = a.n_past + a.N;
+    const int irow = min(i0 + l31, a.N - 1);
+    // causal: rows of this tile see keys <= n_past + i0 + 31
+    const int jend = a.causal ? min(ctx, a.n_past + i0 + 32) : ctx;
+    const float * prow = a.scores + ((size_t) h * a.N + irow) * a.P;
+    const float * vbase = a.vc + (size_t) h * a.P * 64;
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
+    const int jlim = (jend + 1) & ~1;                            // P rows are zero-filled up to a multiple of 32 keys
+    #pragma unroll 2
+    for (int jb = 0; jb < jend; jb += 32) {
+        const int j = jb + 2 * w + 16 * half;                   // chains 2w, 2w+1: keys j, j+1 (this half-wave's k slot)
+        const bool ok = j < jlim;
+        const float2 p2 = ok ? *reinterpret_cast<const float2 *>(prow + j) : float2{0.0f, 0.0f};
+        #pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const bool oks = j + s < jend;
+            const float pv = s ? p2.y : p2.x;
+            #pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float vv = oks ? vbase[(size_t) (j + s) * 64 + t * 32 + l31] : 0.0f;
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(oks ? pv : 0.0f, vv, acc[s][t], 0, 0, 0);
+            }
+        }
+    }
+    #pragma unroll
+    for (int t = 0; t < 2; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            part[w][row][t * 32 + l31] = acc[0][t][r] + acc[1][t][r];
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 512) {
+        const int row = idx >> 6, d = idx & 63;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = part[q][row][d];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        const int i = i0 + row;
+        if (i < a.N) { if (a.att32) a.att32[(size_t) i * a.ld_att + h * 64 + d] = v; else a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused prefill / fine attention: one workgroup (8 waves) per (head, 32-query tile); the 32 x ctx score tile
+// lives in LDS (row stride 1026 floats: conflict-free column reads), so scores never travel through HBM:
+//   1. S = 0.125 * Q K^T   f32 MFMA, wave w takes key tiles w, w+8, ... (C2: one accumulator chain over d)
+//   2. row softmax in LDS   (4 rows per wave; max, e = (float) exp((double)(s - max)), double sum)
+//   3. O = P V              f32 MFMA, wave w owns chains 2w, 2w+1 of C5; p = e * inv formed at the operand read
+//   4. the 16 chains meet in LDS (aliasing the score tile) in tree order
+// ------------------------------------------------------------------------------------------------
+constexpr int ATT_LD = 1026;
+__global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // [32][ATT_LD] scores, then [8][32][64] partial sums
+    __shared__ float rowinv[32];
+    const int h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctx = a.n_past + a.N;
+    // keys this tile can see: causal rows of the tile end at n_past + i0 + 31
+    const int jend = a.causal ? min(ctx, a.n_past + i0 + 32) : ctx;
+    const int jend32 = (jend + 31) & ~31;
+    // ---- 1. scores -------------------------------------------------------------------------------------
+    {
+        const int irow = min(i0 + l31, a.N - 1);
+        const float4 * qp = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
+        float4 qv[16];
+        #pragma unroll
+        for (int dq = 0; dq < 16; dq++) qv[dq] = qp[dq];
+        auto load_k = [&](float4 (&kv)[16], int jt) {
+            const int jrow = min(jt + l31, ctx - 1);
+            const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * a.P];
+        };
+        auto score_tile = [&](const float4 (&kv)[16], int jt) {
+            floatx16 acc;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].y : qv[dq].x, half ? kv[dq].y : kv[dq].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].w : qv[dq].z, half ? kv[dq].w : kv[dq].z, acc, 0, 0, 0);
+            }
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;       // accumulator row = query, column = key
+                lds[i * ATT_LD + jt + l31] = acc[r] * 0.125f;            // 1/sqrt(64), bark.cpp:1318
+            }
+        };
+        // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs
+        float4 ka[16], kb[16];
+        int jt = w * 32;
+        if (a.dbg & 1) jt = jend;
+        if (jt < jend) load_k(ka, jt);
+        for (; jt < jend; jt += 512) {
+            const bool more = jt + 256 < jend;
+            if (more) load_k(kb, jt + 256);
+            __builtin_amdgcn_sched_barrier(0);
+            score_tile(ka, jt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (jt + 512 < jend) load_k(ka, jt + 512);
+                __builtin_amdgcn_sched_barrier(0);
+                score_tile(kb, jt + 256);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. softmax, rows 4w .. 4w+3 ---------------------------------------------------------------------
+    #pragma unroll 1
+    for (int rr = 0; rr < 4; rr++) {
+        const int il = 4 * w + rr, i = i0 + il;
+        float * s = lds + il * ATT_LD;
+        const int valid = i < a.N ? (a.causal ? min(ctx, a.n_past + i + 1) : ctx) : 0;
+        float mx = -INFINITY;
+        for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
+        mx = wave_max(mx);
+        // four independent exp evaluations per lane and trip: the double-precision exp is a long dependent chain
+        double sum4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = lane; j < valid; j += 256) {
+            float e[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? ((a.dbg & 2) ? s[j + 64 * u] - mx : (float) exp((double) (s[j + 64 * u] - mx))) : 0.0f;
+            #pragma unroll
+            for (int u = 0; u < 4; u++) if (j + 64 * u < valid) { s[j + 64 * u] = e[u]; sum4[u] += (double) e[u]; }
+        }
+        const double sum = wave_sum((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
+        for (int j = valid + lane; j < jend32; j += 64) s[j] = 0.0f;   // masked keys: p == 0
+        if (lane == 0) rowinv[il] = valid ? (float) (1.0 / sum) : 0.0f;
+    }
+    __syncthreads();
+    // ---- 3. mix ------------------------------------------------------------------------------------------
+    const float inv = rowinv[l31];
+    const float * prow = lds + l31 * ATT_LD;
+    const float * vbase = a.vc + (size_t) h * a.P * 64;
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
+    // batches of 8 key blocks (256 keys): the V rows and probabilities of batch b+1 are requested before the 32 MFMAs
+    // of batch b issue (static double buffer; per-lane key slot j = jb + 2w + 16*half, chains 2w and 2w+1)
+    float va[8][2][2], vb[8][2][2];
+    float2 ea[8], eb[8];
+#define ATT_LOAD_BATCH(V, E, JB0)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                      \
+        const int j = (JB0) + 32 * u + 2 * w + 16 * half;                                                \
+        const int jc = min(j, jend32 - 2);                                                               \
+        E[u] = *reinterpret_cast<const float2 *>(prow + jc);                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                  \
+            const int jr = min(j + s, ctx - 1);                                                          \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) V[u][s][t] = vbase[(size_t) jr * 64 + t * 32 + l31]; \
+        }                                                                                                \
+    }
+#define ATT_MFMA_BATCH(V, E, JB0)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                                      \
+        const int j = (JB0) + 32 * u + 2 * w + 16 * half;                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                  \
+            const bool oks = j + s < jend;                                                               \
+            const float pv = oks ? (s ? E[u].y : E[u].x) * inv : 0.0f;      /* p = e * (float)(1/sum) */ \
+            _Pragma("unroll") for (int t = 0; t < 2; t++)                                                \
+                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, oks ? V[u][s][t] : 0.0f, acc[s][t], 0, 0, 0); \
+        }                                                                                                \
+    }
+    const int jstop = (a.dbg & 4) ? 0 : jend;
+    if (jstop > 0) { ATT_LOAD_BATCH(va, ea, 0) }
+    for (int jb = 0; jb < jstop; jb += 512) {
+        const bool more = jb + 256 < jstop;
+        if (more) { ATT_LOAD_BATCH(vb, eb, jb + 256) }
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_MFMA_BATCH(va, ea, jb)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (jb + 512 < jstop) { ATT_LOAD_BATCH(va, ea, jb + 512) }
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MFMA_BATCH(vb, eb, jb + 256)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef ATT_LOAD_BATCH
+#undef ATT_MFMA_BATCH
+    __syncthreads();                                             // every wave is done reading the score tile
+    float * part = lds;                                          // [8][32][64]
+    #pragma unroll
+    for (int t = 0; t < 2; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            part[(w * 32 + row) * 64 + t * 32 + l31] = acc[0][t][r] + acc[1][t][r];
+        }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += 512) {
+        const int row = idx >> 6, d = idx & 63;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = part[(q * 32 + row) * 64 + d];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        const int i = i0 + row;
+        if (i < a.N) { if (a.att32) a.att32[(size_t) i * a.ld_att + h * 64 + d] = v; else a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v); }
+    }
+}
+
+void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
+    static const bool materialised = getenv("BARK_HIP_ATTN_MATERIALISED") != nullptr;   // three-kernel variant kept for A/B checks
+    if (!materialised) {
+        hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
+        return;
+    }
+    const int ctx = a.n_past + a.N;
+    hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 127) / 128, (a.N + 127) / 128, a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.H * a.N + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_pv_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 0, s, a);
+}
+
+
+void init_attention_attributes() {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(attn_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               32 * ATT_LD * (int) sizeof(float));
+}
+
+}  // namespace barkhip

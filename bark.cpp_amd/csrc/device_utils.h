@@ -1,0 +1,154 @@
+// device_utils.h - device-side helpers shared by the GPT kernel files: wave64 DPP reductions in the canonical tree order,
+// the explicit f16 rounding point, ggml's GELU table lookup, KV-cache addressing, embedding-row reads and the fused
+// epilogues of the linear operators (bias / residual / GELU / KV append / logits).  See DESIGN.md section 3 for the numerics.
+#pragma once
+#include "kernels.h"
+
+namespace barkhip {
+
+
+typedef float  floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define DEVINL __device__ __forceinline__
+
+// Sums over the 16 lanes of a DPP row in the C1/C5 tree order (partner xor 1, 2, 4, 8).  After the
+// xor-1 / xor-2 quad permutes every lane of a quad holds the quad sum, so the half-row mirror (lane i
+// <- 7-i) and the row mirror (lane i <- 15-i) deliver exactly the xor-4 / xor-8 partner sums; fp add is
+// commutative, so every lane ends with the same bits as the butterfly.  DPP moves cost one VALU op,
+// ds_bpermute-based __shfl_xor costs an LDS round trip per stage.
+template <int CTRL> DEVINL float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> DEVINL double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) u, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (u >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+DEVINL float wave_xor_add16(float v) {
+    v = v + dpp_f32<DPP_XOR1>(v);
+    v = v + dpp_f32<DPP_XOR2>(v);
+    v = v + dpp_f32<DPP_HALF_MIRROR>(v);
+    v = v + dpp_f32<DPP_MIRROR>(v);
+    return v;
+}
+DEVINL double group16_sum(double v) {
+    v += dpp_f64<DPP_XOR1>(v); v += dpp_f64<DPP_XOR2>(v); v += dpp_f64<DPP_HALF_MIRROR>(v); v += dpp_f64<DPP_MIRROR>(v);
+    return v;
+}
+DEVINL float readlane_f32(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+DEVINL double readlane_f64(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, lane);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+// whole-wave reductions: DPP inside each 16-lane row, then the four row results through SGPRs
+DEVINL double wave_sum(double v) {
+    v = group16_sum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+DEVINL float wave_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+// order-preserving float <-> unsigned map, so that the row maximum can be kept with an integer atomicMax
+DEVINL unsigned f32_ordered(float f) { const unsigned b = __builtin_bit_cast(unsigned, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+DEVINL float f32_unordered(unsigned u) { const unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; return __builtin_bit_cast(float, b); }
+DEVINL half8 ld_half8(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
+// f32 -> f16, round to nearest even, of an ALREADY ROUNDED f32 value.  The empty asm keeps hipcc from
+// folding the producing multiply/add into v_fma_mixlo_f16, which rounds the exact result once and
+// differs from the CPU's two roundings in about one of 2^13 cases.
+DEVINL half_t to_half(float v) { asm("" : "+v"(v)); return (half_t) v; }
+
+// ggml_gelu on the CPU backend: f16 lookup table, pass-through outside (-10, 10)
+DEVINL half_t gelu_lut_apply(float v, const uint16_t * lut) {
+    if (v <= -10.0f) return (half_t) 0.0f;
+    if (v >= 10.0f) return to_half(v);
+    const half_t hv = to_half(v);                         // round to nearest even
+    const uint16_t bits = __builtin_bit_cast(uint16_t, hv);
+    return __builtin_bit_cast(half_t, lut[bits]);
+}
+
+// one element of an embedding row: f16 table, or a quantised table dequantised as ggml_get_rows does (level * d (+ m))
+DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e) {
+    if (!q.qs) return (float) wte[(size_t) tok * E + e];
+    if (q.qt == QT_F32) return reinterpret_cast<const float *>(q.qs)[(size_t) tok * E + e];
+    const size_t blk = (size_t) tok * (E >> 5) + (e >> 5);
+    const int j = e & 31;
+    const float d = (float) q.d[blk];
+    if (q.qt == QT_Q8_0) return (float) (int) reinterpret_cast<const int8_t *>(q.qs)[blk * 32 + j] * d;
+    const uint8_t byte = q.qs[blk * 16 + (j & 15)];
+    int lev = j < 16 ? (byte & 0x0F) : (byte >> 4);
+    if (q.qh) lev |= (int) ((q.qh[blk] >> j) & 1u) << 4;
+    if (q.qt == QT_Q4_0) lev -= 8;
+    if (q.qt == QT_Q5_0) lev -= 16;
+    const float v = (float) lev * d;
+    return q.m ? v + (float) q.m[blk] : v;
+}
+
+// K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
+DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
+DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
+
+// Operands the epilogue reads, fetched at kernel entry so that their latency overlaps the weight stream.
+struct EpiPre { float bias; float res; int n_past; };
+DEVINL EpiPre epilogue_prefetch(const LinArgs & a, int n, int m, int row_off) {
+    EpiPre p;
+    p.bias = a.bias ? a.bias[row_off + m] : 0.0f;
+    p.res = a.epi == EPI_RESID ? a.res[(size_t) n * a.M + m] : 0.0f;
+    p.n_past = (a.epi == EPI_QKV && a.st) ? (a.batched ? a.st[n].n_past : a.st->n_past) : 0;
+    return p;
+}
+DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, const EpiPre & p) {
+    float v = dot;
+    if (a.bias) v = v + p.bias;
+    switch (a.epi) {
+        case EPI_QKV: {
+            const int E = a.E;
+            if (m < E) { a.q[(size_t) n * E + m] = v; break; }
+            // batched decode: row n is sequence slot n with its own cache and position; otherwise rows are consecutive positions
+            const int pos = a.pos0 + p.n_past + (a.batched ? 0 : n);
+            const size_t slot = a.batched ? (size_t) n * a.kv_slot_stride : 0;
+            const int mm = m < 2 * E ? m - E : m - 2 * E;
+            const int h = mm >> 6, d = mm & 63;
+            if (m < 2 * E) a.kc[slot + kc_index(h, d, pos, a.P)] = v; else a.vc[slot + vc_index(h, d, pos, a.P)] = v;
+            break;
+        }
+        case EPI_RESID: a.res[(size_t) n * a.M + m] = v + p.res; break;                          // cur + inpL (bark.cpp:1352,1388)
+        case EPI_GELU: {
+            const half_t g = gelu_lut_apply(v, a.lut);
+            if (a.out_h32) a.out_h32[(size_t) n * a.M + m] = (float) g; else a.out_h[(size_t) n * a.M + m] = g;
+            break;
+        }
+        default:        a.out[(size_t) n * a.ld_out + m] = v; break;
+    }
+}
+DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_off) {
+    float v = dot;
+    if (a.bias) v = v + a.bias[row_off + m];
+    switch (a.epi) {
+        case EPI_QKV: {
+            const int E = a.E;
+            if (m < E) { a.q[(size_t) n * E + m] = v; break; }
+            const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
+            const int mm = m < 2 * E ? m - E : m - 2 * E;
+            const int h = mm >> 6, d = mm & 63;
+            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else a.vc[vc_index(h, d, pos, a.P)] = v;
+            break;
+        }
+        case EPI_RESID: { float * r = a.res + (size_t) n * a.M + m; *r = v + *r; break; }       // cur + inpL (bark.cpp:1352,1388)
+        case EPI_GELU: {
+            const half_t g = gelu_lut_apply(v, a.lut);
+            if (a.out_h32) a.out_h32[(size_t) n * a.M + m] = (float) g; else a.out_h[(size_t) n * a.M + m] = g;
+            break;
+        }
+        default:        a.out[(size_t) n * a.ld_out + m] = v; break;
+    }
+}
+
+
+}  // namespace barkhip

@@ -144,6 +144,10 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
                         int out_stride, StepState * st);
 
 void init_kernel_attributes();
+// internal: per-file pieces of the above and the weight-type specific back ends of launch_linear
+void init_attention_attributes();
+void launch_linear_q(hipStream_t s, const LinArgs & a);
+void launch_linear_w32(hipStream_t s, const LinArgs & a);
 
 // ---- EnCodec decoder (codec_kernels.hip) ---------------------------------------------------------
 // Activations are channel-major [C][T] f32; every conv / LSTM matmul consumes them rounded to f16

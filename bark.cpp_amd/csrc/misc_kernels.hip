@@ -1,0 +1,400 @@
+// misc_kernels.hip - embeddings, LayerNorm over rows, and the sampling kernels (greedy rule C8, multinomial picks aligned
+// with std::discrete_distribution, per-row picks of the fine stage).
+#include "device_utils.h"
+
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+
+namespace barkhip {
+
+// ------------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_causal_kernel(const EmbedArgs a) {
+    const int i = blockIdx.x;
+    int tok, tok2 = -1, pos;
+    if (a.st) { tok = a.st->cur_token; pos = min(a.st->n_past, a.P - 1); }
+    else {
+        pos = a.pos0 + i;
+        if (a.merge) { if (i < 256) { tok = a.tokens[i]; tok2 = a.tokens[256 + i]; } else tok = a.tokens[512]; }
+        else tok = a.tokens[i];
+    }
+    tok = min(max(tok, 0), a.n_in - 1);
+    if (tok2 >= 0) tok2 = min(tok2, a.n_in - 1);
+    const float * pe = a.wpe + (size_t) pos * a.E;
+    float * out = a.x + (size_t) i * a.E;
+    for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
+        float v = wte_elem(a.wte, a.wte_q, a.E, tok, e);
+        if (tok2 >= 0) v = v + wte_elem(a.wte, a.wte_q, a.E, tok2, e);   // wte[text] + wte[history]  (bark.cpp:1237-1248)
+        out[e] = v + pe[e];
+    }
+}
+void launch_embed_causal(hipStream_t s, const EmbedArgs & a) {
+    hipLaunchKernelGGL(embed_causal_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
+}
+
+struct FineEmbedArgs { const half_t * wte[8]; QMat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
+__global__ void embed_fine_kernel(const FineEmbedArgs a) {
+    const int i = blockIdx.x;
+    float * out = a.x + (size_t) i * a.E;
+    const float * pe = a.wpe + (size_t) i * a.E;
+    for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
+        float v = 0.0f;                                     // ggml_set_zero(tok_emb), bark.cpp:1936-1937
+        for (int cb = 0; cb <= a.nn; cb++) {
+            int id = a.tok[cb * 1024 + i];
+            id = min(max(id, 0), a.n_in - 1);
+            v = v + wte_elem(a.wte[cb], a.wte_q[cb], a.E, id, e);
+        }
+        out[e] = v + pe[e];
+    }
+}
+void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const QMat * wte_q, const float * wpe, int E, int n_in,
+                       const int32_t * tokens_8x1024, int nn, float * x) {
+    FineEmbedArgs a; for (int i = 0; i < 8; i++) { a.wte[i] = wte[i]; a.wte_q[i] = wte_q[i]; }
+    a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens_8x1024; a.nn = nn; a.x = x;
+    hipLaunchKernelGGL(embed_fine_kernel, dim3(1024), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows -> f16 (one wave per row)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float * x, int N, int E, const float * g, const float * b, half_t * out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    half_t * o = out + (size_t) row * E;
+    for (int e = lane; e < E; e += 64) {
+        float v = (xr[e] - mean) * scale;
+        v = v * g[e];
+        if (b) v = v + b[e];
+        o[e] = to_half(v);
+    }
+}
+// LayerNorm statistics only (batched decode): stats[row] = {mean, 1/sqrt(var + eps)}, same arithmetic as ln_rows_kernel
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float * x, int N, int E, float * stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = 1.0f / sqrtf(var + 1e-5f); }
+}
+void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, stats);
+}
+// the same LayerNorm without the f16 rounding of the result: input of products with f32 weights
+__global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float * x, int N, int E, const float * g, const float * b, float * out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float * xr = x + (size_t) row * E;
+    double s1 = 0.0;
+    for (int e = lane; e < E; e += 64) s1 += (double) xr[e];
+    s1 = wave_sum(s1);
+    const float mean = (float) (s1 / (double) E);
+    double s2 = 0.0;
+    for (int e = lane; e < E; e += 64) { const float v = xr[e] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum(s2);
+    const float var = (float) (s2 / (double) E);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    float * o = out + (size_t) row * E;
+    for (int e = lane; e < E; e += 64) {
+        float v = (xr[e] - mean) * scale;
+        v = v * g[e];
+        if (b) v = v + b[e];
+        o[e] = v;
+    }
+}
+void launch_ln_rows_f32(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, float * out) {
+    hipLaunchKernelGGL(ln_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);
+}
+void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, N, E, g, b, out);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// greedy sampling (gpt_argmax_sample, bark.cpp:223-247): l /= 0.7; softmax; first index of the
+// largest probability.  p_i = e_i / sum is monotone in e_i = (float) exp((double)(l_i/0.7 - max)), so
+// the winner is the first index whose e_i rounds to 1.0f, i.e. l_i/0.7 - max >= -2^-25.
+// Picks whose runner-up is within kNearTie are counted in st->near_tie (the float division can
+// merge neighbouring probabilities; the host re-checks those).
+// ------------------------------------------------------------------------------------------------
+constexpr float kTieCut = -2.98023223876953125e-08f;     // -2^-25
+constexpr float kNearTie = -4.0e-7f;
+
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a) {
+    __shared__ float red_f[16];
+    __shared__ int red_i[16];
+    __shared__ int red_c[16];
+    __shared__ float red_s[16];
+    __shared__ int next_tok, next_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;                               // sequence slot (batched decode); 0 otherwise
+    const float * logits = a.logits + (size_t) slot * a.ld_logits;
+    constexpr int MAXV = 12;                                   // up to 12288 logits
+    float sv[MAXV];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = tid + 1024 * k;
+        sv[k] = i < a.n ? logits[i] / 0.7f : -INFINITY;        // gpt_argmax_sample divides by 0.7 whatever the temperature
+        mx = fmaxf(mx, sv[k]);
+    }
+    const float last_logit = logits[a.n - 1];
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    int best = INT32_MAX, close = 0;
+    float sum = 0.0f;
+    #pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int i = tid + 1024 * k;
+        if (i < a.n) {
+            const float d = sv[k] - mx;
+            if (d >= kTieCut && i < best) best = i;
+            if (d >= kNearTie) close++;
+            if (a.mode == 0) sum += (float) exp((double) d);
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        best = min(best, __shfl_xor(best, m, 64));
+        close += __shfl_xor(close, m, 64);
+        sum += __shfl_xor(sum, m, 64);
+    }
+    if (lane == 0) { red_i[wave] = best; red_c[wave] = close; red_s[wave] = sum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; i++) { best = min(best, red_i[i]); close += red_c[i]; sum += red_s[i]; }
+        StepState * st = a.st + slot;
+        const int step = st->step;
+        int tok = best;
+        float eos_p = 0.0f;
+        if (a.mode == 0) {
+            // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
+            eos_p = (float) exp((double) (last_logit / 0.7f - mx)) / sum;
+            if ((tok == a.eos_token || eos_p >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = eos_p;
+        } else {
+            tok += a.token_base + ((step & 1) ? 1024 : 0);   // slice start (bark.cpp:1829-1841)
+        }
+        if (close > 1) st->near_tie += 1;
+        a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
+        st->n_out += 1;
+        st->cur_token = tok;
+        st->step = step + 1;
+        const int np = st->n_past + a.n_past_add;
+        st->n_past = np;
+        st->last_eos_p = eos_p;
+        next_tok = tok; next_pos = np;
+    }
+    __syncthreads();
+    // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
+    if (a.x && next_pos < a.P) {
+        const int tok = min(max(next_tok, 0), a.n_in - 1);
+        const float * pe = a.wpe + (size_t) next_pos * a.E;
+        float * xo = a.x + (size_t) slot * a.E;
+        for (int e = tid; e < a.E; e += 1024) xo[e] = wte_elem(a.wte, a.wte_q, a.E, tok, e) + pe[e];
+    }
+}
+// ------------------------------------------------------------------------------------------------
+// multinomial sampling on the device (gpt_multinomial_sample, bark.cpp:201-221): l /= temp; softmax;
+// std::discrete_distribution.  libstdc++'s distribution normalises the probabilities once more in double, takes the
+// running sums (last one forced to 1.0) and returns lower_bound(sums, u) for ONE uniform double u in [0,1) drawn with
+// std::generate_canonical<double, 53> - the host draws those u from the context's std::mt19937 in the order the
+// reference would (one per sample) and uploads them, so a seed selects the same random stream as in the reference.
+// The running sums are formed per thread range + block scan instead of sequentially: a pick can differ from libstdc++
+// only if u falls within ~1e-16 of a boundary.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleArgs a) {
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ int red_i[16];
+    __shared__ int next_tok, next_pos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.x;
+    const float * logits = a.logits + (size_t) slot * a.ld_logits;
+    StepState * st = a.st + slot;
+    const int step = st->step;
+    const double u = a.u[(size_t) slot * a.u_stride + step];
+    constexpr int CH = 12;                                      // thread t owns the contiguous ids [t*CH, t*CH+CH): up to 12288 logits
+    float pv[CH];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = tid * CH + k;
+        pv[k] = i < a.n ? logits[i] / a.temp : -INFINITY;
+        mx = fmaxf(mx, pv[k]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    float fsum = 0.0f;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = tid * CH + k < a.n ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
+    __syncthreads();
+    if (lane == 0) red_f[wave] = fsum;
+    __syncthreads();
+    fsum = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) fsum += red_f[i];
+    double dsum = 0.0;
+    float eos_p = 0.0f;                                         // set in the thread that owns the last id
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        pv[k] = pv[k] / fsum; dsum += (double) pv[k];           // softmax probabilities (float), bark.cpp:197-199
+        if (tid * CH + k == a.n - 1) eos_p = pv[k];
+    }
+    double wtot = wave_sum(dsum);
+    if (lane == 0) red_d[wave] = wtot;
+    __syncthreads();
+    double total = 0.0, wave_off = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) { if (i < wave) wave_off += red_d[i]; total += red_d[i]; }
+    // exclusive prefix of the per-thread sums inside the wave
+    double incl = dsum;
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    double run = (wave_off + (incl - dsum)) / total;
+    int pick = INT32_MAX;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = tid * CH + k;
+        if (i < a.n) {
+            run += (double) pv[k] / total;
+            const double cp = i == a.n - 1 ? 1.0 : run;                                    // libstdc++ pins the last running sum to 1.0
+            if (cp >= u && i < pick) pick = i;
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
+    if (lane == 0) red_i[wave] = pick;
+    if (tid == ((a.n - 1) / CH)) red_f[0] = eos_p;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; i++) pick = min(pick, red_i[i]);
+        int tok = pick;
+        float ep = 0.0f;
+        if (a.mode == 0) {
+            ep = red_f[0];                                      // probability of the LAST logit (bark.cpp:217-218)
+            if ((tok == a.eos_token || ep >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = ep;
+        } else {
+            tok += a.token_base + ((step & 1) ? 1024 : 0);
+        }
+        a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
+        st->n_out += 1;
+        st->cur_token = tok;
+        st->step = step + 1;
+        const int np = st->n_past + a.n_past_add;
+        st->n_past = np;
+        st->last_eos_p = ep;
+        next_tok = tok; next_pos = np;
+    }
+    __syncthreads();
+    if (a.x && next_pos < a.P) {
+        const int tok = min(max(next_tok, 0), a.n_in - 1);
+        const float * pe = a.wpe + (size_t) next_pos * a.E;
+        float * xo = a.x + (size_t) slot * a.E;
+        for (int e = tid; e < a.E; e += 1024) xo[e] = wte_elem(a.wte, a.wte_q, a.E, tok, e) + pe[e];
+    }
+}
+
+// fine stage: one wave per row, multinomial over the first n_cols logits of the row; u[row] is that sample's uniform draw
+__global__ __launch_bounds__(256) void sample_rows_multinomial_kernel(const float * logits, int ld, int n_rows, int n_cols, float temp,
+                                                                     const double * u, int32_t * out, int out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float * l = logits + (size_t) row * ld;
+    constexpr int CH = 16;                                      // lane owns ids [lane*16, lane*16+16): n_cols <= 1024
+    float pv[CH];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { const int i = lane * CH + k; pv[k] = i < n_cols ? l[i] / temp : -INFINITY; mx = fmaxf(mx, pv[k]); }
+    mx = wave_max(mx);
+    float fsum = 0.0f;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = lane * CH + k < n_cols ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
+    double dsum = 0.0;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) { pv[k] = pv[k] / fsum; dsum += (double) pv[k]; }
+    const double total = wave_sum(dsum);
+    double incl = dsum;
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
+    double run = (incl - dsum) / total;
+    const double uu = u[row];
+    int pick = INT32_MAX;
+    #pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const int i = lane * CH + k;
+        if (i < n_cols) {
+            run += (double) pv[k] / total;
+            const double cp = i == n_cols - 1 ? 1.0 : run;
+            if (cp >= uu && i < pick) pick = i;
+        }
+    }
+    for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
+    if (lane == 0) out[(size_t) row * out_stride] = pick;
+}
+void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, float temp, const double * u,
+                                    int32_t * out, int out_stride) {
+    hipLaunchKernelGGL(sample_rows_multinomial_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, temp, u, out, out_stride);
+}
+
+void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
+    if (a.temp > 0.0f) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
+                                                         int out_stride, StepState * st) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float * l = logits + (size_t) row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < n_cols; i += 64) mx = fmaxf(mx, l[i] / 0.7f);
+    mx = wave_max(mx);
+    int best = INT32_MAX, close = 0;
+    for (int i = lane; i < n_cols; i += 64) {
+        const float d = l[i] / 0.7f - mx;
+        if (d >= kTieCut && i < best) best = i;
+        if (d >= kNearTie) close++;
+    }
+    for (int m = 1; m < 64; m <<= 1) { best = min(best, __shfl_xor(best, m, 64)); close += __shfl_xor(close, m, 64); }
+    if (lane == 0) {
+        out[(size_t) row * out_stride] = best;
+        if (close > 1 && st) atomicAdd(&st->near_tie, 1);
+    }
+}
+void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out, int out_stride,
+                        StepState * st) {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, out, out_stride, st);
+}
+
+}  // namespace barkhip

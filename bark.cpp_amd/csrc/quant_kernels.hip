@@ -1,0 +1,562 @@
+// quant_kernels.hip - linear operators whose weights are not f16: ggml block formats (q4_0, q4_1, q5_0, q5_1, q8_0 files
+// written by bark_model_quantize) and plain f32 (files converted without --use-f16).  Same canonical chains as kernels.hip.
+#include "device_utils.h"
+
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+
+namespace barkhip {
+
+// ------------------------------------------------------------------------------------------------
+// Quantised weights (ggml block formats q4_0 - BASELINE config 4 - q4_1, q5_0, q5_1, q8_0; quant_formats.h), computed as
+// ggml's vec_dot_q*_q8_* restated by the oracle's C1q order: the activation row is quantised to q8 blocks of 32
+// (d = amax / 127, q = roundf(x / d), d stored as f16, s = f16(d * sum q) for the formats with a minimum), every block
+// product is an exact integer sum, scaled per format (block_term), block b belongs to chain b mod 16, chains are plain float
+// adds in ascending block order and meet in the C1 tree.  Weight levels are widened to int8 in registers (unpack_raw) so that
+// one code path - v_dot4_i32_i8 for decode, v_mfma_i32_32x32x32_i8 for rows - serves all five formats.
+// ------------------------------------------------------------------------------------------------
+template <int QT> struct QTraits {
+    static constexpr bool has_m = QT == QT_Q4_1 || QT == QT_Q5_1;
+    static constexpr bool has_h = QT == QT_Q5_0 || QT == QT_Q5_1;
+    static constexpr bool wide = QT == QT_Q8_0;                // 32 bytes of levels per block instead of 16
+};
+template <int QT> struct RawBlock { uint4 qs, qs2; unsigned qh; half_t d, m; };
+template <int QT> DEVINL RawBlock<QT> load_raw(const QMat & q, size_t idx) {
+    RawBlock<QT> r;
+    if constexpr (QTraits<QT>::wide) { const uint4 * p = reinterpret_cast<const uint4 *>(q.qs) + 2 * idx; r.qs = p[0]; r.qs2 = p[1]; }
+    else r.qs = reinterpret_cast<const uint4 *>(q.qs)[idx];
+    if constexpr (QTraits<QT>::has_h) r.qh = q.qh[idx];
+    r.d = q.d[idx];
+    if constexpr (QTraits<QT>::has_m) r.m = q.m[idx];
+    return r;
+}
+// four bits b3 b2 b1 b0 -> bit 4 of bytes 3..0
+DEVINL unsigned spread_fifth_bits(unsigned b) { return ((b * 0x00204081u) & 0x01010101u) << 4; }
+// per-byte v - k for bytes v < 128, k < 128, without borrows between bytes: set bit 7, subtract, flip bit 7 back
+DEVINL int bytes_minus(unsigned v, unsigned k4) { return (int) (((v | 0x80808080u) - k4) ^ 0x80808080u); }
+// half == 0: elements 0..15 of the block, half == 1: elements 16..31, as four dwords of int8 levels
+template <int QT> DEVINL void unpack_half(const RawBlock<QT> & r, int half, int (&o)[4]) {
+    if constexpr (QTraits<QT>::wide) {
+        const uint4 v = half ? r.qs2 : r.qs;
+        o[0] = (int) v.x; o[1] = (int) v.y; o[2] = (int) v.z; o[3] = (int) v.w;
+    } else {
+        const unsigned w[4] = {r.qs.x, r.qs.y, r.qs.z, r.qs.w};
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned v = (w[i] >> (4 * half)) & 0x0F0F0F0Fu;
+            if constexpr (QTraits<QT>::has_h) v |= spread_fifth_bits((r.qh >> (16 * half + 4 * i)) & 0xFu);
+            if constexpr (QT == QT_Q4_0) o[i] = bytes_minus(v, 0x08080808u);
+            else if constexpr (QT == QT_Q5_0) o[i] = bytes_minus(v, 0x10101010u);
+            else o[i] = (int) v;
+        }
+    }
+}
+template <int QT> DEVINL void unpack_raw(const RawBlock<QT> & r, int (&o)[8]) {
+    int lo[4], hi[4];
+    unpack_half<QT>(r, 0, lo); unpack_half<QT>(r, 1, hi);
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { o[i] = lo[i]; o[4 + i] = hi[i]; }
+}
+// ggml's per-block scaling (oracle: dot_q_q8)
+template <int QT> DEVINL float block_term(int sumi, float dw, float mw, float dx, float sx) {
+    if constexpr (QT == QT_Q4_0) return ((float) sumi * dw) * dx;
+    else {
+        const float dd = dw * dx;
+        float t = dd * (float) sumi;
+        if constexpr (QTraits<QT>::has_m) { const float ms = mw * sx; t = t + ms; }
+        return t;
+    }
+}
+DEVINL int dot_q4_q8(const int (&w)[8], const int (&q)[8]) {
+    int s = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) s = __builtin_amdgcn_sdot4(w[i], q[i], s, false);
+    return s;
+}
+// NV f32 values -> NV/4 dwords of int8 levels q = roundf(v * id); returns sum q
+template <int NV> DEVINL int quantize_levels(const float (&v)[NV], float id, int (&q)[NV / 4]) {
+    int sum = 0;
+    #pragma unroll
+    for (int i = 0; i < NV / 4; i++) {
+        unsigned w = 0;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int qi = (int) __builtin_roundf(v[4 * i + j] * id);       // round half away from zero, as roundf on the host
+            sum += qi;
+            w |= ((unsigned) qi & 0xFFu) << (8 * j);
+        }
+        q[i] = (int) w;
+    }
+    return sum;
+}
+
+// decode (N = 1): x is an f32 row, optionally LayerNorm-ed first.  A 256-thread workgroup owns 16 output rows:
+//   1. every lane requests the weight blocks of its chain (up to 8) before anything else,
+//   2. the q8 quantisation of x (~8 VALU ops per element) is spread over the workgroup - two threads per block of 32,
+//      block maximum / level sum through one DPP exchange - and published in LDS once for the 16 rows,
+//   3. wave w dots rows 4 w .. 4 w + 3: lane c of a row walks the blocks c, c + 16, ... (chain c of C1q).
+// The first version quantised inside every 16-lane group (each lane its own blocks): 1500 VALU instructions per wave
+// for K = 3072, 8.0 us per launch; this one measures about half of that (quantised files).
+template <int QT, bool LN, bool LNB>
+__global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
+    constexpr int MAXB = 8;                                    // blocks per chain: K <= 4096
+    __shared__ int4 xq[128][2];                                // q8 levels of block b: elements 0..15 and 16..31
+    __shared__ float xd[128], xs[128];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 16 + wave * 4 + rg;
+    const int K = a.K, nblk = K >> 5;
+    const int slot = a.batched ? blockIdx.y : 0;              // lock-step batch: one sequence per grid.y (own x row, state, KV cache)
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
+    RawBlock<QT> wb[MAXB];
+    #pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        const int b = c + 16 * i;
+        if (b < nblk) wb[i] = load_raw<QT>(a.wq, wrow + b);
+    }
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, row_off);
+
+    // ---- x -> q8: thread t quantises elements [16 (t & 1), +16) of block t >> 1
+    const int qb = tid >> 1, qh = tid & 1;
+    const bool mine = qb < nblk;
+    const int k0 = mine ? (qb << 5) + (qh << 4) : 0;
+    float v[16];
+    {
+        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (size_t) slot * K + k0);
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    }
+    if constexpr (LN) {
+        float g[16], bb[16];
+        {
+            const float4 * gp = reinterpret_cast<const float4 *>(a.ln_g + k0);
+            const float4 * bp = reinterpret_cast<const float4 *>((LNB ? a.ln_b : a.ln_g) + k0);
+            #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 f = gp[i]; g[4 * i] = f.x; g[4 * i + 1] = f.y; g[4 * i + 2] = f.z; g[4 * i + 3] = f.w;
+                if constexpr (LNB) { const float4 h = bp[i]; bb[4 * i] = h.x; bb[4 * i + 1] = h.y; bb[4 * i + 2] = h.z; bb[4 * i + 3] = h.w; }
+            }
+        }
+        // ggml_norm: double sums over the row (bark.cpp:1265-1274)
+        double s1 = 0.0;
+        if (mine) {
+            #pragma unroll
+            for (int j = 0; j < 16; j++) s1 += (double) v[j];
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wave] = s1;
+        __syncthreads();
+        const float mean = (float) (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double) K);
+        double s2 = 0.0;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) { const float u = v[j] - mean; v[j] = u; if (mine) s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wave] = s2;
+        __syncthreads();
+        const float var = (float) (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double) K);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float u = v[j] * scale;
+            u = u * g[j];
+            if constexpr (LNB) u = u + bb[j];
+            v[j] = u;
+        }
+    }
+    {
+        float amax = 0.0f;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
+        amax = fmaxf(amax, dpp_f32<DPP_XOR1>(amax));           // the other half of the block sits in the neighbouring lane
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        int q[4];
+        int sum = quantize_levels<16>(v, id, q);
+        sum += __builtin_amdgcn_update_dpp(0, sum, DPP_XOR1, 0xF, 0xF, false);
+        if (mine) {
+            xq[qb][qh] = make_int4(q[0], q[1], q[2], q[3]);
+            if (qh == 0) { xd[qb] = (float) to_half(d); xs[qb] = (float) to_half((float) sum * d); }
+        }
+    }
+    __syncthreads();
+
+    float acc = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < MAXB; i++) {
+        const int b = c + 16 * i;
+        if (b < nblk) {
+            const int4 q0 = xq[b][0], q1 = xq[b][1];
+            const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            int w[8]; unpack_raw<QT>(wb[i], w);
+            const int sumi = dot_q4_q8(w, q);
+            const float tb = block_term<QT>(sumi, (float) wb[i].d, QTraits<QT>::has_m ? (float) wb[i].m : 0.0f, xd[b], xs[b]);
+            acc = acc + tb;
+        }
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, slot, m, acc, pre);
+}
+
+// rows (N > 1): q8 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
+struct Q8RowsArgs { const float * x; int N, K; const float * ln_g; const float * ln_b; int8_t * q; float * d; float * dT; float * s; float * sT; };
+__global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
+    const int lane = threadIdx.x, n = blockIdx.x;
+    const int K = a.K, nblk = K >> 5;
+    const float * xr = a.x + (size_t) n * K;
+    float mean = 0.0f, scale = 1.0f;
+    if (a.ln_g) {
+        double s1 = 0.0;
+        for (int e = lane; e < K; e += 64) s1 += (double) xr[e];
+        s1 = wave_sum(s1);
+        mean = (float) (s1 / (double) K);
+        double s2 = 0.0;
+        for (int e = lane; e < K; e += 64) { const float u = xr[e] - mean; s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        const float var = (float) (s2 / (double) K);
+        scale = 1.0f / sqrtf(var + 1e-5f);
+    }
+    for (int b = lane; b < nblk; b += 64) {
+        float v[32];
+        const float4 * xp = reinterpret_cast<const float4 *>(xr + (b << 5));
+        #pragma unroll
+        for (int i = 0; i < 8; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+        if (a.ln_g) {
+            #pragma unroll
+            for (int j = 0; j < 32; j++) {
+                float u = (v[j] - mean) * scale;
+                u = u * a.ln_g[(b << 5) + j];
+                if (a.ln_b) u = u + a.ln_b[(b << 5) + j];
+                v[j] = u;
+            }
+        }
+        float amax = 0.0f;
+        #pragma unroll
+        for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        int q[8];
+        const int sum = quantize_levels<32>(v, id, q);
+        int4 * qp = reinterpret_cast<int4 *>(a.q + (size_t) n * K + (b << 5));
+        qp[0] = make_int4(q[0], q[1], q[2], q[3]);
+        qp[1] = make_int4(q[4], q[5], q[6], q[7]);
+        const float dh = (float) to_half(d), sh = (float) to_half((float) sum * d);
+        a.d[(size_t) n * nblk + b] = dh;
+        a.s[(size_t) n * nblk + b] = sh;
+        // block-major copies for the MFMA kernel ([K/32][1024])
+        a.dT[(size_t) b * 1024 + n] = dh;
+        a.sT[(size_t) b * 1024 + n] = sh;
+    }
+}
+
+// rows (N > 1), v_dot4 version: NB pre-quantised activation rows per wave share each unpacked weight block.  Kept as the
+// cross-check path of the MFMA kernel (BARK_HIP_Q4_ROWS); bound by L2 re-reads of the weights.
+struct QRowsArgs { LinArgs lin; const int8_t * q; const float * d, * dT, * s, * sT; };
+template <int QT, int NB>
+__global__ __launch_bounds__(64) void gemm_q_rows_kernel(const QRowsArgs qa) {
+    const LinArgs & a = qa.lin;
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int n0 = blockIdx.y * NB;
+    const int K = a.K, nblk = K >> 5;
+    const bool live = m < a.M;
+    const size_t wrow = (size_t) (live ? m : 0) * nblk;
+    float acc[NB];
+    #pragma unroll
+    for (int i = 0; i < NB; i++) acc[i] = 0.0f;
+    for (int b = c; b < nblk; b += 16) {
+        const RawBlock<QT> wb = load_raw<QT>(a.wq, wrow + b);
+        int w[8]; unpack_raw<QT>(wb, w);
+        const float dw = (float) wb.d, mw = QTraits<QT>::has_m ? (float) wb.m : 0.0f;
+        #pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int n = min(n0 + i, a.N - 1);
+            const int4 * qp = reinterpret_cast<const int4 *>(qa.q + (size_t) n * K + (b << 5));
+            const int4 q0 = qp[0], q1 = qp[1];
+            const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const int sumi = dot_q4_q8(w, q);
+            const float tb = block_term<QT>(sumi, dw, mw, qa.d[(size_t) n * nblk + b], QTraits<QT>::has_m ? qa.s[(size_t) n * nblk + b] : 0.0f);
+            acc[i] = acc[i] + tb;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const float r = wave_xor_add16(acc[i]);
+        if (live && c == 0 && n0 + i < a.N) linear_epilogue(a, n0 + i, m, r, 0);
+    }
+}
+
+// rows (N > 1) on the matrix cores: v_mfma_i32_32x32x32_i8 multiplies exactly one weight block (32 levels of 32 output rows,
+// widened to int8) by one q8 block of 32 activation rows - the int32 results are the exact block sums of C1q.
+// Workgroup tile: 64 activation rows x 32 output rows, 8 waves; wave w owns the chains 2 w and 2 w + 1 (blocks 2 w + 16 i
+// and 2 w + 1 + 16 i, ascending), scales every block sum per format (block_term) and adds it to the chain in f32.
+// The weight scale (and minimum) is per lane (the lane's output row), the 16 activation scales of a lane's accumulator rows
+// come from the block-major copies of d8 / s8 as float4 loads.  Chains 2 w and 2 w + 1 meet in registers (tree level xor 1),
+// the eight pair sums of an output in LDS (levels xor 2, 4, 8).
+constexpr int Q4G_TM = 32, Q4G_TN = 64, Q4G_LD = 33;
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
+template <int QT>
+__global__ __launch_bounds__(512) void gemm_q_mfma_kernel(const QRowsArgs qa) {
+    extern __shared__ float q4g_red[];                         // [8 chain pairs][64 activation rows][33]
+    const LinArgs & a = qa.lin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * Q4G_TM, n0 = blockIdx.y * Q4G_TN;
+    const int K = a.K, nblk = K >> 5;
+    const int li = lane & 31, kh = lane >> 5;
+    const int m = min(m0 + li, a.M - 1);
+    const size_t wrow = (size_t) m * nblk;
+    const int8_t * xq[2]; const float * xdT[2], * xsT[2];
+    #pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        const int n = min(n0 + 32 * nt + li, a.N - 1);
+        xq[nt] = qa.q + (size_t) n * K + 16 * kh;
+        xdT[nt] = qa.dT + n0 + 32 * nt + 4 * kh;                 // accumulator register r <-> activation row (r & 3) + 8 (r >> 2) + 4 kh
+        xsT[nt] = qa.sT + n0 + 32 * nt + 4 * kh;
+    }
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+        #pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[ch][nt][r] = 0.0f;
+    const intx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b0 = 2 * wave; b0 < nblk; b0 += 16) {
+        #pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const int b = b0 + ch;
+            if (b < nblk) {                                    // wave-uniform
+                const RawBlock<QT> wb = load_raw<QT>(a.wq, wrow + b);
+                intx4 xa[2]; float4 d8[2][4], s8[2][4];
+                #pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    xa[nt] = *reinterpret_cast<const intx4 *>(xq[nt] + (b << 5));
+                    #pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        d8[nt][g] = *reinterpret_cast<const float4 *>(xdT[nt] + (size_t) b * 1024 + 8 * g);
+                        if constexpr (QTraits<QT>::has_m) s8[nt][g] = *reinterpret_cast<const float4 *>(xsT[nt] + (size_t) b * 1024 + 8 * g);
+                    }
+                }
+                // lanes 0..31 carry elements 0..15 of the block, lanes 32..63 elements 16..31
+                int wlo[4], whi[4];
+                unpack_half<QT>(wb, 0, wlo); unpack_half<QT>(wb, 1, whi);
+                intx4 wv;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) wv[i] = kh ? whi[i] : wlo[i];
+                const float dw = (float) wb.d, mw = QTraits<QT>::has_m ? (float) wb.m : 0.0f;
+                #pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    const intx16 si = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[nt], wv, zero, 0, 0, 0);
+                    #pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float dd[4] = {d8[nt][g].x, d8[nt][g].y, d8[nt][g].z, d8[nt][g].w};
+                        float ss[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if constexpr (QTraits<QT>::has_m) { ss[0] = s8[nt][g].x; ss[1] = s8[nt][g].y; ss[2] = s8[nt][g].z; ss[3] = s8[nt][g].w; }
+                        #pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int r = 4 * g + j;
+                            const float tb = block_term<QT>(si[r], dw, mw, dd[j], ss[j]);
+                            acc[ch][nt][r] = acc[ch][nt][r] + tb;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // tree level xor 1 in registers, then the 8 pair sums per output through LDS
+    float * red = q4g_red + (size_t) wave * (Q4G_TN * Q4G_LD);
+    #pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int nl = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            red[nl * Q4G_LD + li] = acc[0][nt][r] + acc[1][nt][r];
+        }
+    __syncthreads();
+    #pragma unroll
+    for (int k = 0; k < (Q4G_TM * Q4G_TN) / 512; k++) {
+        const int o = tid + 512 * k;
+        const int nl = o >> 5, ml = o & 31;
+        float p[8];
+        #pragma unroll
+        for (int c = 0; c < 8; c++) p[c] = q4g_red[(size_t) c * (Q4G_TN * Q4G_LD) + nl * Q4G_LD + ml];
+        const float r = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (n0 + nl < a.N && m0 + ml < a.M) linear_epilogue(a, n0 + nl, m0 + ml, r, 0);
+    }
+}
+
+void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, const Q8Scratch & o) {
+    if (N > 1024) { fprintf(stderr, "bark-hip: q8 row quantisation handles at most 1024 rows\n"); abort(); }
+    Q8RowsArgs a{x, N, K, ln_g, ln_b, o.q, o.d, o.dT, o.s, o.sT};
+    hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
+}
+
+template <int QT>
+static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
+    if (a.N == 1) {
+        // lock-step batch: grid.y walks the sequences; grid.x rounded up to a multiple of 8 so that every grid.y of a row group
+        // lands on the same XCD and re-reads the weight blocks from its L2
+        const int gx = (a.M + 15) / 16;
+        dim3 grid(a.batched ? (gx + 7) / 8 * 8 : gx, a.batched ? a.nbatch : 1), block(256);
+        if (a.ln_g) {
+            if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_q_kernel<QT, true, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((gemv_q_kernel<QT, false, false>), grid, block, 0, s, a);
+        return;
+    }
+    static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, the cross-check path
+    const QRowsArgs qa{a, a.xq.q, a.xq.d, a.xq.dT, a.xq.s, a.xq.sT};
+    if (!force_rows) {
+        static const bool attr = [] {
+            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
+            return true;
+        }();
+        (void) attr;
+        dim3 grid((a.M + Q4G_TM - 1) / Q4G_TM, (a.N + Q4G_TN - 1) / Q4G_TN), block(512);
+        hipLaunchKernelGGL((gemm_q_mfma_kernel<QT>), grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
+        return;
+    }
+    constexpr int NB = 8;
+    dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
+    hipLaunchKernelGGL((gemm_q_rows_kernel<QT, NB>), grid, block, 0, s, qa);
+}
+void launch_linear_q(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 31) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: quantised rows must be a multiple of 32 and at most 4096 long\n"); abort(); }
+    if (a.batched && (a.N != 1 || a.ln_stats)) { fprintf(stderr, "bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics\n"); abort(); }
+    if (a.N == 1 && !a.x_f32) { fprintf(stderr, "bark-hip: quantised GEMV needs an f32 activation row\n"); abort(); }
+    if (a.N > 1 && (!a.xq.q || a.parity_rows)) { fprintf(stderr, "bark-hip: quantised row product needs pre-quantised rows\n"); abort(); }
+    switch (a.wq.qt) {
+        case QT_Q4_0: launch_linear_qt<QT_Q4_0>(s, a); break;
+        case QT_Q4_1: launch_linear_qt<QT_Q4_1>(s, a); break;
+        case QT_Q5_0: launch_linear_qt<QT_Q5_0>(s, a); break;
+        case QT_Q5_1: launch_linear_qt<QT_Q5_1>(s, a); break;
+        case QT_Q8_0: launch_linear_qt<QT_Q8_0>(s, a); break;
+        default: fprintf(stderr, "bark-hip: unknown weight block format %d\n", a.wq.qt); abort();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 weights (model files converted without --use-f16).  ggml converts the activation only when the weight type asks for
+// it, so both operands are f32 here; the summation order is C1 unchanged (8-element chunks, chunk q -> chain q mod 16, fmaf).
+// These are plain kernels - the format is a compatibility path, not a tuned one: decode stages the (LayerNorm-ed) row in
+// LDS once per 16 output rows, rows (N > 1) re-read the weights from L2 for every eight activation rows.
+// ------------------------------------------------------------------------------------------------
+template <bool LN, bool LNB>
+__global__ __launch_bounds__(256) void gemv_w32_kernel(const LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[4096];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 16 + wave * 4 + rg;
+    const int K = a.K, nchunk = K >> 3;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const float * wrow = reinterpret_cast<const float *>(a.wq.qs) + (size_t) (row_off + (live ? m : 0)) * K;
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    // ---- stage x: thread t owns elements [16 t, 16 t + 16)
+    const bool mine = 16 * tid < K;
+    const int k0 = mine ? 16 * tid : 0;
+    float v[16];
+    {
+        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + k0);
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    }
+    if constexpr (LN) {
+        double s1 = 0.0;
+        if (mine) {
+            #pragma unroll
+            for (int j = 0; j < 16; j++) s1 += (double) v[j];
+        }
+        s1 = wave_sum(s1);
+        if (lane == 0) red[0][wave] = s1;
+        __syncthreads();
+        const float mean = (float) (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double) K);
+        double s2 = 0.0;
+        #pragma unroll
+        for (int j = 0; j < 16; j++) { const float u = v[j] - mean; v[j] = u; if (mine) s2 += (double) (u * u); }
+        s2 = wave_sum(s2);
+        if (lane == 0) red[1][wave] = s2;
+        __syncthreads();
+        const float var = (float) (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double) K);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float u = v[j] * scale;
+            u = u * a.ln_g[k0 + j];
+            if constexpr (LNB) u = u + a.ln_b[k0 + j];
+            v[j] = u;
+        }
+    }
+    if (mine) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<float4 *>(xs + k0 + 4 * i) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    #pragma unroll 4
+    for (int q = c; q < nchunk; q += 16) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow + (q << 3)), w1 = *reinterpret_cast<const float4 *>(wrow + (q << 3) + 4);
+        const float4 x0 = *reinterpret_cast<const float4 *>(xs + (q << 3)), x1 = *reinterpret_cast<const float4 *>(xs + (q << 3) + 4);
+        acc = fmaf(w0.x, x0.x, acc); acc = fmaf(w0.y, x0.y, acc); acc = fmaf(w0.z, x0.z, acc); acc = fmaf(w0.w, x0.w, acc);
+        acc = fmaf(w1.x, x1.x, acc); acc = fmaf(w1.y, x1.y, acc); acc = fmaf(w1.z, x1.z, acc); acc = fmaf(w1.w, x1.w, acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+}
+// rows (N > 1): x_f32 holds N rows of length K (already LayerNorm-ed where the operator has one)
+template <int NB>
+__global__ __launch_bounds__(64) void gemm_w32_rows_kernel(const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int n0 = blockIdx.y * NB;
+    const int K = a.K, nchunk = K >> 3;
+    const bool live = m < a.M;
+    const float * wrow = reinterpret_cast<const float *>(a.wq.qs) + (size_t) (live ? m : 0) * K;
+    float acc[NB];
+    #pragma unroll
+    for (int i = 0; i < NB; i++) acc[i] = 0.0f;
+    for (int q = c; q < nchunk; q += 16) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow + (q << 3)), w1 = *reinterpret_cast<const float4 *>(wrow + (q << 3) + 4);
+        #pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int n = min(n0 + i, a.N - 1);
+            const float * xr = a.x_f32 + (size_t) n * K + (q << 3);
+            const float4 x0 = *reinterpret_cast<const float4 *>(xr), x1 = *reinterpret_cast<const float4 *>(xr + 4);
+            float r = acc[i];
+            r = fmaf(w0.x, x0.x, r); r = fmaf(w0.y, x0.y, r); r = fmaf(w0.z, x0.z, r); r = fmaf(w0.w, x0.w, r);
+            r = fmaf(w1.x, x1.x, r); r = fmaf(w1.y, x1.y, r); r = fmaf(w1.z, x1.z, r); r = fmaf(w1.w, x1.w, r);
+            acc[i] = r;
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const float r = wave_xor_add16(acc[i]);
+        if (live && c == 0 && n0 + i < a.N) linear_epilogue(a, n0 + i, m, r, 0);
+    }
+}
+void launch_linear_w32(hipStream_t s, const LinArgs & a) {
+    if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in f32 linear op\n", a.K); abort(); }
+    if (a.batched || !a.x_f32) { fprintf(stderr, "bark-hip: f32-weight products take f32 rows, one sequence at a time\n"); abort(); }
+    if (a.N == 1) {
+        dim3 grid((a.M + 15) / 16), block(256);
+        if (a.ln_g) {
+            if (a.ln_b) hipLaunchKernelGGL((gemv_w32_kernel<true, true>), grid, block, 0, s, a);
+            else        hipLaunchKernelGGL((gemv_w32_kernel<true, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((gemv_w32_kernel<false, false>), grid, block, 0, s, a);
+        return;
+    }
+    if (a.ln_g || a.parity_rows) { fprintf(stderr, "bark-hip: f32 row product needs LayerNorm-ed rows\n"); abort(); }
+    constexpr int NB = 8;
+    dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
+    hipLaunchKernelGGL((gemm_w32_rows_kernel<NB>), grid, block, 0, s, a);
+}
+
+}  // namespace barkhip
