@@ -417,8 +417,10 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, ctx->device));
     char buf[512];
-    snprintf(buf, sizeof(buf), "bark-mi355x engine on %s (%s, %d CUs), weights %.1f MB, n_embd %d/%d/%d, layers %d/%d/%d, graph=%d",
-             prop.name, prop.gcnArchName, prop.multiProcessorCount, plan.total / 1e6, ctx->gpt[0].hp.n_embd, ctx->gpt[1].hp.n_embd,
+    const GptModel & g0 = ctx->gpt[0];
+    const char * wfmt = g0.w32 ? "f32" : g0.q4 ? quant_formats()[g0.layers[0].attn_q.qt].name : "f16";
+    snprintf(buf, sizeof(buf), "bark-mi355x engine on %s (%s, %d CUs), %s weights %.1f MB, n_embd %d/%d/%d, layers %d/%d/%d, graph=%d",
+             prop.name, prop.gcnArchName, prop.multiProcessorCount, wfmt, ctx->weight_bytes / 1e6, ctx->gpt[0].hp.n_embd, ctx->gpt[1].hp.n_embd,
              ctx->gpt[2].hp.n_embd, ctx->gpt[0].hp.n_layer, ctx->gpt[1].hp.n_layer, ctx->gpt[2].hp.n_layer, (int) ctx->use_graph);
     ctx->description = buf;
     if (params.verbosity >= MEDIUM) fprintf(stderr, "%s\n", buf);
