@@ -208,7 +208,7 @@ def main():
                 out["q4_0"] = {"error": str(e)}
         if not a.no_cpu_baseline and world == 1:
             from oracle.pyoracle import Oracle
-            cores = min(os.cpu_count() or 4, 8)
+            cores = min(os.cpu_count() or 4, 4)                 # BASELINE config 1: examples/main -t 4
             orc = Oracle(path, n_threads=cores)
             n_small = 24
             t1 = time.perf_counter()
