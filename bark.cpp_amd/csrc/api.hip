@@ -16,8 +16,16 @@ namespace {
 int64_t wall_us() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// noexcept shell of every entry point.  Kernel launches are not checked one by one (hipLaunchKernelGGL), so the sticky launch
+// error is read here: a launch that was rejected means missing results, which must fail the call instead of returning them.
 template <typename F> auto guarded(const char * what, decltype(std::declval<F>()()) fail, F && f) -> decltype(f()) {
-    try { return f(); }
+    try {
+        (void) hipGetLastError();
+        auto r = f();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { fprintf(stderr, "%s: a kernel launch failed: %s\n", what, hipGetErrorString(e)); return fail; }
+        return r;
+    }
     catch (const std::exception & e) { fprintf(stderr, "%s: %s\n", what, e.what()); }
     catch (...) { fprintf(stderr, "%s: unknown failure\n", what); }
     return fail;

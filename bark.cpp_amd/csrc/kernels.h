@@ -146,6 +146,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 void init_kernel_attributes();
 // internal: per-file pieces of the above and the weight-type specific back ends of launch_linear
 void init_attention_attributes();
+void init_quant_attributes();
 void launch_linear_q(hipStream_t s, const LinArgs & a);
 void launch_linear_w32(hipStream_t s, const LinArgs & a);
 

@@ -477,6 +477,7 @@ void init_kernel_attributes() {
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
     init_attention_attributes();
+    init_quant_attributes();
 }
 
 }  // namespace barkhip

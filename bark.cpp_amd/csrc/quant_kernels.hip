@@ -412,12 +412,6 @@ static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
     static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, the cross-check path
     const QRowsArgs qa{a, a.xq.q, a.xq.d, a.xq.dT, a.xq.s, a.xq.sT};
     if (!force_rows) {
-        static const bool attr = [] {
-            (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
-            return true;
-        }();
-        (void) attr;
         dim3 grid((a.M + Q4G_TM - 1) / Q4G_TM, (a.N + Q4G_TN - 1) / Q4G_TN), block(512);
         hipLaunchKernelGGL((gemm_q_mfma_kernel<QT>), grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
         return;
@@ -426,6 +420,15 @@ static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
     dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
     hipLaunchKernelGGL((gemm_q_rows_kernel<QT, NB>), grid, block, 0, s, qa);
 }
+// the MFMA kernels' LDS tree (67.6 KB) is above the default 64 KB limit; set once at load time, outside any stream capture
+template <int QT> static void allow_large_lds() {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_q_mfma_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               8 * Q4G_TN * Q4G_LD * (int) sizeof(float));
+}
+void init_quant_attributes() {
+    allow_large_lds<QT_Q4_0>(); allow_large_lds<QT_Q4_1>(); allow_large_lds<QT_Q5_0>(); allow_large_lds<QT_Q5_1>(); allow_large_lds<QT_Q8_0>();
+}
+
 void launch_linear_q(hipStream_t s, const LinArgs & a) {
     if ((a.K & 31) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: quantised rows must be a multiple of 32 and at most 4096 long\n"); abort(); }
     if (a.batched && (a.N != 1 || a.ln_stats)) { fprintf(stderr, "bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics\n"); abort(); }
