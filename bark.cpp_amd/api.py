@@ -45,7 +45,8 @@ class BarkHipStats(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "lib", "libbark.so")
+    # BARK_HIP_LIBRARY: another build of the same library (e.g. a host-AddressSanitizer build used while debugging)
+    return os.environ.get("BARK_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libbark.so")
 
 
 def build_library(force: bool = False) -> str:
