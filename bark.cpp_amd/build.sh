@@ -8,7 +8,7 @@ mkdir -p "$OUT" "$OUT/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function -I$HERE/../include -I$SRC"
 pids=()
-for f in kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine.hip api.hip; do
+for f in kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_batch.hip engine_timing.hip api.hip; do
     o="$OUT/obj/${f%.*}.o"
     if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h' -newer "$o" 2>/dev/null | head -1)" ]; then
         $HIPCC $FLAGS -c "$SRC/$f" -o "$o" &

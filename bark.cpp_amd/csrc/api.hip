@@ -18,8 +18,9 @@ int64_t wall_us() {
 }
 // noexcept shell of every entry point.  Kernel launches are not checked one by one (hipLaunchKernelGGL), so the sticky launch
 // error is read here: a launch that was rejected means missing results, which must fail the call instead of returning them.
-template <typename F> auto guarded(const char * what, decltype(std::declval<F>()()) fail, F && f) -> decltype(f()) {
+template <typename F> auto guarded(const char * what, decltype(std::declval<F>()()) fail, F && f, bool uses_gpu = true) -> decltype(f()) {
     try {
+        if (!uses_gpu) return f();                                   // host-only entry points (bark_model_quantize) work without a device
         (void) hipGetLastError();
         auto r = f();
         const hipError_t e = hipGetLastError();
@@ -98,7 +99,7 @@ bool bark_model_quantize(const char * fname_inp, const char * fname_out, enum gg
         std::string err;
         if (!model_quantize(fname_inp, fname_out, (int) ftype, err)) { fprintf(stderr, "bark_model_quantize: %s\n", err.c_str()); return false; }
         return true;
-    });
+    }, /*uses_gpu=*/false);
 }
 
 void bark_free(struct bark_context * bctx) { delete bctx; }

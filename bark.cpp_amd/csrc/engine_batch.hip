@@ -1,0 +1,389 @@
+// engine_batch.hip - bark_hip_generate_batch: several utterances in lock step on one context.
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <stdexcept>
+
+using namespace barkhip;
+using namespace barkhip::detail;
+
+namespace barkhip {
+
+// ---------------------------------------------------------------------------------------------------
+// batched decode: B utterances advance in lock step through the semantic and coarse decode loops; every decode
+// kernel processes all slots (weights are read from HBM once per step instead of once per utterance), prefill,
+// fine passes and the codec still run per utterance.  Per-slot arithmetic is exactly the single-utterance one.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+void ensure_batch(bark_context * c, int B) {
+    bark_context::Batch & bb = c->batch;
+    if (bb.cap >= B) return;
+    if (bb.cap) throw std::runtime_error("batch capacity is fixed by the first bark_hip_generate_batch call of a context");
+    const int E = c->max_E;
+    for (int g = 0; g < 2; g++) {
+        GptModel & m = c->gpt[g];
+        bb.slot_stride[g] = m.kv_layer_stride * m.hp.n_layer;
+        bb.kc[g] = dev_alloc<float>(c, bb.slot_stride[g] * B);
+        bb.vc[g] = dev_alloc<float>(c, bb.slot_stride[g] * B);
+    }
+    bb.ld_logits = 0;
+    for (int g = 0; g < 2; g++) bb.ld_logits = std::max(bb.ld_logits, (size_t) c->gpt[g].hp.n_out_vocab);
+    bb.x = dev_alloc<float>(c, (size_t) B * E);
+    bb.q = dev_alloc<float>(c, (size_t) B * E);
+    bb.att = dev_alloc<half_t>(c, (size_t) B * E);
+    bb.h = dev_alloc<half_t>(c, (size_t) B * 4 * E);
+    bb.logits = dev_alloc<float>(c, (size_t) B * bb.ld_logits);
+    bb.state = dev_alloc<StepState>(c, (size_t) B);
+    bb.ln_stats = dev_alloc<float>(c, (size_t) B * 2);
+    bb.out_tokens = dev_alloc<int32_t>(c, (size_t) B * 2048);
+    bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
+    bb.u = dev_alloc<double>(c, (size_t) B * 8192);
+    if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
+    bb.cap = B;
+}
+
+void set_slot_state(bark_context * c, int slot, const StepState & st) {
+    HIP_OK(hipMemcpyAsync(c->batch.state + slot, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+std::vector<StepState> get_slot_states(bark_context * c, int B) {
+    std::vector<StepState> st((size_t) B);
+    HIP_OK(hipMemcpyAsync(st.data(), c->batch.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return st;
+}
+
+// all slots: layers -> LM head -> greedy sample (+ embedding of the sampled token)
+void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_context::Batch & bb) {
+    GptModel & m = c->gpt[s.which];
+    const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
+    hipStream_t st = c->stream;
+    float * kc0 = bb.kc[s.which], * vc0 = bb.vc[s.which];
+    const size_t slot = bb.slot_stride[s.which];
+    // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
+    // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
+    const bool hoist = B >= 24 && !m.q4;
+    for (int l = 0; l < m.hp.n_layer; l++) {
+        const GptModel::Layer & L = m.layers[(size_t) l];
+        float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
+        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+        LinArgs a;
+        a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
+        a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
+        launch_linear(st, a);
+        AttnDecodeArgs at;
+        at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
+        at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
+        launch_attn_decode_part(st, at, 4);
+        LinArgs p;
+        p.batched = 1; p.nbatch = B;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
+        launch_linear(st, p);
+        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+        LinArgs f;
+        f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
+        f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
+        launch_linear(st, f);
+        LinArgs o;
+        o.batched = 1; o.nbatch = B;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
+        launch_linear(st, o);
+    }
+    if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+    LinArgs h;
+    h.batched = 1; h.nbatch = B; h.ln_stats = hoist ? bb.ln_stats : nullptr;
+    if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, E); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * E;
+    h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b;
+    h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
+    launch_linear(st, h);
+    SampleArgs sa;
+    sa.logits = bb.logits; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
+    sa.token_base = s.token_base; sa.n_past_add = 1; sa.out_tokens = bb.out_tokens; sa.eos_trace = s.mode == 0 ? bb.eos_trace : nullptr;
+    sa.st = bb.state; sa.nbatch = B; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
+    sa.temp = s.temp; sa.u = bb.u; sa.u_stride = 8192;
+    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x;
+    launch_sample_greedy(st, sa);
+}
+
+void batch_step(bark_context * c, const StageCfg & s, int B) {
+    bark_context::Batch & bb = c->batch;
+    if (c->use_graph) {
+        if (bb.graph[s.which] && bb.graph_B[s.which] != B) { (void) hipGraphExecDestroy(bb.graph[s.which]); bb.graph[s.which] = nullptr; }
+        if (!bb.graph[s.which]) {
+            hipGraph_t graph = nullptr;
+            HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            try { enqueue_batch_step(c, s, B, bb); }
+            catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+            HIP_OK(hipStreamEndCapture(c->stream, &graph));
+            HIP_OK(hipGraphInstantiate(&bb.graph[s.which], graph, nullptr, nullptr, 0));
+            (void) hipGraphDestroy(graph);
+            bb.graph_B[s.which] = B;
+        }
+        HIP_OK(hipGraphLaunch(bb.graph[s.which], c->stream));
+        c->stats.graph_replays++;
+    } else {
+        enqueue_batch_step(c, s, B, bb);
+    }
+}
+
+// the buffers of slot b alone, as a batch of one
+bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b) {
+    bark_context::Batch v = c->batch;
+    const size_t E = (size_t) c->gpt[s.which].hp.n_embd;
+    for (int g = 0; g < 2; g++) { v.kc[g] += v.slot_stride[g] * (size_t) b; v.vc[g] += v.slot_stride[g] * (size_t) b; }
+    v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
+    if (v.att32) { v.att32 += E * b; v.h32 += 4 * E * b; }
+    v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b; v.u += (size_t) b * 8192;
+    v.graph[0] = v.graph[1] = nullptr;
+    return v;
+}
+void embed_slot(bark_context * c, const StageCfg & s, int b) {
+    GptModel & m = c->gpt[s.which];
+    EmbedArgs e;
+    e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1;
+    e.st = c->batch.state + b; e.x = c->batch.x + (size_t) b * m.hp.n_embd;
+    launch_embed_causal(c->stream, e);
+}
+
+// temp > 0: the next `n` uniform draws of a slot's own generator, taken from a COPY as in upload_uniforms()
+void upload_slot_uniforms(bark_context * c, int slot, const std::mt19937 & rng, int n) {
+    if (n > 8192) throw std::runtime_error("too many samples in one stage");
+    std::mt19937 tmp = rng;
+    std::vector<double> u((size_t) std::max(n, 1));
+    for (auto & v : u) v = std::generate_canonical<double, 53>(tmp);
+    HIP_OK(hipMemcpyAsync(c->batch.u + (size_t) slot * 8192, u.data(), (size_t) n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
+// prompt of one slot through the model (single-utterance kernels, the slot's own cache), first sample of the slot
+// L > 0: rows [0, L) of the prompt are already in the slot's cache (prefix reuse); only ids[L..] are evaluated
+void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, const std::vector<int32_t> & ids, bool merge, int step0, int L = 0) {
+    GptModel & m = c->gpt[s.which];
+    bark_context::Batch & bb = c->batch;
+    check_ids(ids.data(), ids.size(), m.hp.n_in_vocab, "batch prefill");
+    upload_tokens(c, ids.data() + L, ids.size() - (size_t) L);
+    StepState st = fresh_state(); st.step = step0; st.n_past = L;
+    set_slot_state(c, slot, st);
+    float * kb = bb.kc[s.which] + bb.slot_stride[s.which] * (size_t) slot, * vb = bb.vc[s.which] + bb.slot_stride[s.which] * (size_t) slot;
+    const int N = run_prefill(c, m, (int) ids.size() - L, merge, kb, vb, L);
+    LinArgs h;
+    if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, m.hp.n_embd); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd;
+    h.M = s.lm_rows; h.K = m.hp.n_embd; h.N = 1;
+    h.x_f32 = c->x + (size_t) (N - 1) * m.hp.n_embd; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
+    h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
+    launch_linear(c->stream, h);
+    SampleArgs sa;
+    sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
+    sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
+    sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
+    sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
+    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot * m.hp.n_embd;
+    launch_sample_greedy(c->stream, sa);
+}
+
+}  // namespace
+
+int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds) {
+    HIP_OK(hipSetDevice(c->device));
+    const bark_context_params & p = c->params;
+    if (n <= 0 || n > 32) throw std::runtime_error("generate_batch: batch size must be in 1..32");
+    c->batch_results.assign((size_t) n, bark_context::BatchResult());
+    // one generator per utterance (bark.cpp:1179 seeds one per context): utterance i of a batch is what a fresh context with
+    // seed seeds[i] would generate.  Without explicit seeds they are drawn from the context's generator, in order.
+    std::vector<std::mt19937> slot_rng((size_t) n);
+    for (int i = 0; i < n; i++) slot_rng[(size_t) i] = std::mt19937(seeds ? seeds[i] : (uint32_t) c->rng());
+    const bool sampled = p.temp != 0.0f;
+    if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) {
+        // host-side sampling and f32 model files keep one utterance in flight: fall back to the sequential loop
+        int good = 0;
+        for (int i = 0; i < n; i++) {
+            bark_context::BatchResult & r = c->batch_results[(size_t) i];
+            std::swap(c->rng, slot_rng[(size_t) i]);
+            try { r.ok = engine_generate(c, texts[i]); } catch (...) { std::swap(c->rng, slot_rng[(size_t) i]); throw; }
+            std::swap(c->rng, slot_rng[(size_t) i]);
+            if (r.ok) { r.semantic = c->semantic_tokens; r.coarse = c->coarse_tokens; r.fine = c->fine_tokens; r.audio = c->audio; good++; }
+        }
+        return good;
+    }
+    const int64_t t0 = now_us();
+    const int64_t t_load = c->stats.t_load_us;
+    c->stats = bark_hip_stats{};
+    c->stats.t_load_us = t_load;
+    const int B = n;
+    ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
+    bark_context::Batch & bb = c->batch;
+    if (B > bb.cap) throw std::runtime_error("generate_batch: batch larger than the capacity fixed by the first call");
+    HIP_OK(hipMemsetAsync(c->d_hmax, 0, 64 * sizeof(unsigned), c->stream));
+
+    // ---- semantic (bark.cpp:1645-1701), lock step -----------------------------------------------------
+    int64_t t = now_us();
+    {
+        GptModel & m = c->gpt[0];
+        const StageCfg s = stage_cfg(c, 0);
+        const int n_steps = std::max(0, std::min(p.n_steps_text_encoder, m.hp.block_size - 257 + 1));
+        PromptParams pp;
+        pp.block_size = m.hp.block_size; pp.text_encoding_offset = p.text_encoding_offset; pp.text_pad_token = p.text_pad_token;
+        pp.semantic_pad_token = p.semantic_pad_token; pp.semantic_infer_token = p.semantic_infer_token;
+        if (n_steps > 0) {
+            if (sampled) for (int b = 0; b < B; b++) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps);
+            for (int b = 0; b < B; b++) batch_prefill_and_sample(c, s, b, build_semantic_prompt(c->vocab, pp, texts[b], true), true, 0);
+            int issued = 1;
+            std::vector<StepState> st;
+            while (true) {
+                const int batch_end = std::min(n_steps, issued + 32);
+                for (; issued < batch_end; issued++) { batch_step(c, s, B); progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder)); }
+                st = get_slot_states(c, B);
+                bool all_done = true;
+                for (auto & v : st) all_done = all_done && v.eos_step != INT32_MAX;
+                if (all_done || issued >= n_steps) break;
+            }
+            for (int b = 0; b < B; b++) {
+                const int keep = std::min(st[(size_t) b].eos_step, issued);
+                auto & out = c->batch_results[(size_t) b].semantic;
+                out.resize((size_t) keep);
+                if (keep) HIP_OK(hipMemcpy(out.data(), bb.out_tokens + (size_t) b * 2048, (size_t) keep * 4, hipMemcpyDeviceToHost));
+                const int n_used = std::min(issued, st[(size_t) b].eos_step == INT32_MAX ? issued : st[(size_t) b].eos_step + 1);
+                c->stats.n_sample_semantic += n_used;
+                if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_used);      // as consume_uniforms()
+                c->stats.n_near_tie += st[(size_t) b].near_tie;
+            }
+        }
+    }
+    c->stats.t_semantic_us = now_us() - t;
+
+    // ---- coarse (bark.cpp:1745-1863), windows in lock step ---------------------------------------------
+    t = now_us();
+    std::vector<std::vector<int32_t>> coarse_out((size_t) B);
+    {
+        GptModel & m = c->gpt[1];
+        const StageCfg s = stage_cfg(c, 1);
+        if (p.n_coarse_codebooks != 2 || p.codebook_size != 1024 || p.sliding_window_size <= 0 || p.max_coarse_history < 0)
+            throw std::runtime_error("coarse: unsupported parameters");
+        const float stc_ratio = p.coarse_rate_hz / p.semantic_rate_hz * p.n_coarse_codebooks;
+        const int max_semantic_history = (int) floorf(p.max_coarse_history / stc_ratio);
+        std::vector<int> n_steps((size_t) B, 0), step_idx((size_t) B, 0);
+        int max_windows = 0;
+        for (int b = 0; b < B; b++) {
+            const auto & sem = c->batch_results[(size_t) b].semantic;
+            if (sem.empty()) continue;
+            n_steps[(size_t) b] = (int) (floorf(sem.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);
+            max_windows = std::max(max_windows, (int) ceilf((float) n_steps[(size_t) b] / p.sliding_window_size));
+            if (sampled) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps[(size_t) b]);          // indexed by the slot's step_idx
+        }
+        std::vector<std::vector<int32_t>> cached((size_t) B);          // per slot: ids whose K/V rows are in its cache
+        static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
+        for (int w = 0; w < max_windows; w++) {
+            int max_here = 0;
+            std::vector<int> here((size_t) B, 0), Ls((size_t) B, 0);
+            std::vector<std::vector<int32_t>> ins((size_t) B);
+            bool all_single = true;                                      // every live slot needs exactly one new row
+            for (int b = 0; b < B; b++) {
+                if (step_idx[(size_t) b] >= n_steps[(size_t) b]) continue;
+                const auto & sem = c->batch_results[(size_t) b].semantic;
+                auto & out = coarse_out[(size_t) b];
+                const int semantic_idx = (int) roundf(step_idx[(size_t) b] / stc_ratio);
+                std::vector<int32_t> in(sem.begin() + std::max(semantic_idx - max_semantic_history, 0), sem.end());
+                const size_t had = in.size();
+                in.resize(256);
+                for (size_t i = had; i < 256; i++) in[i] = p.coarse_semantic_pad_token;
+                in.push_back(p.coarse_infer_token);
+                const int nh = std::min(p.max_coarse_history, (int) out.size());
+                in.insert(in.end(), out.end() - nh, out.end());
+                here[(size_t) b] = std::min(p.sliding_window_size, n_steps[(size_t) b] - step_idx[(size_t) b]);
+                if ((int) in.size() + here[(size_t) b] - 1 > m.hp.block_size) throw std::runtime_error("coarse: window exceeds the context");
+                check_ids(in.data(), in.size(), m.hp.n_in_vocab, "coarse");
+                int L = 0;
+                if (reuse_prefix) {
+                    const auto & cd = cached[(size_t) b];
+                    while (L < (int) in.size() && L < (int) cd.size() && cd[(size_t) L] == in[(size_t) L]) L++;
+                    if (L >= (int) in.size()) L = (int) in.size() - 1;
+                }
+                Ls[(size_t) b] = L;
+                if ((int) in.size() - L != 1) all_single = false;
+                ins[(size_t) b] = std::move(in);
+                max_here = std::max(max_here, here[(size_t) b]);
+            }
+            int lock_steps = max_here - 1;                               // batched steps after every live slot has its first sample
+            for (int b = 0; b < B; b++) {
+                if (!here[(size_t) b]) {                                 // finished (or empty) slot: park it at position 0
+                    StepState idle = fresh_state(); idle.cur_token = 0;
+                    idle.step = w * p.sliding_window_size;          // same codebook parity as the live slots (slot 0's step selects the LM-head rows)
+                    set_slot_state(c, b, idle);
+                    continue;
+                }
+                const auto & in = ins[(size_t) b];
+                const int L = Ls[(size_t) b];
+                c->stats.n_prefix_rows_reused += L;
+                if ((int) in.size() - L == 1) {
+                    // the prompt is the cached sequence plus one token: a decode step (prefix reuse, see engine_coarse)
+                    StepState st1 = fresh_state(); st1.step = step_idx[(size_t) b]; st1.n_past = L; st1.cur_token = in[(size_t) L];
+                    set_slot_state(c, b, st1);
+                    embed_slot(c, s, b);
+                    if (!all_single) enqueue_batch_step(c, s, 1, slot_view(c, s, b));      // mixed window: this slot alone, eagerly
+                } else {
+                    batch_prefill_and_sample(c, s, b, in, false, step_idx[(size_t) b], L);
+                }
+            }
+            if (all_single && max_here > 0) lock_steps = max_here;       // the first sample of the window is a lock-step too
+            for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
+            const std::vector<StepState> st = get_slot_states(c, B);
+            for (int b = 0; b < B; b++) {
+                if (!here[(size_t) b]) continue;
+                std::vector<int32_t> got((size_t) here[(size_t) b]);
+                HIP_OK(hipMemcpy(got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4, hipMemcpyDeviceToHost));
+                coarse_out[(size_t) b].insert(coarse_out[(size_t) b].end(), got.begin(), got.end());
+                // rows now in the slot's cache: its prompt and every token fed back (a parked tail of lock steps past `here`
+                // wrote further rows, but those are never matched because the ids are not recorded)
+                cached[(size_t) b] = ins[(size_t) b];
+                cached[(size_t) b].insert(cached[(size_t) b].end(), got.begin(), got.end() - 1);
+                step_idx[(size_t) b] += here[(size_t) b];
+                c->stats.n_sample_coarse += here[(size_t) b];
+                c->stats.n_near_tie += st[(size_t) b].near_tie;
+            }
+            progress(c, COARSE, 100 * (w + 1) / std::max(1, max_windows));
+        }
+        for (int b = 0; b < B; b++) {
+            if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_steps[(size_t) b]);
+            auto & res = c->batch_results[(size_t) b].coarse;
+            const auto & out = coarse_out[(size_t) b];
+            for (size_t i = 0; i + 1 < out.size(); i += 2) {
+                res.push_back(out[i] - p.semantic_vocab_size);
+                res.push_back(out[i + 1] - p.semantic_vocab_size - p.codebook_size);
+            }
+        }
+    }
+    c->stats.t_coarse_us = now_us() - t;
+
+    // ---- fine + codec, one utterance at a time ------------------------------------------------------------
+    int good = 0;
+    for (int b = 0; b < B; b++) {
+        bark_context::BatchResult & r = c->batch_results[(size_t) b];
+        if (r.coarse.empty()) continue;
+        t = now_us();
+        std::swap(c->rng, slot_rng[(size_t) b]);                        // the fine stage draws from the utterance's generator
+        try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, slot_rng[(size_t) b]); throw; }
+        std::swap(c->rng, slot_rng[(size_t) b]);
+        c->stats.t_fine_us += now_us() - t;
+        const int T = (int) r.fine.size() / 8;
+        std::vector<int32_t> codes((size_t) 8 * T);
+        for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) codes[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];
+        t = now_us();
+        r.audio = engine_codec_decode(c, codes.data(), 8, T, -1, nullptr);
+        c->stats.t_codec_us += now_us() - t;
+        c->stats.n_frames += T; c->stats.n_samples += (int32_t) r.audio.size(); c->stats.n_semantic += (int32_t) r.semantic.size();
+        r.ok = true; good++;
+    }
+    c->stats.t_eval_us = now_us() - t0;
+    return good;
+}
+
+}  // namespace barkhip

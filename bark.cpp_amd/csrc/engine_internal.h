@@ -1,0 +1,71 @@
+// engine_internal.h - declarations shared by the engine's translation units (engine_load.hip: model upload; engine.hip:
+// building blocks and the stage loops; engine_batch.hip: lock-step batching; engine_timing.hip: bench hooks).  Not an API.
+#pragma once
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define HIP_OK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);   \
+    } while (0)
+
+namespace barkhip { namespace detail {
+
+inline int64_t now_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
+    void * p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ctx->allocs.push_back(p);
+    return (T *) p;
+}
+
+// rows [row0, ...) of a weight matrix behind a QMat handle (block formats or f32)
+inline QMat q4_rows(const QMat & w, size_t row0, int K) {
+    QMat r = w;
+    if (w.qt == QT_F32) { r.qs = w.qs + row0 * (size_t) K * 4; return r; }
+    const size_t nb = row0 * (size_t) (K / 32);
+    r.d = w.d + nb; r.qs = w.qs + nb * (size_t) quant_formats()[w.qt].qs_bytes;
+    if (w.m) r.m = w.m + nb;
+    if (w.qh) r.qh = w.qh + nb;
+    return r;
+}
+
+// ---- building blocks (engine.hip) ------------------------------------------------------------------
+double weight_bytes_per_element(const GptModel & m);
+float * layer_k(const GptModel & m, int l);
+float * layer_v(const GptModel & m, int l);
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0);
+void run_layers_decode(bark_context * c, GptModel & m);
+void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows);
+void set_state(bark_context * c, const StepState & st);
+StepState get_state(bark_context * c);
+StepState fresh_state();
+void upload_tokens(bark_context * c, const int32_t * tok, size_t n);
+void check_ids(const int32_t * tok, size_t n, int n_in, const char * what);
+int run_prefill(bark_context * c, GptModel & m, int n_tokens, bool merge, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0);
+struct StageCfg {            // what differs between the semantic and the coarse decode step
+    int which; int mode; int lm_row0, lm_rows, parity_rows; int token_base; float min_eos_p; int eos_token; float temp;
+};
+StageCfg stage_cfg(bark_context * c, int which);
+void run_sample(bark_context * c, const StageCfg & s, int n_past_add);
+void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add, bool embed = true);
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add);
+void decode_step_greedy(bark_context * c, const StageCfg & s);
+int sample_host(std::vector<float> & l, std::mt19937 & rng, float temp, float * eos_p);
+std::vector<float> fetch_logits(bark_context * c, size_t n);
+void upload_uniforms(bark_context * c, int n);
+void consume_uniforms(bark_context * c, int n_used);
+void progress(bark_context * c, bark_encoding_step step, int pct);
+void run_fine_forward(bark_context * c, int nn, int n_rows);
+
+} }  // namespace barkhip::detail
