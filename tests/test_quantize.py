@@ -163,3 +163,29 @@ def test_quantize_rejects_other_types_and_bad_paths(toy_model, tmp_path):
     q = str(tmp_path / "q.bin")
     assert lib.bark_model_quantize(toy_model.encode(), q.encode(), 2)
     assert not lib.bark_model_quantize(q.encode(), str(tmp_path / "qq.bin").encode(), 7)            # already quantised
+
+
+def test_malformed_model_files_are_rejected_cleanly(toy_model, tmp_path):
+    """The container parser (model_file.cpp) on damaged input: truncation anywhere, bad magic, absurd counts - `false` and a
+    message, never a crash (bark.cpp:1095-1102 checks the magic; the reference trusts everything after it)."""
+    from bark_amd_loader import load_package
+    lib = load_package().load_library()
+    raw = open(toy_model, "rb").read()
+    out = str(tmp_path / "out.bin").encode()
+    rng = np.random.default_rng(3)
+    cuts = [0, 3, 4, 8, 100, len(raw) // 3, len(raw) - 1] + [int(v) for v in rng.integers(8, len(raw) - 1, 12)]
+    for i, cut in enumerate(cuts):
+        p = tmp_path / f"cut{i}.bin"
+        p.write_bytes(raw[:cut])
+        assert not lib.bark_model_quantize(str(p).encode(), out, 2), cut
+    bad = bytearray(raw); bad[0] ^= 0xFF
+    (tmp_path / "magic.bin").write_bytes(bytes(bad))
+    assert not lib.bark_model_quantize(str(tmp_path / "magic.bin").encode(), out, 2)
+    bad = bytearray(raw); bad[4:8] = struct.pack("<i", 2**30)                     # vocabulary size
+    (tmp_path / "vocab.bin").write_bytes(bytes(bad))
+    assert not lib.bark_model_quantize(str(tmp_path / "vocab.bin").encode(), out, 2)
+    # a flipped tensor-type field somewhere inside the first GPT section
+    off = raw.index(b"model/wpe") - 4 * 3 - 8
+    bad = bytearray(raw); bad[off + 8:off + 12] = struct.pack("<i", 77)
+    (tmp_path / "ttype.bin").write_bytes(bytes(bad))
+    assert not lib.bark_model_quantize(str(tmp_path / "ttype.bin").encode(), out, 2)
