@@ -12,6 +12,14 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    # a fresh checkout has no binaries (they are git-ignored): build the product library and the oracle once, exactly as
+    # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  A failed build fails the run - no fallback.
+    import subprocess
+    lib = os.path.join(ROOT, "bark.cpp_amd", "lib", "libbark.so")
+    if not os.path.exists(lib):
+        subprocess.check_call([os.path.join(ROOT, "bark.cpp_amd", "build.sh")])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "build", "libbark_oracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
 
 
 @pytest.fixture(scope="session")
