@@ -105,7 +105,8 @@ BARK_API int64_t bark_get_load_time(struct bark_context * bctx);
 BARK_API int64_t bark_get_eval_time(struct bark_context * bctx);
 BARK_API void    bark_reset_statistics(struct bark_context * bctx);
 
-/* reference bark.h:229-232 - offline tool, out of scope for the hot path: always returns false */
+/* reference bark.h:229-232 - rewrites an f16 / f32 model file with the GPT matrices in a ggml block format (q4_0, q4_1, q5_0,
+ * q5_1, q8_0: the types of examples/quantize); host-only, needs no GPU; false + a message on stderr for anything else */
 BARK_API bool bark_model_quantize(const char * fname_inp, const char * fname_out, enum ggml_ftype ftype);
 
 /* reference bark.h:239-240 ; NULL-safe */

@@ -117,7 +117,7 @@ BARK_API double bark_hip_time_decode_step(struct bark_context * bctx, int which,
 
 /* Device time (us) of ONE decode GEMV kernel launch (gemv_kernel), averaged over `iters` back-to-back launches that
  * rotate through the layers' weights.  op: 0 LN+QKV, 1 attention out-proj, 2 LN+FC+GELU, 3 MLP out-proj.
- * *bytes_per_launch receives the algorithmic bytes (the f16 weight matrix). */
+ * *bytes_per_launch receives the algorithmic bytes (the weight matrix in the file's format: f16, f32 or blocks). */
 BARK_API double bark_hip_time_gemv(struct bark_context * bctx, int which, int op, int iters, double * bytes_per_launch);
 
 /* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
