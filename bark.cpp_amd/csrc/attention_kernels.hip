@@ -213,7 +213,12 @@ __global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a
     __shared__ float red_f[4];
     __shared__ double red_d[4];
     __shared__ float part[16][16];
-    const int h = blockIdx.x, s = blockIdx.y;
+    // workgroup id -> (head, slice) such that the ATTN_SPLIT slices of a head have ids congruent mod 8: under the round-robin
+    // workgroup -> XCD dispatch they share one XCD, so the head's K rows are fetched from HBM once and the other slices hit that
+    // L2 (FETCH_SIZE showed 2.4x the algorithmic bytes when the slices were spread over XCDs).  Speed only; any placement is correct.
+    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // id = x8 + 8 * g8, g8 = s + ATTN_SPLIT * (h / 8), x8 = h % 8
+    const int h = x8 + 8 * (g8 / ATTN_SPLIT), s = g8 % ATTN_SPLIT;
+    if (h >= a.H) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
     const float * __restrict__ qh = a.q + h * 64;
@@ -286,7 +291,7 @@ void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts)
     if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
     if (parts == 5) {
         if (a.nbatch != 1 || a.P != 1024) { fprintf(stderr, "bark-hip: value-sliced decode attention needs one sequence and block_size 1024\n"); abort(); }
-        hipLaunchKernelGGL(attn_dslice_kernel, dim3(a.H, ATTN_SPLIT), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(attn_dslice_kernel, dim3(8 * ATTN_SPLIT * ((a.H + 7) / 8)), dim3(256), 0, s, a);
         return;
     }
     if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
