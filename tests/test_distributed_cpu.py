@@ -45,3 +45,21 @@ def test_two_rank_sharding_and_reduction(tmp_path):
     import bench
     prompts = bench.synth_prompts(64)
     assert out["prompts"][0] == [prompts[0], prompts[2], prompts[4], prompts[6]]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_small_n1.json is a bench.py line from the GPU box: keys and units of the driver's contract."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_small_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and d["value"] > 10.0 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
