@@ -107,10 +107,10 @@ def load_library() -> C.CDLL:
     lib.bark_hip_bert_tokenize.argtypes = [vp, C.c_char_p, ip, C.c_int]
     lib.bark_hip_gpt_eval.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int, C.c_int, fp]
     lib.bark_hip_fine_eval.argtypes = [vp, ip, C.c_int, fp]
-    lib.bark_hip_semantic.argtypes = [vp, ip, ip, fp]
-    lib.bark_hip_coarse.argtypes = [vp, ip, C.c_int, ip]
-    lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip]
-    lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp]
+    lib.bark_hip_semantic.argtypes = [vp, ip, ip, C.c_int, fp]
+    lib.bark_hip_coarse.argtypes = [vp, ip, C.c_int, ip, C.c_int]
+    lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip, C.c_int]
+    lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_generate_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
     lib.bark_hip_generate_batch_seeded.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint32)]
@@ -246,16 +246,17 @@ class BarkContext:
         prompt = _i32(prompt513)
         assert prompt.shape == (513,)
         out = np.zeros(1024, np.int32)
-        tr = np.zeros(1024, np.float32)
-        n = self._lib.bark_hip_semantic(self._h, prompt.ctypes.data, out.ctypes.data, tr.ctypes.data if want_eos_trace else None)
+        tr = np.zeros(1025, np.float32)
+        n = self._lib.bark_hip_semantic(self._h, prompt.ctypes.data, out.ctypes.data, 1024, tr.ctypes.data if want_eos_trace else None)
         if n < 0:
             raise RuntimeError("bark_hip_semantic failed")
         return (out[:n].copy(), tr) if want_eos_trace else out[:n].copy()
 
     def coarse(self, semantic) -> np.ndarray:
         sem = _i32(semantic)
-        out = np.zeros((4096, 2), np.int32)
-        T = self._lib.bark_hip_coarse(self._h, sem.ctypes.data, len(sem), out.ctypes.data)
+        cap = int(len(sem) * 75.0 / 49.9) + 8          # T = floor(n_sem * coarse_rate / semantic_rate) with the default rates
+        out = np.zeros((cap, 2), np.int32)
+        T = self._lib.bark_hip_coarse(self._h, sem.ctypes.data, len(sem), out.ctypes.data, cap)
         if T < 0:
             raise RuntimeError("bark_hip_coarse failed")
         return out[:T].copy()
@@ -263,7 +264,7 @@ class BarkContext:
     def fine(self, coarse_Tx2) -> np.ndarray:
         co = _i32(coarse_Tx2).reshape(-1, 2)
         out = np.zeros((max(len(co), 1), 8), np.int32)
-        T = self._lib.bark_hip_fine(self._h, co.ctypes.data, len(co), out.ctypes.data)
+        T = self._lib.bark_hip_fine(self._h, co.ctypes.data, len(co), out.ctypes.data, len(out))
         if T < 0:
             raise RuntimeError("bark_hip_fine failed")
         return out[:T].copy()
@@ -272,7 +273,7 @@ class BarkContext:
         codes = _i32(codes_qxT)
         n_q, T = codes.shape
         pcm = np.zeros(T * 320, np.float32)
-        n = self._lib.bark_hip_codec_decode(self._h, codes.ctypes.data, n_q, T, pcm.ctypes.data)
+        n = self._lib.bark_hip_codec_decode(self._h, codes.ctypes.data, n_q, T, pcm.ctypes.data, pcm.size)
         if n < 0:
             raise RuntimeError("bark_hip_codec_decode failed")
         return pcm[:n].copy()
@@ -306,7 +307,7 @@ class BarkContext:
                 continue
             d = {"pcm": np.ctypeslib.as_array(p, shape=(ns,)).copy() if ns else np.zeros(0, np.float32)}
             for stage, (name, w) in enumerate((("semantic", 1), ("coarse", 2), ("fine", 8))):
-                buf = np.zeros(32768, np.int32)
+                buf = np.zeros(65536, np.int32)
                 k = self._lib.bark_hip_batch_tokens(self._h, i, stage, buf.ctypes.data, buf.size)
                 d[name] = buf[:max(k, 0)].copy().reshape(-1, w) if w > 1 else buf[:max(k, 0)].copy()
             out.append(d)
@@ -333,13 +334,13 @@ class BarkContext:
         return out[:max(n, 0)].copy()
 
     def coarse_tokens(self) -> np.ndarray:
-        out = np.zeros((4096, 2), np.int32)
-        n = self._lib.bark_hip_get_coarse_tokens(self._h, out.ctypes.data, 4096)
+        out = np.zeros((8192, 2), np.int32)            # engine_fine accepts up to 8192 frames
+        n = self._lib.bark_hip_get_coarse_tokens(self._h, out.ctypes.data, 8192)
         return out[:max(n, 0)].copy()
 
     def fine_tokens(self) -> np.ndarray:
-        out = np.zeros((4096, 8), np.int32)
-        n = self._lib.bark_hip_get_fine_tokens(self._h, out.ctypes.data, 4096)
+        out = np.zeros((8192, 8), np.int32)
+        n = self._lib.bark_hip_get_fine_tokens(self._h, out.ctypes.data, 8192)
         return out[:max(n, 0)].copy()
 
     def stats(self) -> dict:

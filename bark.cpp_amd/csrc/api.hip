@@ -154,40 +154,45 @@ int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * tokens_8x1024
     return guarded("bark_hip_fine_eval", -1, [&] { engine_fine_eval(bctx, tokens_8x1024, nn, logits); return 0; });
 }
 
-int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, float * eos_trace) {
-    if (!bctx || !prompt513 || !out) return -1;
+int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, int capacity, float * eos_trace) {
+    if (!bctx || !prompt513 || !out || capacity < 0) return -1;
     return guarded("bark_hip_semantic", -1, [&] {
         std::vector<int32_t> prompt(prompt513, prompt513 + 513);
         std::vector<float> tr;
         std::vector<int32_t> r = engine_semantic(bctx, prompt, eos_trace ? &tr : nullptr);
+        // the trace holds one entry per evaluated step: at most one more than the ids kept
+        if ((int) r.size() > capacity || (eos_trace && (int) tr.size() > capacity + 1)) throw std::runtime_error("output buffer too small");
         if (!r.empty()) memcpy(out, r.data(), r.size() * 4);
         if (eos_trace && !tr.empty()) memcpy(eos_trace, tr.data(), tr.size() * 4);
         return (int) r.size();
     });
 }
 
-int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2) {
+int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2, int capacity_rows) {
     if (!bctx || !semantic || n_semantic <= 0 || !out_Tx2) return -1;
     return guarded("bark_hip_coarse", -1, [&] {
         std::vector<int32_t> r = engine_coarse(bctx, std::vector<int32_t>(semantic, semantic + n_semantic));
+        if ((int) (r.size() / 2) > capacity_rows) throw std::runtime_error("output buffer too small");
         memcpy(out_Tx2, r.data(), r.size() * 4);
         return (int) r.size() / 2;
     });
 }
 
-int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8) {
+int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8, int capacity_rows) {
     if (!bctx || !coarse_Tx2 || T <= 0 || !out_Tx8) return -1;
     return guarded("bark_hip_fine", -1, [&] {
         std::vector<int32_t> r = engine_fine(bctx, std::vector<int32_t>(coarse_Tx2, coarse_Tx2 + (size_t) T * 2));
+        if ((int) (r.size() / 8) > capacity_rows) throw std::runtime_error("output buffer too small");
         memcpy(out_Tx8, r.data(), r.size() * 4);
         return (int) r.size() / 8;
     });
 }
 
-int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm) {
+int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm, int capacity) {
     if (!bctx || !codes || !pcm) return -1;
     return guarded("bark_hip_codec_decode", -1, [&] {
         std::vector<float> r = engine_codec_decode(bctx, codes, n_q, T, -1, nullptr);
+        if ((int) r.size() > capacity) throw std::runtime_error("output buffer too small");
         memcpy(pcm, r.data(), r.size() * 4);
         return (int) r.size();
     });

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
     if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
     if (parts == 5) {
-        if (a.nbatch != 1 || a.P != 1024) { fprintf(stderr, "bark-hip: value-sliced decode attention needs one sequence and block_size 1024\n"); abort(); }
+        if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: value-sliced decode attention needs one sequence and block_size 1024"); }
         hipLaunchKernelGGL(attn_dslice_kernel, dim3(8 * ATTN_SPLIT * ((a.H + 7) / 8)), dim3(256), 0, s, a);
         return;
     }

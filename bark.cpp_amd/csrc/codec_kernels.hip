@@ -192,14 +192,14 @@ void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int 
     const int co_grp = cout >= 4 ? 4 : 1;
     dim3 grid((T + 256 * TT - 1) / (256 * TT), (cout + co_grp - 1) / co_grp), block(256);
 #define LAUNCH_CONV(CO, KK) hipLaunchKernelGGL((conv1d_blocked_kernel<CO, TT, KK>), grid, block, 0, s, w, bias, cout, cin, xh, T, add, y)
-    if (co_grp == 4) { if (K == 7) LAUNCH_CONV(4, 7); else if (K == 3) LAUNCH_CONV(4, 3); else if (K == 1) LAUNCH_CONV(4, 1); else abort(); }
-    else             { if (K == 7) LAUNCH_CONV(1, 7); else if (K == 3) LAUNCH_CONV(1, 3); else if (K == 1) LAUNCH_CONV(1, 1); else abort(); }
+    if (co_grp == 4) { if (K == 7) LAUNCH_CONV(4, 7); else if (K == 3) LAUNCH_CONV(4, 3); else if (K == 1) LAUNCH_CONV(4, 1); else kernel_fail("bark-hip: unsupported convolution kernel size %d", K); }
+    else             { if (K == 7) LAUNCH_CONV(1, 7); else if (K == 3) LAUNCH_CONV(1, 3); else if (K == 1) LAUNCH_CONV(1, 1); else kernel_fail("bark-hip: unsupported convolution kernel size %d", K); }
 #undef LAUNCH_CONV
 }
 bool conv1d_f32w_supported(int K) { return K == 7 || K == 3 || K == 1; }
 
 void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh, int T, float * y) {
-    if (K != 2 * stride) abort();
+    if (K != 2 * stride) kernel_fail("bark-hip: transposed convolution needs kernel == 2 * stride (got %d, %d)", K, stride);
     const int KB = stride % 4 == 0 ? 4 : (stride % 2 == 0 ? 2 : 1);
     const int CO = cout >= 2 ? 2 : 1;
     dim3 grid((T + 255) / 256, ((cout + CO - 1) / CO) * (stride / KB)), block(256);

@@ -268,6 +268,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         const StageCfg s = stage_cfg(c, 1);
         if (p.n_coarse_codebooks != 2 || p.codebook_size != 1024 || p.sliding_window_size <= 0 || p.max_coarse_history < 0)
             throw std::runtime_error("coarse: unsupported parameters");
+        if (s.lm_row0 + 2 * s.lm_rows > m.hp.n_out_vocab) throw std::runtime_error("coarse: vocabulary too small");
         const float stc_ratio = p.coarse_rate_hz / p.semantic_rate_hz * p.n_coarse_codebooks;
         const int max_semantic_history = (int) floorf(p.max_coarse_history / stc_ratio);
         std::vector<int> n_steps((size_t) B, 0), step_idx((size_t) B, 0);

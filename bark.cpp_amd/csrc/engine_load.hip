@@ -30,12 +30,18 @@ struct SlabPlan {
     }
 };
 
+// ne0 / ne1 > 0: the tensor must have exactly that rank-1 / rank-2 shape (every further dim 1; bark.cpp:1034 compares ne[0], ne[1]);
+// ne0 == 0: any shape (the caller checks it)
 const TensorRef & need(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0, int64_t ne1) {
     auto it = m.find(name);
     if (it == m.end()) throw std::runtime_error("missing tensor '" + name + "'");
     const TensorRef & t = it->second;
-    if (ne0 > 0 && (t.ne[0] != ne0 || (ne1 > 0 && t.ne[1] != ne1)))       // shape check on ne[0], ne[1] (bark.cpp:1034)
-        throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
+    if (ne0 > 0) {
+        const int rank = ne1 > 0 ? 2 : 1;
+        bool ok = t.n_dims >= 1 && t.n_dims <= 4 && t.ne[0] == ne0 && (rank == 1 || t.ne[1] == ne1);
+        for (int i = rank; i < 4; i++) ok = ok && t.ne[i] == 1;
+        if (!ok) throw std::runtime_error("tensor '" + name + "' has an unexpected shape");
+    }
     if (t.ttype != ttype)
         throw std::runtime_error("tensor '" + name + "' is " + (quant_format_by_type(t.ttype) ? quant_format_by_type(t.ttype)->name : t.ttype ? "f16" : "f32") +
                                  ", expected " + (ttype == 1 ? "f16" : ttype == 0 ? "f32" : "another type"));
@@ -50,7 +56,7 @@ const TensorRef & need_w(const std::map<std::string, TensorRef> & m, const std::
 const TensorRef * maybe(const std::map<std::string, TensorRef> & m, const std::string & name, int ttype, int64_t ne0) {
     auto it = m.find(name);
     if (it == m.end()) return nullptr;
-    if (it->second.ne[0] != ne0 || it->second.ttype != ttype) throw std::runtime_error("tensor '" + name + "' has an unexpected shape/type");
+    if (it->second.ne[0] != ne0 || it->second.nelements() != ne0 || it->second.ttype != ttype) throw std::runtime_error("tensor '" + name + "' has an unexpected shape/type");
     return &it->second;
 }
 
@@ -204,7 +210,10 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         const auto & T = mf.gpt[g].tensors;
         const int E = m.hp.n_embd;
         if (E / m.hp.n_head != 64) throw std::runtime_error("head_dim must be 64");
-        if (E % 128 != 0 || E > 1024) throw std::runtime_error("n_embd must be a multiple of 128 and <= 1024");
+        // the decode GEMV is instantiated for K / 128 in {1, 2, 4, 6, 8} (and 4x those): kernels.hip
+        if (E != 128 && E != 256 && E != 512 && E != 768 && E != 1024) throw std::runtime_error("n_embd must be one of 128, 256, 512, 768, 1024");
+        // the sampling kernels hold up to 12288 logits in registers (misc_kernels.hip)
+        if (m.hp.n_in_vocab <= 0 || m.hp.n_out_vocab <= 0 || m.hp.n_out_vocab > 12288) throw std::runtime_error("vocabulary sizes must be in 1..12288 (output) and positive (input)");
         if (m.hp.block_size != 1024) throw std::runtime_error("block_size must be 1024");
         if (m.hp.n_wtes > 8 || m.hp.n_lm_heads > 8 || m.hp.n_layer > 64) throw std::runtime_error("unsupported GPT shape");
         m.layers.resize((size_t) m.hp.n_layer);
@@ -239,7 +248,9 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         ctx->max_E = std::max(ctx->max_E, E);
         ctx->max_H = std::max(ctx->max_H, m.hp.n_head);
     }
-    if (ctx->gpt[2].hp.n_wtes != 8 || ctx->gpt[2].hp.n_lm_heads < 6) throw std::runtime_error("fine model must have 8 embeddings and >= 6 heads");
+    // the fine stage predicts codebook nn = 2..7 with lm_heads[nn - 1] (n_codes_given = 1, bark.cpp:1573) over logits [0, 1024)
+    if (ctx->gpt[2].hp.n_wtes != 8 || ctx->gpt[2].hp.n_lm_heads < 7) throw std::runtime_error("fine model must have 8 embeddings and >= 7 heads");
+    if (ctx->gpt[2].hp.n_out_vocab < 1024 || ctx->gpt[2].hp.n_in_vocab < 1025) throw std::runtime_error("fine model vocabulary is smaller than a codebook");
 
     // ---- codec -------------------------------------------------------------------------------------
     CodecModel & cm = ctx->codec;
@@ -265,6 +276,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         const auto & T = mf.codec;
         auto conv = [&](const std::string & p, CodecModel::Conv & cv) {
             const TensorRef & w = codec_weight(p + ".weight", 0, 0);
+            if (w.n_dims != 3 || w.ne[3] != 1 || w.ne[0] > 64 || w.ne[1] > 4096 || w.ne[2] > 4096) throw std::runtime_error("codec conv weight '" + p + "' has an unexpected shape");
             cv.k = (int) w.ne[0]; cv.cin = (int) w.ne[1]; cv.cout = (int) w.ne[2];
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
@@ -273,15 +285,18 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         };
         auto convt = [&](const std::string & p, CodecModel::ConvT & cv, int stride) {
             const TensorRef & w = codec_weight(p + ".weight", 0, 0);
+            if (w.n_dims != 3 || w.ne[3] != 1 || w.ne[0] < stride || w.ne[0] > 64 || w.ne[1] > 4096 || w.ne[2] > 4096) throw std::runtime_error("codec transposed-conv weight '" + p + "' has an unexpected shape");
             cv.k = (int) w.ne[0]; cv.cout = (int) w.ne[1]; cv.cin = (int) w.ne[2]; cv.stride = stride;
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
             if (b.nelements() != cv.cout) throw std::runtime_error("codec bias size mismatch at " + p);
             place(b, (const void **) &cv.b);
         };
+        if (cm.hp.hidden_dim <= 0 || cm.hp.hidden_dim > 4096 || cm.hp.n_bins <= 0 || cm.hp.n_bins > (1 << 20)) throw std::runtime_error("implausible codec hparams");
         conv("decoder.model.0.conv.conv", cm.init);
+        if (cm.init.cin != cm.hp.hidden_dim) throw std::runtime_error("codec: the first conv does not take hidden_dim channels");
         cm.D = cm.init.cout;
-        if (cm.D % 128 != 0) throw std::runtime_error("codec LSTM width must be a multiple of 128");
+        if (cm.D % 128 != 0 || cm.D > 1024) throw std::runtime_error("codec LSTM width must be a multiple of 128 and <= 1024");
         for (int l = 0; l < 2; l++) {
             const std::string s = std::to_string(l);
             place(codec_weight("decoder.model.1.lstm.weight_ih_l" + s, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_ih);
@@ -298,6 +313,17 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             conv("decoder.model." + std::to_string(idx + 1) + ".shortcut.conv.conv", cm.blocks[i].sc);
         }
         conv("decoder.model.15.conv.conv", cm.fin);
+        // channel continuity of the decoder stack (modeling_encodec.py:316-347)
+        int ch = cm.D;
+        bool chain_ok = true;
+        for (int i = 0; i < 4; i++) {
+            const CodecModel::Block & b = cm.blocks[i];
+            chain_ok = chain_ok && b.up.cin == ch && b.c1.cin == b.up.cout && b.c2.cin == b.c1.cout && b.c2.cout == b.up.cout &&
+                       b.sc.cin == b.up.cout && b.sc.cout == b.up.cout;
+            ch = b.up.cout;
+        }
+        chain_ok = chain_ok && cm.fin.cin == ch && cm.fin.cout == 1;
+        if (!chain_ok) throw std::runtime_error("codec: decoder convolutions do not chain (channel counts)");
         // codebooks are uploaded contiguously (separate allocation below)
         while (T.count("quantizer.vq.layers." + std::to_string(cm.n_q) + "._codebook.embed")) cm.n_q++;
         if (cm.n_q == 0) throw std::runtime_error("codec has no codebooks");

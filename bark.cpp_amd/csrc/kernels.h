@@ -14,6 +14,10 @@ namespace barkhip {
 
 typedef _Float16 half_t;
 
+// Launch-side rejection of a shape no kernel is instantiated for: throws std::runtime_error (printf-style message), which the
+// C API turns into nullptr / false / -1 like every other failure (api.hip) - the host process is never aborted.
+[[noreturn]] void kernel_fail(const char * fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // Device-resident state of one autoregressive stage; kernels read/advance it so that a captured
 // hipGraph of one decode step can be replayed without host-side parameter updates.
 struct StepState {

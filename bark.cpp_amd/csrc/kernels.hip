@@ -14,10 +14,21 @@
 #include "device_utils.h"
 
 #include <cfloat>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 
 namespace barkhip {
+
+void kernel_fail(const char * fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw std::runtime_error(buf);
+}
 
 // ------------------------------------------------------------------------------------------------
 // decode GEMV.  One wave = 4 output rows x 16 lanes; lane c of a row owns chain c of C1, i.e. the
@@ -126,7 +137,7 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
         if constexpr (NBLK <= 8) {
             if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
             else        hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);
-        } else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
+        } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
     } else {
         hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a);
     }
@@ -255,7 +266,7 @@ static void launch_gemv_batch_n(hipStream_t s, const LinArgs & a) {
         if constexpr (NBLK <= 8) {
             if (a.ln_b) hipLaunchKernelGGL((gemv_batch_kernel<NBLK, true, true, BPW>), grid, block, 0, s, a);
             else        hipLaunchKernelGGL((gemv_batch_kernel<NBLK, true, false, BPW>), grid, block, 0, s, a);
-        } else { fprintf(stderr, "bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024\n"); abort(); }
+        } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
     } else {
         hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, BPW>), grid, block, 0, s, a);
     }
@@ -431,8 +442,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
 void launch_linear(hipStream_t s, const LinArgs & a) {
     if (a.wq.qs && a.wq.qt == QT_F32) { launch_linear_w32(s, a); return; }
     if (a.wq.qs) { launch_linear_q(s, a); return; }
-    if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in linear op\n", a.K); abort(); }
-    if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { fprintf(stderr, "bark-hip: batched linear op needs M %% 4 == 0\n"); abort(); }
+    if ((a.K & 127) != 0 || a.K > 4096) { kernel_fail("bark-hip: unsupported K=%d in linear op", a.K); }
+    if (a.N > 1 && ((a.M & 3) || (a.epi == EPI_LOGITS && (a.ld_out & 3)))) { kernel_fail("bark-hip: batched linear op needs M %% 4 == 0"); }
     const int nblk = a.K >> 7;
     if (a.batched) {
         switch (nblk) {
@@ -444,7 +455,7 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
             case 16: launch_gemv_batch_n<16>(s, a); break;
             case 24: launch_gemv_batch_n<24>(s, a); break;
             case 32: launch_gemv_batch_n<32>(s, a); break;
-            default: fprintf(stderr, "bark-hip: unsupported K=%d in batched decode GEMV\n", a.K); abort();
+            default: kernel_fail("bark-hip: unsupported K=%d in batched decode GEMV", a.K);
         }
         return;
     }
@@ -458,11 +469,11 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
             case 16: launch_gemv_n<16>(s, a); break;
             case 24: launch_gemv_n<24>(s, a); break;
             case 32: launch_gemv_n<32>(s, a); break;
-            default: fprintf(stderr, "bark-hip: unsupported K=%d in decode GEMV\n", a.K); abort();
+            default: kernel_fail("bark-hip: unsupported K=%d in decode GEMV", a.K);
         }
         return;
     }
-    if (a.x_f32 || a.parity_rows) { fprintf(stderr, "bark-hip: batched linear op needs f16 rows\n"); abort(); }
+    if (a.x_f32 || a.parity_rows) { kernel_fail("bark-hip: batched linear op needs f16 rows"); }
     static const bool force_rows = getenv("BARK_HIP_GEMM_ROWS") != nullptr;      // cross-check path
     if (force_rows) {
         dim3 grid((a.M + 15) / 16, a.N), block(256);

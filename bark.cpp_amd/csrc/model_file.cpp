@@ -32,9 +32,13 @@ bool read_record(Cursor & c, std::string & name, TensorRef & t, std::string & er
     const int32_t name_len = c.get<int32_t>();
     t.ttype = c.get<int32_t>();
     if (!c.ok || t.n_dims < 0 || t.n_dims > 4 || name_len < 0 || name_len > 1024) { err = "corrupt tensor record header"; return false; }
+    int64_t count = 1;
     for (int i = 0; i < t.n_dims; i++) {
         t.ne[i] = c.get<int32_t>();
         if (t.ne[i] <= 0) { err = "corrupt tensor dims"; return false; }
+        // the element count can never exceed what the file could hold (>= 0.5 byte per element): bounds it far below 2^63
+        if (t.ne[i] > (int64_t) (2 * c.size) / count) { err = "tensor dims exceed the file size"; return false; }
+        count *= t.ne[i];
     }
     const uint8_t * nm = c.take((size_t) name_len);
     if (!c.ok) { err = "truncated tensor name"; return false; }

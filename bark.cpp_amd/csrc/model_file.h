@@ -57,7 +57,8 @@ struct ModelFile {
     ModelFile(const ModelFile &) = delete;
     ModelFile & operator=(const ModelFile &) = delete;
     ~ModelFile();
-    // Returns false (message in err) on any malformed / unsupported input.
+    // Returns false (message in err) when the container itself is malformed (magic, counts, record headers, dims that
+    // overflow or exceed the file, unknown types, truncation).  Shapes are checked against the hparams by the engine's loader.
     bool open(const char * path, std::string & err);
 };
 

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_q_mfma_kernel(const QRowsArgs qa) {
 }
 
 void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * ln_g, const float * ln_b, const Q8Scratch & o) {
-    if (N > 1024) { fprintf(stderr, "bark-hip: q8 row quantisation handles at most 1024 rows\n"); abort(); }
+    if (N > 1024) { kernel_fail("bark-hip: q8 row quantisation handles at most 1024 rows"); }
     Q8RowsArgs a{x, N, K, ln_g, ln_b, o.q, o.d, o.dT, o.s, o.sT};
     hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
 }
@@ -430,17 +430,17 @@ void init_quant_attributes() {
 }
 
 void launch_linear_q(hipStream_t s, const LinArgs & a) {
-    if ((a.K & 31) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: quantised rows must be a multiple of 32 and at most 4096 long\n"); abort(); }
-    if (a.batched && (a.N != 1 || a.ln_stats)) { fprintf(stderr, "bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics\n"); abort(); }
-    if (a.N == 1 && !a.x_f32) { fprintf(stderr, "bark-hip: quantised GEMV needs an f32 activation row\n"); abort(); }
-    if (a.N > 1 && (!a.xq.q || a.parity_rows)) { fprintf(stderr, "bark-hip: quantised row product needs pre-quantised rows\n"); abort(); }
+    if ((a.K & 31) != 0 || a.K > 4096) { kernel_fail("bark-hip: quantised rows must be a multiple of 32 and at most 4096 long"); }
+    if (a.batched && (a.N != 1 || a.ln_stats)) { kernel_fail("bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics"); }
+    if (a.N == 1 && !a.x_f32) { kernel_fail("bark-hip: quantised GEMV needs an f32 activation row"); }
+    if (a.N > 1 && (!a.xq.q || a.parity_rows)) { kernel_fail("bark-hip: quantised row product needs pre-quantised rows"); }
     switch (a.wq.qt) {
         case QT_Q4_0: launch_linear_qt<QT_Q4_0>(s, a); break;
         case QT_Q4_1: launch_linear_qt<QT_Q4_1>(s, a); break;
         case QT_Q5_0: launch_linear_qt<QT_Q5_0>(s, a); break;
         case QT_Q5_1: launch_linear_qt<QT_Q5_1>(s, a); break;
         case QT_Q8_0: launch_linear_qt<QT_Q8_0>(s, a); break;
-        default: fprintf(stderr, "bark-hip: unknown weight block format %d\n", a.wq.qt); abort();
+        default: kernel_fail("bark-hip: unknown weight block format %d", a.wq.qt);
     }
 }
 
@@ -546,8 +546,8 @@ __global__ __launch_bounds__(64) void gemm_w32_rows_kernel(const LinArgs a) {
     }
 }
 void launch_linear_w32(hipStream_t s, const LinArgs & a) {
-    if ((a.K & 127) != 0 || a.K > 4096) { fprintf(stderr, "bark-hip: unsupported K=%d in f32 linear op\n", a.K); abort(); }
-    if (a.batched || !a.x_f32) { fprintf(stderr, "bark-hip: f32-weight products take f32 rows, one sequence at a time\n"); abort(); }
+    if ((a.K & 127) != 0 || a.K > 4096) { kernel_fail("bark-hip: unsupported K=%d in f32 linear op", a.K); }
+    if (a.batched || !a.x_f32) { kernel_fail("bark-hip: f32-weight products take f32 rows, one sequence at a time"); }
     if (a.N == 1) {
         dim3 grid((a.M + 15) / 16), block(256);
         if (a.ln_g) {
@@ -556,7 +556,7 @@ void launch_linear_w32(hipStream_t s, const LinArgs & a) {
         } else hipLaunchKernelGGL((gemv_w32_kernel<false, false>), grid, block, 0, s, a);
         return;
     }
-    if (a.ln_g || a.parity_rows) { fprintf(stderr, "bark-hip: f32 row product needs LayerNorm-ed rows\n"); abort(); }
+    if (a.ln_g || a.parity_rows) { kernel_fail("bark-hip: f32 row product needs LayerNorm-ed rows"); }
     constexpr int NB = 8;
     dim3 grid((a.M + 3) / 4, (a.N + NB - 1) / NB), block(64);
     hipLaunchKernelGGL((gemm_w32_rows_kernel<NB>), grid, block, 0, s, a);

@@ -13,6 +13,21 @@
  * Engine extensions (device selection, stage-level entry points, batches) live in
  * bark_mi355x.h and never change anything in this file.
  */
+/*
+ * The declarations below restate the public interface of PABannier/bark.cpp's bark.h, which is distributed under the
+ * ISC licence; its notice is reproduced here as that licence requires:
+ *
+ *   Copyright 2024 Pierre-Antoine Bannier
+ *
+ *   Permission to use, copy, modify, and/or distribute this software for any purpose with or without fee is hereby
+ *   granted, provided that the above copyright notice and this permission notice appear in all copies.
+ *
+ *   THE SOFTWARE IS PROVIDED "AS IS" AND THE AUTHOR DISCLAIMS ALL WARRANTIES WITH REGARD TO THIS SOFTWARE INCLUDING ALL
+ *   IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS. IN NO EVENT SHALL THE AUTHOR BE LIABLE FOR ANY SPECIAL, DIRECT,
+ *   INDIRECT, OR CONSEQUENTIAL DAMAGES OR ANY DAMAGES WHATSOEVER RESULTING FROM LOSS OF USE, DATA OR PROFITS, WHETHER IN
+ *   AN ACTION OF CONTRACT, NEGLIGENCE OR OTHER TORTIOUS ACTION, ARISING OUT OF OR IN CONNECTION WITH THE USE OR
+ *   PERFORMANCE OF THIS SOFTWARE.
+ */
 #pragma once
 
 #include "encodec.h"

@@ -53,16 +53,17 @@ BARK_API int bark_hip_gpt_eval(struct bark_context * bctx, int which, const int3
  * logits [1024][n_out].  Returns 0 or -1. */
 BARK_API int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * tokens_8x1024, int nn, float * logits);
 
-/* Stage loops (greedy on device when temp == 0; host sampling otherwise).
- * semantic: prompt513 -> out (capacity >= n_steps_text_encoder); returns count or -1.
- * coarse  : semantic ids -> out [T][2]; returns T or -1.
- * fine    : coarse [T][2] -> out [T][8]; returns T or -1 (T <= 1024). */
-BARK_API int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, float * eos_trace);
-BARK_API int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2);
-BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8);
+/* Stage loops (sampled on the device: argmax when temp == 0, multinomial otherwise).  Every output buffer comes with its
+ * capacity; a result that does not fit fails the call (-1) instead of overrunning the buffer.
+ * semantic: prompt513 -> out (capacity ids; eos_trace, when given, holds capacity + 1 floats); returns count or -1.
+ * coarse  : semantic ids -> out [T][2] (capacity_rows rows; T = floor(n_semantic * 75 / 49.9 * 2 / 2)); returns T or -1.
+ * fine    : coarse [T][2] -> out [T][8] (capacity_rows rows); returns T or -1 (T <= 8192). */
+BARK_API int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, int capacity, float * eos_trace);
+BARK_API int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2, int capacity_rows);
+BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8, int capacity_rows);
 
-/* EnCodec decode: codes [n_q][T] (time contiguous) -> pcm (capacity 320*T floats). Returns samples or -1. */
-BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm);
+/* EnCodec decode: codes [n_q][T] (time contiguous) -> pcm (capacity floats; 320 * T are produced). Returns samples or -1. */
+BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm, int capacity);
 
 /* Per-layer parity tap of the codec: activation [C][T'] after stage 0 (first conv), 1 (LSTM + skip),
  * 2..5 (the four upsampling blocks).  Returns the element count or -1. */
