@@ -274,6 +274,12 @@ double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * f
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_fine_pass", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass); });
 }
+#ifdef BARK_TRACE
+__attribute__((visibility("default"))) int bark_hip_trace_decode_step(struct bark_context * bctx, int which, int ctx, int replays, unsigned long long * out6, int cap_records) {
+    if (!bctx || !out6) return -1;
+    return guarded("bark_hip_trace_decode_step", -1, [&] { return engine_trace_decode_step(bctx, which, ctx, replays, out6, cap_records); });
+}
+#endif
 const char * bark_hip_describe(struct bark_context * bctx) { return bctx ? bctx->description.c_str() : "no context"; }
 
 }  // extern "C"

@@ -207,8 +207,30 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
 // A variant that also split the keys and exchanged scores through agent-scope atomics measured
 // 10.7 us vs 8.2 us fused at ctx 641: each cross-XCD hop costs ~2 us.
 // ------------------------------------------------------------------------------------------------
+// One C5 chain over the keys chain + 16 i held in vv[]: the probabilities are fetched from LDS in one batch and masked terms are
+// dropped with a select on the RESULT (identical to skipping them, and garbage in unused cache rows never reaches acc).  The
+// in-kernel time line showed the guarded form `if (j < ctx) acc = fmaf(v, es[j] * inv, acc)` costing one LDS round trip per key.
+template <int NG> DEVINL float mix_chain(const float (&vv)[16 * NG], const float * es, float inv, int chain, int ctx) {
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            float pj[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float t = fmaf(vv[16 * g + i], pj[i], acc);
+                acc = (chain + 16 * (16 * g + i) < ctx) ? t : acc;
+            }
+        }
+    }
+    return acc;
+}
 constexpr int ATTN_SPLIT = 4;
 __global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.H);
     __shared__ float es[1024];
     __shared__ float red_f[4];
     __shared__ double red_d[4];
@@ -261,17 +283,8 @@ __global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a
     __syncthreads();
     const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
     const float inv = (float) (1.0 / sum);
-    float acc = 0.0f;
-    #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (g == 0 || ctx > 256 * g) {
-            #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int j = chain + 16 * (16 * g + i);
-                if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc);
-            }
-        }
-    }
+    const float acc = mix_chain<4>(vv, es, inv, chain, ctx);
+    TRACE_T2(acc);
     part[chain][d] = acc;
     __syncthreads();
     if (tid < 16) {
@@ -285,6 +298,130 @@ __global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a
         const int o = h * 64 + 16 * s + tid;
         if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
     }
+    TRACE_END(a.tr);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wide decode attention: the value-sliced layout of attn_dslice_kernel (workgroup = head x 16 value dims, all 16 C5 chains local,
+// no cross-workgroup traffic) with 1024 threads, ONE key per thread.  The in-kernel time line of attn_dslice_kernel (tools/
+// trace_decode.py) showed 6.7 of its 8 us between "arguments ready" and "mix done": a wave alone on its SIMD runs dependent VALU
+// code at ~5 cycles per instruction, and every thread walked 3-4 score chains (64 fmaf each) and 3-4 double-precision exps
+// (~70 fp64 instructions each) one after the other.  Here a thread owns one key: one 64-fmaf chain, one exp; the 16 waves also
+// keep 16 x 16 K loads in flight instead of 4 x 64.  Threads 0..255 then mix as before (chain = tid / 16, dim = tid % 16); their V
+// loads are issued once the K registers are dead and land behind the softmax.
+//   FROM_SCORES = true : second half of the two-launch variant - scores come from attn_keyscores_kernel, which spreads the K
+//                        stream over ctx/64 x H waves (a head's K rows, 164-262 KB, are the per-CU bandwidth bound of the fused form)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_keyscores_kernel(const AttnDecodeArgs a) {
+    const int h = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    constexpr int P = 1024;
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + j;
+    // the first 256 keys are scored without looking at the context length (one scalar round trip less before the loads go out)
+    if (blockIdx.x >= 4 && blockIdx.x * 64 > a.st->n_past) return;
+    float4 kv[16];
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    a.scores[(size_t) h * P + j] = score_chain(kv, a.q + h * 64);
+}
+
+template <bool FROM_SCORES>
+__global__ __launch_bounds__(1024) void attn_wide_kernel(const AttnDecodeArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.H);
+    __shared__ float es[1024];
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ float part[16][16];
+    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // same XCD-affine id -> (head, slice) map as attn_dslice_kernel
+    const int h = x8 + 8 * (g8 / ATTN_SPLIT), s = g8 % ATTN_SPLIT;
+    if (h >= a.H) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int P = 1024;
+    const int chain = (tid >> 4) & 15, d = tid & 15;
+    const float * vp = a.vc + ((size_t) h * P + chain) * 64 + 16 * s + d;        // key `chain`, value dim 16 s + d
+    float sc = -INFINITY;
+    float vv[64];
+    int ctx;
+    if constexpr (FROM_SCORES) {
+        const float v = a.scores[(size_t) h * P + tid];
+        ctx = a.st->n_past + 1;
+        if (wave < 4) {
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g == 0 || ctx > 256 * g) {
+                    #pragma unroll
+                    for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];
+                }
+            }
+        }
+        if (tid < ctx) sc = v;
+    } else {
+        const float * __restrict__ qh = a.q + h * 64;
+        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
+        float4 kv[16];
+        if (wave < 4) {                                            // keys 0..255: always inside the cache, no need to know ctx yet
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+        }
+        ctx = a.st->n_past + 1;
+        if (wave >= 4 && wave * 64 < ctx) {
+            #pragma unroll
+            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+        }
+        if (wave * 64 < ctx) {
+            const float v = score_chain(kv, qh);
+            if (tid < ctx) sc = v;
+        }
+        if (wave < 4) {                                            // K registers are dead: request the value slice
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (g == 0 || ctx > 256 * g) {
+                    #pragma unroll
+                    for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];
+                }
+            }
+        }
+    }
+    TRACE_TA(sc);
+    float mx = wave_max(sc);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    float e = 0.0f;
+    if (tid < ctx) e = (float) exp((double) (sc - mx));
+    es[tid] = e;
+    const double wsum = wave_sum((double) e);
+    if (lane == 0) red_d[wave] = wsum;
+    __syncthreads();
+    TRACE_TB(e);
+    if (wave >= 4) return;
+    // same association as the 4-wave kernels ((w0 + w1) + (w2 + w3) per 256 keys) is not required: a double sum of floats changes
+    // the rounded float only at ~2^-29; fixed order here: ascending waves
+    double sum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) sum += red_d[i];
+    const float inv = (float) (1.0 / sum);
+    const float acc = mix_chain<4>(vv, es, inv, chain, ctx);
+    TRACE_T2(acc);
+    part[chain][d] = acc;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): the four mix waves meet through LDS without the exited waves
+    asm volatile("s_barrier" ::: "memory");
+    if (tid < 16) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        const int o = h * 64 + 16 * s + tid;
+        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
+    }
+    TRACE_END_AB(a.tr);
 }
 
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
@@ -292,6 +429,14 @@ void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts)
     if (parts == 5) {
         if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: value-sliced decode attention needs one sequence and block_size 1024"); }
         hipLaunchKernelGGL(attn_dslice_kernel, dim3(8 * ATTN_SPLIT * ((a.H + 7) / 8)), dim3(256), 0, s, a);
+        return;
+    }
+    if (parts == 6 || parts == 7) {
+        if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: wide decode attention needs one sequence and block_size 1024"); }
+        const dim3 grid(8 * ATTN_SPLIT * ((a.H + 7) / 8));
+        if (parts == 6) { hipLaunchKernelGGL(attn_wide_kernel<false>, grid, dim3(1024), 0, s, a); return; }
+        hipLaunchKernelGGL(attn_keyscores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(attn_wide_kernel<true>, grid, dim3(1024), 0, s, a);
         return;
     }
     if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
@@ -303,7 +448,9 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     if (split) { launch_attn_decode_part(s, a, 3); return; }
     // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
     const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
-    launch_attn_decode_part(s, a, can_split ? 5 : 4);
+    // BARK_HIP_ATTN_MODE (A/B timing): 5 value-sliced 256-thread kernel, 6 wide fused kernel, 7 key scores + wide mix (two launches)
+    static const int mode = getenv("BARK_HIP_ATTN_MODE") ? atoi(getenv("BARK_HIP_ATTN_MODE")) : 6;
+    launch_attn_decode_part(s, a, can_split ? mode : 4);
 }
 
 // ------------------------------------------------------------------------------------------------

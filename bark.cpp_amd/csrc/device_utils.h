@@ -12,6 +12,40 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #define DEVINL __device__ __forceinline__
 
+#ifdef BARK_TRACE
+// time stamps that cannot be scheduled before their operand exists (the asm consumes it)
+DEVINL unsigned long long trace_clock() { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+DEVINL unsigned long long trace_clock_s(int dep) { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep) : "memory"); return t; }
+DEVINL unsigned long long trace_clock_v(float dep) { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory"); return t; }
+DEVINL void trace_emit(const TraceSink & tr, unsigned long long t0, unsigned long long t1, unsigned long long t2, unsigned long long t3,
+                       unsigned long long ta = 0, unsigned long long tb = 0) {
+    if (!tr.rec || (threadIdx.x & 63) != 0) return;
+    const unsigned wpb = (blockDim.x + 63) >> 6;
+    const unsigned i = *tr.pos * tr.per_replay + tr.base + (blockIdx.y * gridDim.x + blockIdx.x) * wpb + (threadIdx.x >> 6);
+    if (i >= tr.cap) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u;          // HW_REG_XCC_ID
+    unsigned long long * r = tr.rec + (size_t) i * 8;
+    r[0] = (unsigned long long) tr.kid | ((unsigned long long) xcc << 16);
+    r[1] = (unsigned long long) blockIdx.x | ((unsigned long long) blockIdx.y << 24) | ((unsigned long long) (threadIdx.x >> 6) << 40);
+    r[2] = t0; r[3] = t1; r[4] = t2; r[5] = t3; r[6] = ta; r[7] = tb;
+}
+#define TRACE_T0() const unsigned long long _tr0 = trace_clock()
+#define TRACE_T1(dep) const unsigned long long _tr1 = trace_clock_s(dep)
+#define TRACE_T2(dep) const unsigned long long _tr2 = trace_clock_v(dep)
+#define TRACE_TA(dep) const unsigned long long _tra = trace_clock_v(dep)
+#define TRACE_TB(dep) const unsigned long long _trb = trace_clock_v(dep)
+#define TRACE_END(tr) trace_emit(tr, _tr0, _tr1, _tr2, trace_clock())
+#define TRACE_END_AB(tr) trace_emit(tr, _tr0, _tr1, _tr2, trace_clock(), _tra, _trb)
+#else
+#define TRACE_T0()
+#define TRACE_T1(dep)
+#define TRACE_T2(dep)
+#define TRACE_TA(dep)
+#define TRACE_TB(dep)
+#define TRACE_END(tr)
+#define TRACE_END_AB(tr)
+#endif
+
 // Sums over the 16 lanes of a DPP row in the C1/C5 tree order (partner xor 1, 2, 4, 8).  After the
 // xor-1 / xor-2 quad permutes every lane of a quad holds the quad sum, so the half-row mirror (lane i
 // <- 7-i) and the row mirror (lane i <- 15-i) deliver exactly the xor-4 / xor-8 partner sums; fp add is
@@ -54,6 +88,20 @@ DEVINL float wave_max(float v) {
     v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
     v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
     return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+// whole-wave integer / float reductions by DPP (every lane ends with the result of its 16-lane row; rows are combined through SGPRs)
+template <int CTRL> DEVINL int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+DEVINL int wave_min_i32(int v) {
+    v = min(v, dpp_i32<DPP_XOR1>(v)); v = min(v, dpp_i32<DPP_XOR2>(v)); v = min(v, dpp_i32<DPP_HALF_MIRROR>(v)); v = min(v, dpp_i32<DPP_MIRROR>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+DEVINL int wave_add_i32(int v) {
+    v += dpp_i32<DPP_XOR1>(v); v += dpp_i32<DPP_XOR2>(v); v += dpp_i32<DPP_HALF_MIRROR>(v); v += dpp_i32<DPP_MIRROR>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+DEVINL float wave_add_f32(float v) {
+    v = wave_xor_add16(v);
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
 // order-preserving float <-> unsigned map, so that the row maximum can be kept with an integer atomicMax
 DEVINL unsigned f32_ordered(float f) { const unsigned b = __builtin_bit_cast(unsigned, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -124,7 +172,7 @@ DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, cons
             if (a.out_h32) a.out_h32[(size_t) n * a.M + m] = (float) g; else a.out_h[(size_t) n * a.M + m] = g;
             break;
         }
-        default:        a.out[(size_t) n * a.ld_out + m] = v; break;
+        default:        a.out[(size_t) n * a.ld_out + m] = a.out_div != 0.0f ? v / a.out_div : v; break;
     }
 }
 DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_off) {

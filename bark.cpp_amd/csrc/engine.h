@@ -113,6 +113,9 @@ struct bark_context {
     struct BatchResult { std::vector<int32_t> semantic, coarse, fine; std::vector<float> audio; bool ok = false; };
     std::vector<BatchResult> batch_results;
 
+#ifdef BARK_TRACE
+    unsigned long long * trace_rec = nullptr; unsigned * trace_pos = nullptr; unsigned trace_cap = 0; int trace_kid = 0; unsigned trace_base = 0, trace_per_replay = 0;
+#endif
     // results of the last generate call
     std::vector<int32_t> tokens, semantic_tokens, coarse_tokens, fine_tokens;
     std::vector<float> audio;
@@ -145,5 +148,8 @@ int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);
 double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass);
+#ifdef BARK_TRACE
+int engine_trace_decode_step(bark_context * ctx, int which, int ctxlen, int replays, unsigned long long * out6, int cap_records);
+#endif
 
 }  // namespace barkhip

@@ -82,32 +82,38 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
+        BARK_TRACE_SET(c, a, (a.M + 3) / 4);
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
         at.att32 = m.q4 ? c->att32 : nullptr;
+        BARK_TRACE_SET(c, at, 8 * 4 * ((H + 7) / 8) * 16);       // wide kernel: 16 waves per workgroup
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = c->att32; else p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        BARK_TRACE_SET(c, p, (p.M + 3) / 4);
         launch_linear(s, p);
         LinArgs f;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
+        BARK_TRACE_SET(c, f, (f.M + 3) / 4);
         launch_linear(s, f);
         LinArgs o;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = c->h32; else o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        BARK_TRACE_SET(c, o, (o.M + 3) / 4);
         launch_linear(s, o);
     }
 }
 
 // final LayerNorm + LM head on ONE row (bark.cpp:1391-1405): rows [row0, row0 + n_rows) of the head,
 // or the parity-selected codebook window of the coarse model.
-void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows) {
+void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div) {
     LinArgs a;
     if (m.q4) a.wq = q4_rows(m.lm_head_q[0], (size_t) row0, m.hp.n_embd); else a.W = m.lm_head[0] + (size_t) row0 * m.hp.n_embd;
     a.M = n_rows; a.K = m.hp.n_embd; a.N = 1;
     a.x_f32 = xrow; a.ln_g = m.lnf_g; a.ln_b = m.lnf_b; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
-    a.parity_rows = parity_rows; a.st = c->d_state;
+    a.parity_rows = parity_rows; a.st = c->d_state; a.out_div = out_div;
+    BARK_TRACE_SET(c, a, (a.M + 3) / 4);
     launch_linear(c->stream, a);
 }
 
@@ -166,14 +172,17 @@ StageCfg stage_cfg(bark_context * c, int which) {
     return s;
 }
 
-void run_sample(bark_context * c, const StageCfg & s, int n_past_add) {
+void run_sample(bark_context * c, const StageCfg & s, int n_past_add, bool prescaled) {
     SampleArgs a;
+    a.prescaled = prescaled ? 1 : 0;
     a.logits = c->logits; a.n = s.lm_rows; a.mode = s.mode; a.min_eos_p = s.min_eos_p; a.eos_token = s.eos_token;
     a.token_base = s.token_base; a.n_past_add = n_past_add; a.out_tokens = c->d_out_tokens;
     a.eos_trace = s.mode == 0 ? c->d_eos_trace : nullptr; a.st = c->d_state;
     a.temp = s.temp; a.u = c->d_u;
+    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; a.force_exact = force_exact; }
     const GptModel & m = c->gpt[s.which];
     a.wte = m.wte[0]; a.wte_q = m.wte_q[0]; a.wpe = m.wpe; a.E = m.hp.n_embd; a.n_in = m.hp.n_in_vocab; a.P = c->P; a.x = c->x;
+    BARK_TRACE_SET(c, a, 16);
     launch_sample_greedy(c->stream, a);
 }
 
@@ -187,8 +196,10 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
         launch_embed_causal(c->stream, e);
     }
     run_layers_decode(c, m);
-    run_lm_head(c, m, c->x, s.lm_row0, s.lm_rows, s.parity_rows);
-    if (sample) run_sample(c, s, n_past_add);
+    // greedy decode step: the LM head divides by 0.7 itself (2512 waves instead of one workgroup doing 10 048 divisions)
+    const bool prescale = sample && s.temp == 0.0f;
+    run_lm_head(c, m, c->x, s.lm_row0, s.lm_rows, s.parity_rows, prescale ? 0.7f : 0.0f);
+    if (sample) run_sample(c, s, n_past_add, prescale);
 }
 
 hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add) {

@@ -106,6 +106,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
     launch_linear(st, h);
     SampleArgs sa;
+    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
     sa.logits = bb.logits; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
     sa.token_base = s.token_base; sa.n_past_add = 1; sa.out_tokens = bb.out_tokens; sa.eos_trace = s.mode == 0 ? bb.eos_trace : nullptr;
     sa.st = bb.state; sa.nbatch = B; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
@@ -182,6 +183,7 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
     launch_linear(c->stream, h);
     SampleArgs sa;
+    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
     sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
     sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
     sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;

@@ -16,6 +16,13 @@
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);   \
     } while (0)
 
+// diagnostic build: hand the context's trace log to a kernel's argument block and number the launch
+#ifdef BARK_TRACE
+#define BARK_TRACE_SET(c, args, nwaves) do { (args).tr.rec = (c)->trace_rec; (args).tr.pos = (c)->trace_pos; (args).tr.cap = (c)->trace_cap; (args).tr.kid = (c)->trace_kid++; (args).tr.base = (c)->trace_base; (args).tr.per_replay = (c)->trace_per_replay; (c)->trace_base += (unsigned) (nwaves); } while (0)
+#else
+#define BARK_TRACE_SET(c, args, nwaves) do { } while (0)
+#endif
+
 namespace barkhip { namespace detail {
 
 inline int64_t now_us() {
@@ -46,7 +53,7 @@ float * layer_k(const GptModel & m, int l);
 float * layer_v(const GptModel & m, int l);
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0);
 void run_layers_decode(bark_context * c, GptModel & m);
-void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows);
+void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);
 StepState get_state(bark_context * c);
 StepState fresh_state();
@@ -57,7 +64,7 @@ struct StageCfg {            // what differs between the semantic and the coarse
     int which; int mode; int lm_row0, lm_rows, parity_rows; int token_base; float min_eos_p; int eos_token; float temp;
 };
 StageCfg stage_cfg(bark_context * c, int which);
-void run_sample(bark_context * c, const StageCfg & s, int n_past_add);
+void run_sample(bark_context * c, const StageCfg & s, int n_past_add, bool prescaled = false);
 void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add, bool embed = true);
 hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add);
 void decode_step_greedy(bark_context * c, const StageCfg & s);

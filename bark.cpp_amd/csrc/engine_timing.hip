@@ -128,6 +128,42 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
     return (double) ms * 1000.0 / std::max(1, iters);
 }
 
+#ifdef BARK_TRACE
+// diagnostic build: `replays` consecutive replays of one decode step with per-wave time stamps; returns the record count
+int engine_trace_decode_step(bark_context * c, int which, int ctxlen, int replays, unsigned long long * out6, int cap_records) {
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    const StageCfg s = stage_cfg(c, which);
+    StepState st = fresh_state(); st.n_past = ctxlen - 1; st.cur_token = 1;
+    set_state(c, st);
+    if (!c->trace_rec) {
+        c->trace_cap = 1u << 18;
+        c->trace_rec = dev_alloc<unsigned long long>(c, (size_t) c->trace_cap * 8);
+        c->trace_pos = dev_alloc<unsigned>(c, 1);
+    }
+    HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    // first capture counts the waves of a step, the second bakes the per-replay stride into the kernels' arguments
+    c->trace_kid = 0; c->trace_base = 0; c->trace_per_replay = 0;
+    hipGraphExec_t g = capture_decode(c, s, 0);
+    (void) hipGraphExecDestroy(g);
+    c->trace_per_replay = c->trace_base; c->trace_kid = 0; c->trace_base = 0;
+    g = capture_decode(c, s, 0);
+    HIP_OK(hipMemsetAsync(c->trace_rec, 0, (size_t) c->trace_cap * 8 * sizeof(unsigned long long), c->stream));
+    for (int i = 0; i < 5; i++) { HIP_OK(hipMemsetAsync(c->trace_pos, 0, sizeof(unsigned), c->stream)); HIP_OK(hipGraphLaunch(g, c->stream)); }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    set_state(c, st);
+    HIP_OK(hipMemsetAsync(c->trace_pos, 0, sizeof(unsigned), c->stream));
+    for (int i = 0; i < replays; i++) HIP_OK(hipGraphLaunch(g, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    unsigned n = c->trace_per_replay * (unsigned) replays;
+    n = std::min(n, std::min(c->trace_cap, (unsigned) std::max(0, cap_records)));
+    HIP_OK(hipMemcpy(out6, c->trace_rec, (size_t) n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void) hipGraphExecDestroy(g);
+    return (int) n;
+}
+#endif
+
 double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pass) {
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[2];

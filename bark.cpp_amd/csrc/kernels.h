@@ -25,7 +25,7 @@ struct StepState {
     int32_t cur_token;     // token embedded by the next decode step
     int32_t step;          // stage step counter (coarse: parity selects the logit slice)
     int32_t eos_step;      // first step whose sample met the stop rule (INT32_MAX if none)
-    int32_t near_tie;      // samples whose runner-up was within kNearTie of the winner
+    int32_t near_tie;      // samples settled by the exact path (near tie of the two largest logits, or eos_p next to min_eos_p)
     int32_t n_out;         // sampled ids written to out_tokens so far
     float   last_eos_p;
     float   pad1;
@@ -41,6 +41,15 @@ struct QMat {
 // q8 image of N <= 1024 activation rows: levels q [N][K] int8, scales d and s = f16(d * sum q) as [N][K/32] and block-major
 // [K/32][1024] (the i8-MFMA kernel reads 16 consecutive rows of one block)
 struct Q8Scratch { int8_t * q = nullptr; float * d = nullptr, * dT = nullptr, * s = nullptr, * sT = nullptr; };
+
+// Diagnostic build only (-DBARK_TRACE, tools/trace_decode.py): every wave of the decode kernels appends one record
+// {kid | xcc << 16, workgroup | wave << 24, t_entry, t_kernarg, t_operands, t_done} (s_memrealtime, 100 MHz) to a device log.
+#ifdef BARK_TRACE
+struct TraceSink { unsigned long long * rec = nullptr; unsigned * pos = nullptr; unsigned cap = 0; int kid = 0; unsigned base = 0, per_replay = 0; };   // slot = *pos (replay) * per_replay + base + wave index: no atomics
+#define BARK_TRACE_FIELD TraceSink tr;
+#else
+#define BARK_TRACE_FIELD
+#endif
 
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
@@ -70,12 +79,14 @@ struct LinArgs {
     float * out_h32 = nullptr;            // q4_0 path: the GELU output stays f32 (it is quantised to q8_0 by the next product)
     // EPI_LOGITS: out[n*ld_out + m] = dot (+ bias)
     float * out = nullptr; int ld_out = 0;
+    float out_div = 0.0f;                 // != 0: out = (dot + bias) / out_div - the sampler's `l /= 0.7f` (bark.cpp:226-228) done where the logit is born
     // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
     // the row window starts at parity_rows * (st->step & 1) rows into W (and bias)
     int parity_rows = 0;
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
+    BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 
@@ -108,6 +119,7 @@ struct AttnDecodeArgs {
     float * scores = nullptr;             // scratch [H][P]
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
+    BARK_TRACE_FIELD
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts);   // 1 scores, 2 mix, 3 both (timing hook)
@@ -131,6 +143,8 @@ struct SampleArgs {
     const double * u = nullptr;
     int u_stride = 0;                      // batched decode: slot b reads u + b * u_stride
     float min_eos_p = 0.2f; int eos_token = 10000;
+    int prescaled = 0;                     // the logits have already been divided by 0.7 (LinArgs::out_div of the LM head)
+    int force_exact = 0;                   // every sample takes the exact path (the reference's sequential float softmax); tests
     int token_base = 0;                    // coarse: added to the pick (slice start); semantic 0
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
     int32_t * out_tokens = nullptr; float * eos_trace = nullptr; StepState * st = nullptr;
@@ -138,6 +152,7 @@ struct SampleArgs {
     // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
     QMat wte_q;
+    BARK_TRACE_FIELD
 };
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]

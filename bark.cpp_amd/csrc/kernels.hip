@@ -41,6 +41,8 @@ void kernel_fail(const char * fmt, ...) {
 // trip deep.  One wave per workgroup (4 output rows) spreads the rows over as many CUs as possible.
 template <int NBLK, bool LN, bool LNB>
 __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.M);
     const int lane = threadIdx.x;
     const int c = lane & 15, rg = lane >> 4;
     const int m = blockIdx.x * 4 + rg;
@@ -105,8 +107,10 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
         }
     } else {
         const half_t * xrow = a.x_f16 + (c << 3);
-        constexpr int G = NBLK < 8 ? NBLK : 8;                // loads in flight per lane and operand
-        static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+        // every chunk of the row is requested before the first fmaf (up to 2 x 32 x 16 bytes per lane: a one-wave workgroup may
+        // use all 512 registers).  The chain of a lane is K / 16 dependent fmaf long whatever the load schedule; with batches of
+        // 8 chunks the K = 3072 product paid two more exposed memory round trips (1.8 us between "arguments ready" and "dot done").
+        constexpr int G = NBLK;                               // loads in flight per lane and operand
         half8 wv[2][G], xv[2][G];
         #pragma unroll
         for (int i = 0; i < G; i++) { wv[0][i] = ld_half8(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
@@ -126,8 +130,83 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
             }
         }
     }
+    TRACE_T2(acc);
     acc = wave_xor_add16(acc);
     if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    TRACE_END(a.tr);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm-fused decode GEMV, workgroup form.  The in-kernel time line (tools/trace_decode.py) showed the one-wave form above
+// spending 2.2 us between "arguments ready" and "dot product done" where the plain GEMV needs 0.6: every wave normalised the
+// whole row on its own - ~1500 dependent VALU instructions (fp64 sums, two fp64 divisions, 48 scale / round steps per lane) on a
+// SIMD that holds nothing else.  Here the 256 threads of a workgroup (4 waves = 16 output rows) normalise the row ONCE: E / 256
+// elements per thread, wave sums by DPP, the four wave sums meet in LDS, and the f16-rounded row is published in LDS (1.5 KB) from
+// where every lane reads its 16-byte chunks.  Same arithmetic per element as before (ggml_norm: double sums, bark.cpp:1265-1274).
+// ------------------------------------------------------------------------------------------------
+template <int NBLK, bool LNB>
+__global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.M);
+    constexpr int K = NBLK * 128;
+    constexpr int EPT = (K + 255) / 256;                     // row elements per thread
+    __shared__ __attribute__((aligned(16))) half_t xs[K];
+    __shared__ double red1[4], red2[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = (blockIdx.x * 4 + wave) * 4 + rg;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < a.M;
+    const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    half8 wv[NBLK];
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
+    float xv[EPT], gv[EPT], bv[EPT];
+    #pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int e = tid + 256 * i;
+        const bool ok = (K % 256 == 0) || e < K;
+        xv[i] = ok ? a.x_f32[e] : 0.0f;
+        gv[i] = ok ? a.ln_g[e] : 0.0f;
+        if constexpr (LNB) bv[i] = ok ? a.ln_b[e] : 0.0f; else bv[i] = 0.0f;
+    }
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    double s1 = 0.0;
+    #pragma unroll
+    for (int i = 0; i < EPT; i++) if ((K % 256 == 0) || tid + 256 * i < K) s1 += (double) xv[i];
+    s1 = wave_sum(s1);
+    if (lane == 0) red1[wave] = s1;
+    __syncthreads();
+    const float mean = (float) (((red1[0] + red1[1]) + (red1[2] + red1[3])) / (double) K);
+    double s2 = 0.0;
+    #pragma unroll
+    for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; if ((K % 256 == 0) || tid + 256 * i < K) s2 += (double) (xv[i] * xv[i]); }
+    s2 = wave_sum(s2);
+    if (lane == 0) red2[wave] = s2;
+    __syncthreads();
+    const float var = (float) (((red2[0] + red2[1]) + (red2[2] + red2[3])) / (double) K);
+    const float scale = 1.0f / sqrtf(var + 1e-5f);
+    #pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int e = tid + 256 * i;
+        float v = xv[i] * scale;
+        v = v * gv[i];
+        if constexpr (LNB) v = v + bv[i];
+        if ((K % 256 == 0) || e < K) xs[e] = to_half(v);      // mul_mat converts the activation to f16 first
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        const half8 xh = *reinterpret_cast<const half8 *>(xs + ((b * 16 + c) << 3));
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
+    }
+    TRACE_T2(acc);
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    TRACE_END(a.tr);
 }
 
 template <int NBLK>
@@ -135,8 +214,14 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
     dim3 grid((a.M + 3) / 4), block(64);
     if (a.x_f32) {
         if constexpr (NBLK <= 8) {
-            if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
-            else        hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);
+            static const bool one_wave = getenv("BARK_HIP_LN_ONE_WAVE") != nullptr;       // A/B: every wave normalises the row itself
+            if (!one_wave) {
+                const dim3 g16((a.M + 15) / 16), b256(256);
+                if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true>), g16, b256, 0, s, a);
+                else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false>), g16, b256, 0, s, a);
+            }
+            else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
+            else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);
         } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
     } else {
         hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a);

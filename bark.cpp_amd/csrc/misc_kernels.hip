@@ -132,91 +132,154 @@ void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * 
 
 
 // ------------------------------------------------------------------------------------------------
-// greedy sampling (gpt_argmax_sample, bark.cpp:223-247): l /= 0.7; softmax; first index of the
-// largest probability.  p_i = e_i / sum is monotone in e_i = (float) exp((double)(l_i/0.7 - max)), so
-// the winner is the first index whose e_i rounds to 1.0f, i.e. l_i/0.7 - max >= -2^-25.
-// Picks whose runner-up is within kNearTie are counted in st->near_tie (the float division can
-// merge neighbouring probabilities; the host re-checks those).
+// greedy sampling (gpt_argmax_sample, bark.cpp:223-247): l /= 0.7; softmax; first index of the largest probability;
+// eos_p = probability of the last logit (semantic stage: the stop rule compares it with min_eos_p, bark.cpp:1690).
+//
+// The reference's softmax is a SEQUENTIAL float sum over all logits of e_i = (float) exp((double)(l_i - max)) followed by one float
+// division per element.  Evaluating that literally takes one CU ~5 us per token (10 048 double-precision exps: fp64 throughput of
+// a single CU; the in-kernel time line showed it as the longest tail of the whole step) plus a 10 048-long dependent add chain.
+// Fast path, provably the reference's decision:
+//   * pick: p_i = RN(e_i / sum) is monotone in e_i, so the winner is the first index whose e_i is 1.0f (d_i = l_i - max >=
+//     -2^-25), PROVIDED no other logit lies within kNearTie = 4e-7 of the maximum: any e_i <= 1 - 4e-7 is more than two float
+//     ulps below 1 and stays below after the division by the common sum.
+//   * stop rule: eos ~= e_last / S with S a tree sum of v_exp_f32 terms (relative error < 1e-5 against the exact sum, while the
+//     reference's own sequential sum may be off by up to n * 2^-24 = 6e-4); the decision eos_p >= min_eos_p is taken from it only
+//     when eos is further than kEosBand = 2e-3 (relative) from the threshold.
+// Anything else - a near tie, or eos inside the band - takes the exact path: every e_i in double precision, the reference's
+// sequential float sum by one thread out of LDS, p_i = e_i / sum, first strict maximum.  That path returns the reference's bits
+// (token AND eos_p); SampleArgs::force_exact (BARK_HIP_EXACT_SAMPLING=1) makes it the only path, which is how it is tested.
 // ------------------------------------------------------------------------------------------------
 constexpr float kTieCut = -2.98023223876953125e-08f;     // -2^-25
 constexpr float kNearTie = -4.0e-7f;
+constexpr float kEosBand = 2.0e-3f;
 
 __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.n);
     __shared__ float red_f[16];
     __shared__ int red_i[16];
     __shared__ int red_c[16];
     __shared__ float red_s[16];
-    __shared__ int next_tok, next_pos;
+    __shared__ float e_all[12288];                             // exact path only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x;                               // sequence slot (batched decode); 0 otherwise
     const float * logits = a.logits + (size_t) slot * a.ld_logits;
+    StepState * st = a.st + slot;
+    // everything the end of the kernel needs from memory is requested now: the stage state, and the position row of the next
+    // step's embedding (its token row can only be fetched once the pick is known)
+    const int np_next = st->n_past + a.n_past_add;
+    const int step = st->step;
+    StepState s0{};
+    if (tid == 0) s0 = *st;
     constexpr int MAXV = 12;                                   // up to 12288 logits
     float sv[MAXV];
-    float mx = -INFINITY;
     #pragma unroll
     for (int k = 0; k < MAXV; k++) {
         const int i = tid + 1024 * k;
-        sv[k] = i < a.n ? logits[i] / 0.7f : -INFINITY;        // gpt_argmax_sample divides by 0.7 whatever the temperature
-        mx = fmaxf(mx, sv[k]);
+        sv[k] = i < a.n ? logits[i] : -INFINITY;
     }
-    const float last_logit = logits[a.n - 1];
+    float last_logit = logits[a.n - 1];
+    const bool embed = a.x != nullptr && tid < a.E;
+    float pe_v = 0.0f;
+    if (embed && np_next < a.P) pe_v = a.wpe[(size_t) np_next * a.E + tid];
+    float mx = -INFINITY;
+    if (!a.prescaled) {                                        // gpt_argmax_sample divides by 0.7 whatever the temperature (bark.cpp:226-228);
+        #pragma unroll                                         // the decode step's LM head has already done it (LinArgs::out_div)
+        for (int k = 0; k < MAXV; k++) sv[k] = sv[k] / 0.7f;
+        last_logit = last_logit / 0.7f;
+    }
+    #pragma unroll
+    for (int k = 0; k < MAXV; k++) mx = fmaxf(mx, sv[k]);
     mx = wave_max(mx);
     if (lane == 0) red_f[wave] = mx;
     __syncthreads();
     mx = red_f[0];
     #pragma unroll
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    TRACE_T2(mx);
     int best = INT32_MAX, close = 0;
     float sum = 0.0f;
     #pragma unroll
     for (int k = 0; k < MAXV; k++) {
+        const float d = sv[k] - mx;                            // -inf beyond n: never best, never close, exp2 = 0
         const int i = tid + 1024 * k;
-        if (i < a.n) {
-            const float d = sv[k] - mx;
-            if (d >= kTieCut && i < best) best = i;
-            if (d >= kNearTie) close++;
-            if (a.mode == 0) sum += (float) exp((double) d);
-        }
+        if (d >= kTieCut && i < best) best = i;
+        if (d >= kNearTie) close++;
+        if (a.mode == 0) sum += __builtin_amdgcn_exp2f(d * 1.44269504088896340736f);      // v_exp_f32: 1 ulp, fast path only
     }
-    for (int m = 1; m < 64; m <<= 1) {
-        best = min(best, __shfl_xor(best, m, 64));
-        close += __shfl_xor(close, m, 64);
-        sum += __shfl_xor(sum, m, 64);
-    }
+    best = wave_min_i32(best); close = wave_add_i32(close); sum = wave_add_f32(sum);
     if (lane == 0) { red_i[wave] = best; red_c[wave] = close; red_s[wave] = sum; }
     __syncthreads();
+    // every thread finishes the reduction itself (same order, same bits): no broadcast, no further barrier on the fast path
+    best = red_i[0]; close = red_c[0]; sum = red_s[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) { best = min(best, red_i[i]); close += red_c[i]; sum += red_s[i]; }
+    float eos_p = 0.0f;
+    bool exact = a.force_exact || close > 1;
+    if (a.mode == 0) {
+        eos_p = (float) exp((double) (last_logit - mx)) / sum;
+        if (fabsf(eos_p - a.min_eos_p) <= kEosBand * a.min_eos_p) exact = true;
+    }
+    if (exact) {                                               // uniform: the reference's arithmetic, literally
+        #pragma unroll
+        for (int k = 0; k < MAXV; k++) {
+            const int i = tid + 1024 * k;
+            if (i < a.n) e_all[i] = (float) exp((double) (sv[k] - mx));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float fs = 0.0f;
+            for (int i = 0; i < a.n; i++) fs += e_all[i];      // float sum in index order (bark.cpp:191-195)
+            red_s[0] = fs;
+        }
+        __syncthreads();
+        const float fs = red_s[0];
+        // first strict maximum of p_i = e_i / sum (bark.cpp:197-198, 239-244): largest p, then smallest index
+        float pbest = -1.0f; int ibest = INT32_MAX;
+        #pragma unroll
+        for (int k = 0; k < MAXV; k++) {
+            const int i = tid + 1024 * k;
+            if (i < a.n) { const float p = e_all[i] / fs; if (p > pbest) { pbest = p; ibest = i; } }     // ascending i within the thread
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            const float po = __shfl_xor(pbest, m, 64); const int io = __shfl_xor(ibest, m, 64);
+            if (po > pbest || (po == pbest && io < ibest)) { pbest = po; ibest = io; }
+        }
+        __syncthreads();
+        if (lane == 0) { red_f[wave] = pbest; red_i[wave] = ibest; }
+        __syncthreads();
+        pbest = red_f[0]; ibest = red_i[0];
+        #pragma unroll
+        for (int i = 1; i < 16; i++) if (red_f[i] > pbest || (red_f[i] == pbest && red_i[i] < ibest)) { pbest = red_f[i]; ibest = red_i[i]; }
+        best = ibest;
+        eos_p = e_all[a.n - 1] / fs;
+    }
+    int tok = best;
+    if (a.mode != 0) { eos_p = 0.0f; tok += a.token_base + ((step & 1) ? 1024 : 0); }     // slice start (bark.cpp:1829-1841)
     if (tid == 0) {
-        for (int i = 1; i < 16; i++) { best = min(best, red_i[i]); close += red_c[i]; sum += red_s[i]; }
-        StepState * st = a.st + slot;
-        const int step = st->step;
-        int tok = best;
-        float eos_p = 0.0f;
         if (a.mode == 0) {
             // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
-            eos_p = (float) exp((double) (last_logit / 0.7f - mx)) / sum;
-            if ((tok == a.eos_token || eos_p >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if ((tok == a.eos_token || eos_p >= a.min_eos_p) && s0.eos_step == INT32_MAX) st->eos_step = step;
             if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = eos_p;
-        } else {
-            tok += a.token_base + ((step & 1) ? 1024 : 0);   // slice start (bark.cpp:1829-1841)
         }
-        if (close > 1) st->near_tie += 1;
-        a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
-        st->n_out += 1;
+        if (exact) st->near_tie = s0.near_tie + 1;            // samples settled by the exact path
+        a.out_tokens[(size_t) slot * a.out_stride + s0.n_out] = tok;
+        st->n_out = s0.n_out + 1;
         st->cur_token = tok;
         st->step = step + 1;
-        const int np = st->n_past + a.n_past_add;
-        st->n_past = np;
+        st->n_past = np_next;
         st->last_eos_p = eos_p;
-        next_tok = tok; next_pos = np;
     }
-    __syncthreads();
     // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
-    if (a.x && next_pos < a.P) {
-        const int tok = min(max(next_tok, 0), a.n_in - 1);
-        const float * pe = a.wpe + (size_t) next_pos * a.E;
-        float * xo = a.x + (size_t) slot * a.E;
-        for (int e = tid; e < a.E; e += 1024) xo[e] = wte_elem(a.wte, a.wte_q, a.E, tok, e) + pe[e];
+    if (embed && np_next < a.P) {
+        const int t = min(max(tok, 0), a.n_in - 1);
+        a.x[(size_t) slot * a.E + tid] = wte_elem(a.wte, a.wte_q, a.E, t, tid) + pe_v;
     }
+    TRACE_END(a.tr);
+#ifdef BARK_TRACE
+    __syncthreads();
+    if (tid == 0 && a.tr.pos) *a.tr.pos += 1;             // last kernel of a step: the next replay logs into the next segment
+#endif
 }
 // ------------------------------------------------------------------------------------------------
 // multinomial sampling on the device (gpt_multinomial_sample, bark.cpp:201-221): l /= temp; softmax;
