@@ -8,6 +8,15 @@
 
 namespace barkhip {
 
+template <int G> DEVINL void load_k_group(float4 (&kv)[16], const float4 * kp, int P) {
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P + 256 * G];
+}
+// C2: four chains over the 16-d blocks (d-quads 4b .. 4b+3), combined as (c0 + c1) + (c2 + c3)
+DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) {
+    const float c0 = score_block_f4(kv, qh), c1 = score_block_f4(kv + 4, qh + 16), c2 = score_block_f4(kv + 8, qh + 32), c3 = score_block_f4(kv + 12, qh + 48);
+    return ((c0 + c1) + (c2 + c3)) * 0.125f;                  // 1/sqrt(64), bark.cpp:1318
+}
 // ------------------------------------------------------------------------------------------------
 // decode attention, two launches so that the key stream is spread over the whole chip:
 //   attn_scores_kernel : one wave per 64 keys and head (grid P/64 x H); lane = key, C2 = one fmaf chain
@@ -26,15 +35,7 @@ __global__ __launch_bounds__(64) void attn_scores_kernel(const AttnDecodeArgs a)
     for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
     const int ctx = a.st->n_past + 1;
     const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
-    float acc = 0.0f;
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) {
-        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
-        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
-        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
-        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
-    }
-    const float sc = acc * 0.125f;                                       // 1/sqrt(64), bark.cpp:1318
+    const float sc = score_chain(kv, qh);
     if (j < ctx) a.scores[(size_t) h * P + j] = sc;
     // row maximum for the softmax, kept exactly with an integer atomic (a.hmax[h] is reset by attn_mix_kernel)
     const float wmax = wave_max(j < ctx ? sc : -INFINITY);
@@ -102,21 +103,6 @@ __global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) 
 // K is loaded two 256-key groups ahead, every V row group of the live context is requested before the
 // first arithmetic instruction.
 // ------------------------------------------------------------------------------------------------
-template <int G> DEVINL void load_k_group(float4 (&kv)[16], const float4 * kp, int P) {
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P + 256 * G];
-}
-DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) {
-    float acc = 0.0f;
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) {
-        acc = fmaf(kv[dq].x, qh[4 * dq + 0], acc);
-        acc = fmaf(kv[dq].y, qh[4 * dq + 1], acc);
-        acc = fmaf(kv[dq].z, qh[4 * dq + 2], acc);
-        acc = fmaf(kv[dq].w, qh[4 * dq + 3], acc);
-    }
-    return acc * 0.125f;                                      // 1/sqrt(64), bark.cpp:1318
-}
 __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a) {
     __shared__ float es[1024];
     __shared__ float red_f[4];
@@ -424,11 +410,132 @@ __global__ __launch_bounds__(1024) void attn_wide_kernel(const AttnDecodeArgs a)
     TRACE_END_AB(a.tr);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Decode attention on partial scores.  The QKV kernel of the step (gemv_ln_wg_kernel<PS>) has already formed, for every cached key,
+// the four 16-d block sums of C2; this kernel adds them ((c0 + c1) + (c2 + c3)) * 0.125, scores the ONE key the step appended
+// itself, and runs softmax + mix in the value-sliced layout (workgroup = head x 64/S value dims, all 16 C5 chains local).  No K row
+// is read here except the newest: per workgroup 16 bytes of partials and 256/S bytes of V per key.
+//   NG = ceil(ctx / 256) is a template parameter chosen by a uniform branch, so every load count is static (the score of a thread
+//   does not wait behind the V stream) and waves without keys leave at once; groups below the last need no masking.
+// ------------------------------------------------------------------------------------------------
+template <int S, int NG>
+DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, const int ctx, float * es, float * red_f, double * red_d,
+                         float (*part)[64 / S], float * snew) {
+    constexpr int P = 1024, DS = 64 / S, NW = 16 * DS / 64, NKW = 4 * NG;      // mix waves, waves that own keys
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave >= NKW) return;                                    // static bound: these waves own no key of this context
+    const float4 p4 = reinterpret_cast<const float4 *>(a.ps)[(size_t) h * P + tid];
+    // value slice: chain = key mod 16, DS dims per chain
+    const int chain = tid / DS, d = tid % DS;                   // mix threads: tid < 16 * DS
+    float vv[16 * NG];
+    if (wave < NW) {
+        const float * vp = a.vc + ((size_t) h * P + chain) * 64 + DS * s + d;
+        #pragma unroll
+        for (int i = 0; i < 16 * NG; i++) vv[i] = vp[(size_t) i * 1024];       // key chain + 16 i
+    }
+    // the key this step appended (position ctx - 1): lanes 0..3 of the last key wave form its four C2 blocks
+    float s_new = -INFINITY;
+    if (wave == NKW - 1) {
+        const int b = lane & 3;
+        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + ((size_t) h * 16 + 4 * b) * P + (ctx - 1);
+        const float4 * qp = reinterpret_cast<const float4 *>(a.q + h * 64 + 16 * b);
+        float4 kq[4], q4[4];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { kq[i] = kp[(size_t) i * P]; q4[i] = qp[i]; }
+        const float qb[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
+                              q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
+        const float cb = score_block_f4(kq, qb);
+        const float c0 = readlane_f32(cb, 0), c1 = readlane_f32(cb, 1), c2 = readlane_f32(cb, 2), c3 = readlane_f32(cb, 3);
+        s_new = ((c0 + c1) + (c2 + c3)) * 0.125f;               // 1/sqrt(64), bark.cpp:1318
+    }
+    float sc = -INFINITY;
+    if (tid < ctx - 1) sc = ((p4.x + p4.y) + (p4.z + p4.w)) * 0.125f;
+    TRACE_TA(sc);
+    float mx = fmaxf(wave_max(sc), s_new);
+    if (lane == 0) { red_f[wave] = mx; if (wave == NKW - 1) *snew = s_new; }
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int i = 1; i < NKW; i++) mx = fmaxf(mx, red_f[i]);
+    if (tid == ctx - 1) sc = *snew;
+    float e = 0.0f;
+    if (tid < ctx) e = (float) exp((double) (sc - mx));
+    es[tid] = e;
+    const double wsum = wave_sum((double) e);
+    if (lane == 0) red_d[wave] = wsum;
+    __syncthreads();
+    TRACE_TB(e);
+    if (wave >= NW) return;
+    double sum = 0.0;                                           // fixed order: ascending waves
+    #pragma unroll
+    for (int i = 0; i < NKW; i++) sum += red_d[i];
+    const float inv = (float) (1.0 / sum);
+    // C5: groups below the last are complete (ctx > 256 (NG - 1)): plain chains; the last group drops masked terms by select
+    float acc = 0.0f;
+    #pragma unroll
+    for (int g = 0; g < NG; g++) {
+        float pj[16];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
+        #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float t = fmaf(vv[16 * g + i], pj[i], acc);
+            acc = (g < NG - 1 || chain + 16 * (16 * g + i) < ctx) ? t : acc;
+        }
+    }
+    [[maybe_unused]] const float trace_acc = acc;
+    part[chain][d] = acc;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0); the mix waves meet without the waves that have left
+    asm volatile("s_barrier" ::: "memory");
+    if (tid < DS) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        const int o = h * 64 + DS * s + tid;
+        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(1024) void attn_ps_kernel(const AttnDecodeArgs a) {
+    TRACE_T0();
+    TRACE_T1(a.H);
+    __shared__ float es[1024];
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ float part[16][64 / S];
+    __shared__ float snew;
+    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // slices of a head get ids congruent mod 8 (same XCD), as attn_dslice_kernel
+    const int h = x8 + 8 * (g8 / S), s = g8 % S;
+    if (h >= a.H) return;
+    const int ctx = a.st->n_past + 1;
+    [[maybe_unused]] const unsigned long long _tr2 = 0, _tra = 0, _trb = 0;
+    switch ((ctx + 255) >> 8) {
+        case 1:  attn_ps_body<S, 1>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
+        case 2:  attn_ps_body<S, 2>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
+        case 3:  attn_ps_body<S, 3>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
+        default: attn_ps_body<S, 4>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
+    }
+    TRACE_END(a.tr);
+}
+
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
     if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
     if (parts == 5) {
         if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: value-sliced decode attention needs one sequence and block_size 1024"); }
         hipLaunchKernelGGL(attn_dslice_kernel, dim3(8 * ATTN_SPLIT * ((a.H + 7) / 8)), dim3(256), 0, s, a);
+        return;
+    }
+    if (parts == 8 || parts == 9) {
+        if (a.nbatch != 1 || a.P != 1024 || !a.ps) { kernel_fail("bark-hip: partial-score decode attention needs one sequence, block_size 1024 and the QKV kernel's partials"); }
+        if (parts == 8) hipLaunchKernelGGL(attn_ps_kernel<4>, dim3(8 * 4 * ((a.H + 7) / 8)), dim3(1024), 0, s, a);
+        else            hipLaunchKernelGGL(attn_ps_kernel<8>, dim3(8 * 8 * ((a.H + 7) / 8)), dim3(1024), 0, s, a);
         return;
     }
     if (parts == 6 || parts == 7) {
@@ -449,7 +556,10 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
     const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
     // BARK_HIP_ATTN_MODE (A/B timing): 5 value-sliced 256-thread kernel, 6 wide fused kernel, 7 key scores + wide mix (two launches)
+    // 8 / 9: attention on the QKV kernel's partial scores, 4 / 8 value slices per head (needs a.ps)
     static const int mode = getenv("BARK_HIP_ATTN_MODE") ? atoi(getenv("BARK_HIP_ATTN_MODE")) : 6;
+    static const int ps_mode = getenv("BARK_HIP_ATTN_PS") ? atoi(getenv("BARK_HIP_ATTN_PS")) : 9;
+    if (can_split && a.ps && ps_mode) { launch_attn_decode_part(s, a, ps_mode); return; }
     launch_attn_decode_part(s, a, can_split ? mode : 4);
 }
 
@@ -476,22 +586,33 @@ __global__ __launch_bounds__(256) void attn_qk_kernel(const AttnPrefillArgs a) {
         qp[t] = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
         kp[t] = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
     }
-    floatx16 acc[2][2];
+    // C2: per 2 x 2 tile one running accumulator per block of 16 d; the block sums are combined as (c0 + c1) + (c2 + c3)
+    floatx16 acc[2][2], c01[2][2], c2[2][2];
     #pragma unroll
-    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    #pragma unroll 4
-    for (int dq = 0; dq < 16; dq++) {
-        float4 qv[2], kv[2];
+    for (int b = 0; b < 4; b++) {
         #pragma unroll
-        for (int t = 0; t < 2; t++) { qv[t] = qp[t][dq]; kv[t] = kp[t][(size_t) dq * a.P]; }
-        // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
         #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int dq = 4 * b; dq < 4 * b + 4; dq++) {
+            float4 qv[2], kv[2];
             #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].y : qv[i].x, half ? kv[j].y : kv[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].w : qv[i].z, half ? kv[j].w : kv[j].z, acc[i][j], 0, 0, 0);
-            }
+            for (int t = 0; t < 2; t++) { qv[t] = qp[t][dq]; kv[t] = kp[t][(size_t) dq * a.P]; }
+            // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].y : qv[i].x, half ? kv[j].y : kv[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].w : qv[i].z, half ? kv[j].w : kv[j].z, acc[i][j], 0, 0, 0);
+                }
+        }
+        #pragma unroll
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) {
+            if (b == 0) c01[i][j][r] = acc[i][j][r];
+            else if (b == 1) c01[i][j][r] = c01[i][j][r] + acc[i][j][r];
+            else if (b == 2) c2[i][j][r] = acc[i][j][r];
+            else acc[i][j][r] = c01[i][j][r] + (c2[i][j][r] + acc[i][j][r]);
+        }
     }
     // A operand = Q (accumulator rows = queries i), B operand = K (accumulator cols = keys j: coalesced stores)
     #pragma unroll
@@ -609,18 +730,22 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
             for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * a.P];
         };
         auto score_tile = [&](const float4 (&kv)[16], int jt) {
-            floatx16 acc;
+            // C2: one accumulator (= one fmaf chain) per block of 16 d, combined as (c0 + c1) + (c2 + c3)
+            floatx16 acc[4];
             #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-            #pragma unroll
-            for (int dq = 0; dq < 16; dq++) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].y : qv[dq].x, half ? kv[dq].y : kv[dq].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].w : qv[dq].z, half ? kv[dq].w : kv[dq].z, acc, 0, 0, 0);
+            for (int b = 0; b < 4; b++) {
+                #pragma unroll
+                for (int r = 0; r < 16; r++) acc[b][r] = 0.0f;
+                #pragma unroll
+                for (int dq = 4 * b; dq < 4 * b + 4; dq++) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].y : qv[dq].x, half ? kv[dq].y : kv[dq].x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[dq].w : qv[dq].z, half ? kv[dq].w : kv[dq].z, acc[b], 0, 0, 0);
+                }
             }
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;       // accumulator row = query, column = key
-                lds[i * ATT_LD + jt + l31] = acc[r] * 0.125f;            // 1/sqrt(64), bark.cpp:1318
+                lds[i * ATT_LD + jt + l31] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * 0.125f;   // 1/sqrt(64), bark.cpp:1318
             }
         };
         // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs

@@ -142,6 +142,19 @@ DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e)
 DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
 DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
 
+// C2: one 16-d block of an attention score: kq = the block's four d-quads of the key, qb = the block's 16 q values; one fmaf chain
+DEVINL float score_block_f4(const float4 * kq, const float * qb) {
+    float acc = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        acc = fmaf(kq[i].x, qb[4 * i + 0], acc);
+        acc = fmaf(kq[i].y, qb[4 * i + 1], acc);
+        acc = fmaf(kq[i].z, qb[4 * i + 2], acc);
+        acc = fmaf(kq[i].w, qb[4 * i + 3], acc);
+    }
+    return acc;
+}
+
 // Operands the epilogue reads, fetched at kernel entry so that their latency overlaps the weight stream.
 struct EpiPre { float bias; float res; int n_past; };
 DEVINL EpiPre epilogue_prefetch(const LinArgs & a, int n, int m, int row_off) {

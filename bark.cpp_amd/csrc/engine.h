@@ -76,6 +76,7 @@ struct bark_context {
     std::vector<void *> allocs;                         // everything else (freed in destroy)
     // GPT scratch
     float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
+    float * ps = nullptr;                               // [H][P][4] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;

@@ -82,12 +82,17 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
+        // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
+        static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
+        const bool ps = use_ps && !m.q4 && P == 1024;
+        if (ps) a.ps = c->ps;
         BARK_TRACE_SET(c, a, (a.M + 3) / 4);
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
         at.att32 = m.q4 ? c->att32 : nullptr;
-        BARK_TRACE_SET(c, at, 8 * 4 * ((H + 7) / 8) * 16);       // wide kernel: 16 waves per workgroup
+        if (ps) at.ps = c->ps;
+        BARK_TRACE_SET(c, at, 8 * 8 * ((H + 7) / 8) * 16);       // up to 8 slices per head, 16 waves per workgroup
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = c->att32; else p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;

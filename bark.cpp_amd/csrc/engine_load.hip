@@ -129,6 +129,8 @@ static void init_runtime(bark_context * ctxp) {
     ctx->att = dev_alloc<half_t>(ctx.get(), NE);
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
     ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
+    ctx->ps = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * 4);
+    HIP_OK(hipMemset(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float)));
     if (ctx->any_q4) {
         ctx->att32 = dev_alloc<float>(ctx.get(), NE);
         ctx->h32 = dev_alloc<float>(ctx.get(), NE * 4);

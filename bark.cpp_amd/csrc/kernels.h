@@ -79,6 +79,9 @@ struct LinArgs {
     float * out_h32 = nullptr;            // q4_0 path: the GELU output stays f32 (it is quantised to q8_0 by the next product)
     // EPI_LOGITS: out[n*ld_out + m] = dot (+ bias)
     float * out = nullptr; int ld_out = 0;
+    // EPI_QKV, decode, f16 weights: the workgroup that produces 16 consecutive q values (one C2 block of one head) also forms that
+    // block's partial score against every cached key: ps[(h * P + j) * 4 + block], j < n_past (attn_ps_kernel finishes the sum)
+    float * ps = nullptr;
     float out_div = 0.0f;                 // != 0: out = (dot + bias) / out_div - the sampler's `l /= 0.7f` (bark.cpp:226-228) done where the logit is born
     // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
     // the row window starts at parity_rows * (st->step & 1) rows into W (and bias)
@@ -117,6 +120,7 @@ struct AttnDecodeArgs {
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32
     float * scores = nullptr;             // scratch [H][P]
+    const float * ps = nullptr;           // [H][P][4] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
     BARK_TRACE_FIELD

@@ -145,7 +145,11 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
 // elements per thread, wave sums by DPP, the four wave sums meet in LDS, and the f16-rounded row is published in LDS (1.5 KB) from
 // where every lane reads its 16-byte chunks.  Same arithmetic per element as before (ggml_norm: double sums, bark.cpp:1265-1274).
 // ------------------------------------------------------------------------------------------------
-template <int NBLK, bool LNB>
+// PS = true (QKV product of a decode step): the 16 rows of a workgroup below n_embd are one 16-d block of one head's q.  C2 sums a
+// score as four such blocks, so this workgroup can form its block's partial score against every cached key right here, where q is
+// born: the K stream of the attention (the per-CU bandwidth bound of every fused decode-attention kernel tried) is spread over the
+// 4 H q-workgroups of this launch, 64 bytes per key each, requested together with the weights.
+template <int NBLK, bool LNB, bool PS>
 __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     TRACE_T0();
     TRACE_T1(a.M);
@@ -162,6 +166,19 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     half8 wv[NBLK];
     #pragma unroll
     for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
+    // partial scores: keys tid, tid + 256, ... ; d-quads 4 blk .. 4 blk + 3 of head hq
+    [[maybe_unused]] float4 kq[4][4];
+    [[maybe_unused]] const int m0 = blockIdx.x * 16;
+    [[maybe_unused]] const bool is_q = PS && m0 < a.E;
+    [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
+    [[maybe_unused]] const float4 * kqp = nullptr;
+    if constexpr (PS) {
+        if (is_q) {
+            kqp = reinterpret_cast<const float4 *>(a.kc) + ((size_t) hq * 16 + 4 * blk) * a.P + tid;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) kq[0][i] = kqp[(size_t) i * a.P];         // keys 0..255: always inside the cache
+        }
+    }
     float xv[EPT], gv[EPT], bv[EPT];
     #pragma unroll
     for (int i = 0; i < EPT; i++) {
@@ -172,6 +189,17 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
         if constexpr (LNB) bv[i] = ok ? a.ln_b[e] : 0.0f; else bv[i] = 0.0f;
     }
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    if constexpr (PS) {
+        if (is_q) {
+            #pragma unroll
+            for (int g = 1; g < 4; g++) {
+                if (pre.n_past > 256 * g) {
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) kq[g][i] = kqp[(size_t) i * a.P + 256 * g];
+                }
+            }
+        }
+    }
     double s1 = 0.0;
     #pragma unroll
     for (int i = 0; i < EPT; i++) if ((K % 256 == 0) || tid + 256 * i < K) s1 += (double) xv[i];
@@ -206,6 +234,21 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     TRACE_T2(acc);
     acc = wave_xor_add16(acc);
     if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    if constexpr (PS) {
+        __shared__ float qs[16];
+        if (is_q) {                                              // uniform per workgroup
+            if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stored
+            __syncthreads();
+            float qb[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) qb[i] = qs[i];
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int j = tid + 256 * g;
+                if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq[g], qb);
+            }
+        }
+    }
     TRACE_END(a.tr);
 }
 
@@ -217,8 +260,12 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
             static const bool one_wave = getenv("BARK_HIP_LN_ONE_WAVE") != nullptr;       // A/B: every wave normalises the row itself
             if (!one_wave) {
                 const dim3 g16((a.M + 15) / 16), b256(256);
-                if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true>), g16, b256, 0, s, a);
-                else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false>), g16, b256, 0, s, a);
+                if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
+                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), g16, b256, 0, s, a);
+                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), g16, b256, 0, s, a);
+                }
+                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a);
+                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a);
             }
             else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
             else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);

@@ -169,7 +169,9 @@ static std::vector<float> to_f32(const Tensor & t) {
 //        walks its chunks in ascending order, and inside a chunk its 8 elements in ascending
 //        order, with acc = fmaf(w, x, acc) starting from +0.  The 16 chain sums are combined by
 //        the pairwise tree ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)) ... (butterfly xor 1,2,4,8).
-//  C2  attention score  s = sum_d k[d]*q[d]  : ONE chain, d ascending, acc = fmaf(k, q, acc).
+//  C2  attention score  s = sum_d k[d]*q[d]  (head_dim 64): FOUR chains, one per block of 16 consecutive d, each walking its d in
+//        ascending order with acc = fmaf(k, q, acc) from +0; combined as (c0 + c1) + (c2 + c3).  (The 16-d block is what one
+//        workgroup of the decode QKV kernel produces of q, so a chain can be formed where its q values are born.)
 //  C5  attention mix    o[d] = sum_j v[j][d]*p[j] : key j belongs to chain (j mod 16), chains walk
 //        j ascending with acc = fmaf(v, p, acc); combined by the same 16-leaf tree as C1.
 // ------------------------------------------------------------------------------------
@@ -590,7 +592,7 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
     const int ctx8 = (ctx_total + 7) & ~7;
     o.scores.ensure((size_t) nth * ctx8);
     o.vt.ensure((size_t) nth * D * ctx8);
-    assert(D % 8 == 0);
+    assert(D == 64);                                       // C2 is stated for head_dim 64 (every Bark model)
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nth) if (nth > 1)
     for (int h = 0; h < H; h++) {
         const int tid = omp_get_thread_num();
@@ -601,11 +603,15 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
         for (int i = 0; i < N; i++) {
             const float * qi = q + (size_t) i * ldq + h * D;
             const int valid = causal ? std::min(ctx_total, n_past + i + 1) : ctx_total;
-            // C2: s[j] = chain over d of fmaf(K[j][d], Q[i][d], acc)   (f32 x f32, bark.cpp:1316)
+            // C2: s[j] = four chains over the 16-d blocks of fmaf(K[j][d], Q[i][d], acc), then (c0 + c1) + (c2 + c3)   (f32 x f32, bark.cpp:1316)
             for (int j0 = 0; j0 < valid; j0 += 8) {
-                __m256 acc = _mm256_setzero_ps();
-                for (int d = 0; d < D; d++) acc = _mm256_fmadd_ps(_mm256_loadu_ps(Kt + (size_t) d * ctx8 + j0), _mm256_set1_ps(qi[d]), acc);
-                _mm256_storeu_ps(row + j0, acc);
+                __m256 blk[4];
+                for (int b = 0; b < 4; b++) {
+                    __m256 acc = _mm256_setzero_ps();
+                    for (int d = 16 * b; d < 16 * b + 16; d++) acc = _mm256_fmadd_ps(_mm256_loadu_ps(Kt + (size_t) d * ctx8 + j0), _mm256_set1_ps(qi[d]), acc);
+                    blk[b] = acc;
+                }
+                _mm256_storeu_ps(row + j0, _mm256_add_ps(_mm256_add_ps(blk[0], blk[1]), _mm256_add_ps(blk[2], blk[3])));
             }
             for (int j = 0; j < valid; j++) row[j] *= scale;                // ggml_scale_inplace, bark.cpp:1318
             softmax_row(row, valid);

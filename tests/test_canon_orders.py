@@ -107,10 +107,14 @@ def test_c2_c5_attention(lib, N, ctx, n_past, causal):
     for i in range(N):
         valid = min(ctx, n_past + i + 1) if causal else ctx
         s = []
-        for j in range(valid):                       # C2: one chain over d
-            acc = np.float32(0.0)
-            for d in range(64):
-                acc = fma32(k[j, d], q[i, d], acc)
+        for j in range(valid):                       # C2: four chains over the 16-d blocks, (c0 + c1) + (c2 + c3)
+            blk = []
+            for b in range(4):
+                acc = np.float32(0.0)
+                for d in range(16 * b, 16 * b + 16):
+                    acc = fma32(k[j, d], q[i, d], acc)
+                blk.append(acc)
+            acc = add32(add32(blk[0], blk[1]), add32(blk[2], blk[3]))
             s.append(np.float32(acc * np.float32(0.125)))
         p = softmax_rows(s, valid)
         for d in range(0, 64, 13):                   # C5: key j -> chain j % 16, tree-combined

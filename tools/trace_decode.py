@@ -68,9 +68,9 @@ def main():
                "gap_from_prev_us": None if prev_end is None else (first - prev_end) * tick,
                "entry_spread_us": (tt[:, 0].max() - first) * tick,
                "kernarg_us_med": float(np.median(tt[:, 1] - tt[:, 0])) * tick,
-               "operands_us_med": float(np.median(tt[:, 2] - tt[:, 1])) * tick,
-               "operands_us_max": float((tt[:, 2] - tt[:, 1]).max()) * tick,
-               "tail_us_med": float(np.median(tt[:, 3] - tt[:, 2])) * tick, "tail_us_max": float((tt[:, 3] - tt[:, 2]).max()) * tick,
+               "operands_us_med": float(np.median(np.maximum(tt[:, 2], tt[:, 1]) - tt[:, 1])) * tick,
+               "operands_us_max": float((np.maximum(tt[:, 2], tt[:, 1]) - tt[:, 1]).max()) * tick,
+               "tail_us_med": float(np.median(tt[:, 3] - np.maximum(tt[:, 2], tt[:, 1]))) * tick, "tail_us_max": float((tt[:, 3] - np.maximum(tt[:, 2], tt[:, 1])).max()) * tick,
                "wave_us_med": float(np.median(tt[:, 3] - tt[:, 0])) * tick, "wave_us_max": float((tt[:, 3] - tt[:, 0]).max()) * tick,
                "span_us": (last - first) * tick}
         ab = tab[idx]
