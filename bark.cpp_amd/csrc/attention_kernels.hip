@@ -421,29 +421,31 @@ __global__ __launch_bounds__(1024) void attn_wide_kernel(const AttnDecodeArgs a)
 // ------------------------------------------------------------------------------------------------
 template <int S, int NG>
 DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, const int ctx, float * es, float * red_f, double * red_d,
-                         float (*part)[64 / S], float * snew) {
+                         float (*part)[64 / S], float * snew, [[maybe_unused]] unsigned long long (&stamp)[3]) {
     constexpr int P = 1024, DS = 64 / S, NW = 16 * DS / 64, NKW = 4 * NG;      // mix waves, waves that own keys
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (wave >= NKW) return;                                    // static bound: these waves own no key of this context
-    const float4 p4 = reinterpret_cast<const float4 *>(a.ps)[(size_t) h * P + tid];
+    // every stream below is a buffer load: wave-uniform base + 32-bit lane offset + scalar offset (device_utils.h)
+    const float4 p4 = buf_ld_f4(buf_rsrc(reinterpret_cast<const float4 *>(a.ps) + (size_t) h * P), (unsigned) tid * 16u, 0u);
     // value slice: chain = key mod 16, DS dims per chain
     const int chain = tid / DS, d = tid % DS;                   // mix threads: tid < 16 * DS
     float vv[16 * NG];
     if (wave < NW) {
-        const float * vp = a.vc + ((size_t) h * P + chain) * 64 + DS * s + d;
+        const BufRsrc vr = buf_rsrc(a.vc + (size_t) h * P * 64 + DS * s);
+        const unsigned voff = (unsigned) (chain * 64 + d) * 4u;
         #pragma unroll
-        for (int i = 0; i < 16 * NG; i++) vv[i] = vp[(size_t) i * 1024];       // key chain + 16 i
+        for (int i = 0; i < 16 * NG; i++) vv[i] = buf_ld_f32(vr, voff, (unsigned) i * 4096u);      // key chain + 16 i: 16 rows of 256 bytes further
     }
     // the key this step appended (position ctx - 1): lanes 0..3 of the last key wave form its four C2 blocks
     float s_new = -INFINITY;
     if (wave == NKW - 1) {
         const int b = lane & 3;
-        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + ((size_t) h * 16 + 4 * b) * P + (ctx - 1);
-        const float4 * qp = reinterpret_cast<const float4 *>(a.q + h * 64 + 16 * b);
+        const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + (ctx - 1));
+        const BufRsrc qr = buf_rsrc(a.q + h * 64);
         float4 kq[4], q4[4];
         #pragma unroll
-        for (int i = 0; i < 4; i++) { kq[i] = kp[(size_t) i * P]; q4[i] = qp[i]; }
+        for (int i = 0; i < 4; i++) { kq[i] = buf_ld_f4(kr, (unsigned) (4 * b) * (P * 16u), (unsigned) i * (P * 16u)); q4[i] = buf_ld_f4(qr, (unsigned) b * 64u, (unsigned) i * 16u); }
         const float qb[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
                               q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
         const float cb = score_block_f4(kq, qb);
@@ -452,7 +454,7 @@ DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, con
     }
     float sc = -INFINITY;
     if (tid < ctx - 1) sc = ((p4.x + p4.y) + (p4.z + p4.w)) * 0.125f;
-    TRACE_TA(sc);
+    TRACE_SET(stamp[0], sc);
     float mx = fmaxf(wave_max(sc), s_new);
     if (lane == 0) { red_f[wave] = mx; if (wave == NKW - 1) *snew = s_new; }
     __syncthreads();
@@ -466,7 +468,7 @@ DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, con
     const double wsum = wave_sum((double) e);
     if (lane == 0) red_d[wave] = wsum;
     __syncthreads();
-    TRACE_TB(e);
+    TRACE_SET(stamp[1], e);
     if (wave >= NW) return;
     double sum = 0.0;                                           // fixed order: ascending waves
     #pragma unroll
@@ -485,7 +487,7 @@ DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, con
             acc = (g < NG - 1 || chain + 16 * (16 * g + i) < ctx) ? t : acc;
         }
     }
-    [[maybe_unused]] const float trace_acc = acc;
+    TRACE_SET(stamp[2], acc);
     part[chain][d] = acc;
     __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0); the mix waves meet without the waves that have left
     asm volatile("s_barrier" ::: "memory");
@@ -515,14 +517,16 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const AttnDecodeArgs a) {
     const int h = x8 + 8 * (g8 / S), s = g8 % S;
     if (h >= a.H) return;
     const int ctx = a.st->n_past + 1;
-    [[maybe_unused]] const unsigned long long _tr2 = 0, _tra = 0, _trb = 0;
+    unsigned long long stamp[3] = {0, 0, 0};                     // diagnostic build: score ready, softmax statistics ready, mix done
     switch ((ctx + 255) >> 8) {
-        case 1:  attn_ps_body<S, 1>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
-        case 2:  attn_ps_body<S, 2>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
-        case 3:  attn_ps_body<S, 3>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
-        default: attn_ps_body<S, 4>(a, h, s, ctx, es, red_f, red_d, part, &snew); break;
+        case 1:  attn_ps_body<S, 1>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
+        case 2:  attn_ps_body<S, 2>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
+        case 3:  attn_ps_body<S, 3>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
+        default: attn_ps_body<S, 4>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
     }
-    TRACE_END(a.tr);
+#ifdef BARK_TRACE
+    trace_emit(a.tr, _tr0, _tr1, stamp[2], trace_clock(), stamp[0], stamp[1]);
+#endif
 }
 
 void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {

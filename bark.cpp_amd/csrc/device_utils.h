@@ -34,6 +34,7 @@ DEVINL void trace_emit(const TraceSink & tr, unsigned long long t0, unsigned lon
 #define TRACE_T2(dep) const unsigned long long _tr2 = trace_clock_v(dep)
 #define TRACE_TA(dep) const unsigned long long _tra = trace_clock_v(dep)
 #define TRACE_TB(dep) const unsigned long long _trb = trace_clock_v(dep)
+#define TRACE_SET(var, dep) var = trace_clock_v(dep)
 #define TRACE_END(tr) trace_emit(tr, _tr0, _tr1, _tr2, trace_clock())
 #define TRACE_END_AB(tr) trace_emit(tr, _tr0, _tr1, _tr2, trace_clock(), _tra, _trb)
 #else
@@ -42,6 +43,7 @@ DEVINL void trace_emit(const TraceSink & tr, unsigned long long t0, unsigned lon
 #define TRACE_T2(dep)
 #define TRACE_TA(dep)
 #define TRACE_TB(dep)
+#define TRACE_SET(var, dep)
 #define TRACE_END(tr)
 #define TRACE_END_AB(tr)
 #endif
@@ -141,6 +143,32 @@ DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e)
 // K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
 DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
 DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
+
+// Buffer loads: address = wave-uniform base (in a 128-bit descriptor held in SGPRs) + 32-bit lane offset + scalar offset, all in bytes.
+// A stream of loads at constant strides then needs ONE address VGPR and one scalar move per load; the flat form the compiler picks
+// for `base[lane_part + i * stride]` spends a 64-bit vector add (+ wait state) per load, ~250 issue slots for a 64-load stream.
+// (The clang builtin __builtin_amdgcn_raw_buffer_load_b128 of this ROCm release is lowered to a ONE-dword load - probe
+// tools/probes/bufload_probe.hip - so the LLVM intrinsics are bound by name, the way composable_kernel does.)
+typedef int   int4v   __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ float4v llvm_amdgcn_raw_buffer_load_v4f32(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float   llvm_amdgcn_raw_buffer_load_f32(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+struct BufRsrc { int4v d; };
+DEVINL BufRsrc buf_rsrc(const void * uniform_base) {
+    const unsigned long long a = (unsigned long long) uniform_base;
+    BufRsrc r;
+    r.d.x = (int) (unsigned) a; r.d.y = (int) (unsigned) (a >> 32);     // 48-bit base, stride 0
+    r.d.z = -1;                                                          // num_records: no bound in practice
+    r.d.w = 0x00020000;                                                  // raw buffer, 32-bit data format (gfx9 descriptor word 3)
+    return r;
+}
+DEVINL float buf_ld_f32(const BufRsrc & r, unsigned lane_bytes, unsigned scalar_bytes) {
+    return llvm_amdgcn_raw_buffer_load_f32(r.d, (int) lane_bytes, (int) scalar_bytes, 0);
+}
+DEVINL float4 buf_ld_f4(const BufRsrc & r, unsigned lane_bytes, unsigned scalar_bytes) {
+    const float4v u = llvm_amdgcn_raw_buffer_load_v4f32(r.d, (int) lane_bytes, (int) scalar_bytes, 0);
+    return float4{u.x, u.y, u.z, u.w};
+}
 
 // C2: one 16-d block of an attention score: kq = the block's four d-quads of the key, qb = the block's 16 q values; one fmaf chain
 DEVINL float score_block_f4(const float4 * kq, const float * qb) {

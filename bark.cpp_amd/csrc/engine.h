@@ -37,7 +37,8 @@ struct GptModel {
     std::vector<Layer> layers;
     float * kcache = nullptr, * vcache = nullptr;       // [L][H][16][P][4] / [L][H][P][64] f32; fine model: L = 1 scratch
     size_t kv_layer_stride = 0;                         // floats per layer (0 for the fine model's shared scratch)
-    hipGraphExec_t decode_graph = nullptr;              // embed -> layers -> LM head -> greedy sample
+    hipGraphExec_t decode_graph = nullptr;              // layers -> LM head -> sample + embedding of the next token
+    hipGraphExec_t decode_graph8 = nullptr;             // eight such steps in one graph: one launch gap (6.5 us) per eight tokens
     hipGraphExec_t bench_graph = nullptr;               // same, without advancing n_past (timing hook)
 };
 

@@ -86,7 +86,7 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
         const bool ps = use_ps && !m.q4 && P == 1024;
         if (ps) a.ps = c->ps;
-        BARK_TRACE_SET(c, a, (a.M + 3) / 4);
+        BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 3 * (E / 4));
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
@@ -207,11 +207,11 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
     if (sample) run_sample(c, s, n_past_add, prescale);
 }
 
-hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add) {
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    try { enqueue_decode_step(c, s, true, n_past_add, false); }
+    try { for (int i = 0; i < n_steps; i++) enqueue_decode_step(c, s, true, n_past_add, false); }
     catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
     HIP_OK(hipStreamEndCapture(c->stream, &graph));
     HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -228,6 +228,21 @@ void decode_step_greedy(bark_context * c, const StageCfg & s) {
     } else {
         enqueue_decode_step(c, s, true, 1, false);
     }
+}
+
+// n consecutive decode steps.  Between two graph launches the GPU idles ~6.5 us (in-kernel time line, tools/trace_decode.py) against
+// ~1.3 us between two kernels of one graph, so runs of steps are replayed from an eight-step graph (the state lives on the device:
+// a step needs nothing from the host) and only the remainder from the one-step graph.
+void decode_steps_greedy(bark_context * c, const StageCfg & s, int n) {
+    GptModel & m = c->gpt[s.which];
+    static const bool multi = !getenv("BARK_HIP_GRAPH_STEPS") || atoi(getenv("BARK_HIP_GRAPH_STEPS")) > 1;
+    while (c->use_graph && multi && n >= 8) {
+        if (!m.decode_graph8) m.decode_graph8 = capture_decode(c, s, 1, 8);
+        HIP_OK(hipGraphLaunch(m.decode_graph8, c->stream));
+        c->stats.graph_replays++;
+        n -= 8;
+    }
+    for (; n > 0; n--) decode_step_greedy(c, s);
 }
 
 // ---- host-side sampling (temp > 0, or settling a near tie): bark.cpp:184-270 -------------------------
@@ -375,10 +390,8 @@ std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t
         StepState cur{};
         while (true) {
             const int batch_end = std::min(n_steps, issued + 32);
-            for (; issued < batch_end; issued++) {
-                decode_step_greedy(c, s);
-                progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder));
-            }
+            decode_steps_greedy(c, s, batch_end - issued);
+            for (; issued < batch_end; issued++) progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder));
             cur = get_state(c);                                        // poll the stop rule every 32 steps
             if (cur.eos_step != INT32_MAX || issued >= n_steps) break;
         }
@@ -483,10 +496,8 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
                 run_sample(c, s, rows);
             }
             progress(c, COARSE, 100 * (step_idx + 1) / n_steps);
-            for (int j = 1; j < steps_here; j++) {
-                decode_step_greedy(c, s);
-                progress(c, COARSE, 100 * (step_idx + j + 1) / n_steps);
-            }
+            decode_steps_greedy(c, s, steps_here - 1);
+            for (int j = 1; j < steps_here; j++) progress(c, COARSE, 100 * (step_idx + j + 1) / n_steps);
             const StepState cur = get_state(c);
             std::vector<int32_t> got((size_t) steps_here);
             HIP_OK(hipMemcpy(got.data(), c->d_out_tokens, (size_t) steps_here * 4, hipMemcpyDeviceToHost));

@@ -66,8 +66,9 @@ struct StageCfg {            // what differs between the semantic and the coarse
 StageCfg stage_cfg(bark_context * c, int which);
 void run_sample(bark_context * c, const StageCfg & s, int n_past_add, bool prescaled = false);
 void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add, bool embed = true);
-hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add);
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps = 1);
 void decode_step_greedy(bark_context * c, const StageCfg & s);
+void decode_steps_greedy(bark_context * c, const StageCfg & s, int n);
 int sample_host(std::vector<float> & l, std::mt19937 & rng, float temp, float * eos_p);
 std::vector<float> fetch_logits(bark_context * c, size_t n);
 void upload_uniforms(bark_context * c, int n);

@@ -79,6 +79,7 @@ bark_context::~bark_context() {
     (void) hipSetDevice(device);
     for (auto & g : gpt) {
         if (g.decode_graph) (void) hipGraphExecDestroy(g.decode_graph);
+        if (g.decode_graph8) (void) hipGraphExecDestroy(g.decode_graph8);
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
@@ -101,6 +102,7 @@ void engine_invalidate_graphs(bark_context * ctx) {
     for (auto & g : ctx->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
     for (auto & g : ctx->gpt) {
         if (g.decode_graph) { (void) hipGraphExecDestroy(g.decode_graph); g.decode_graph = nullptr; }
+        if (g.decode_graph8) { (void) hipGraphExecDestroy(g.decode_graph8); g.decode_graph8 = nullptr; }
         if (g.bench_graph) { (void) hipGraphExecDestroy(g.bench_graph); g.bench_graph = nullptr; }
     }
 }
@@ -437,7 +439,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     for (int g = 0; g < 3; g++) {
         ctx->gpt[g] = src->gpt[g];
         ctx->gpt[g].kcache = ctx->gpt[g].vcache = nullptr;
-        ctx->gpt[g].decode_graph = ctx->gpt[g].bench_graph = nullptr;
+        ctx->gpt[g].decode_graph = ctx->gpt[g].decode_graph8 = ctx->gpt[g].bench_graph = nullptr;
     }
     ctx->codec = src->codec;
     ctx->device = src->device; ctx->use_graph = src->use_graph;

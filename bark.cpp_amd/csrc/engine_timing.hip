@@ -30,15 +30,18 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     // but keep them finite: zero them once
     HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-    if (!m.bench_graph) m.bench_graph = capture_decode(c, s, 0);       // n_past does not advance
+    // the graph the stage loops replay: eight steps per launch (BARK_HIP_GRAPH_STEPS=1: one); n_past does not advance here
+    static const int per_graph = (getenv("BARK_HIP_GRAPH_STEPS") && atoi(getenv("BARK_HIP_GRAPH_STEPS")) <= 1) ? 1 : 8;
+    if (!m.bench_graph) m.bench_graph = capture_decode(c, s, 0, per_graph);
     for (int i = 0; i < 3; i++) HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
     set_state(c, st);
+    iters = std::max(1, iters / per_graph) * per_graph;
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; i++) {
+    for (int i = 0; i < iters; i += per_graph) {
         HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
-        if ((i & 1023) == 1023) set_state(c, st);                        // out_tokens holds 2048 entries
+        if (((i / per_graph) & 127) == 127) set_state(c, st);             // out_tokens holds 2048 entries
     }
     HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipEventSynchronize(e1));

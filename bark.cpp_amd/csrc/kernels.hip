@@ -159,24 +159,29 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     __shared__ double red1[4], red2[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
-    const int m = (blockIdx.x * 4 + wave) * 4 + rg;
+    // PS: the grid carries three more copies of the q workgroups (ids behind the M / 16 main ones).  Copy r repeats the LayerNorm and
+    // the 16 q rows (weights come from L2) and scores the keys 256 r .. 256 r + 255 only, so no workgroup pulls more than 16 KB of K;
+    // it writes nothing but partial scores.
+    [[maybe_unused]] const int n_main = (a.M + 15) >> 4, n_q = a.E >> 4;
+    [[maybe_unused]] const int rep = PS && (int) blockIdx.x >= n_main ? 1 + ((int) blockIdx.x - n_main) / n_q : 0;
+    const int wg = PS && rep ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
+    const int m = (wg * 4 + wave) * 4 + rg;
     const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
     const bool live = m < a.M;
     const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
     half8 wv[NBLK];
     #pragma unroll
     for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
-    // partial scores: keys tid, tid + 256, ... ; d-quads 4 blk .. 4 blk + 3 of head hq
-    [[maybe_unused]] float4 kq[4][4];
-    [[maybe_unused]] const int m0 = blockIdx.x * 16;
+    // partial scores: key 256 rep + tid; d-quads 4 blk .. 4 blk + 3 of head hq
+    [[maybe_unused]] float4 kq[4];
+    [[maybe_unused]] const int m0 = wg * 16;
     [[maybe_unused]] const bool is_q = PS && m0 < a.E;
     [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
-    [[maybe_unused]] const float4 * kqp = nullptr;
     if constexpr (PS) {
         if (is_q) {
-            kqp = reinterpret_cast<const float4 *>(a.kc) + ((size_t) hq * 16 + 4 * blk) * a.P + tid;
+            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(a.kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + 256 * rep);     // PS implies P == 1024
             #pragma unroll
-            for (int i = 0; i < 4; i++) kq[0][i] = kqp[(size_t) i * a.P];         // keys 0..255: always inside the cache
+            for (int i = 0; i < 4; i++) kq[i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);    // rows beyond n_past hold stale bits; their scores are not stored
         }
     }
     float xv[EPT], gv[EPT], bv[EPT];
@@ -189,17 +194,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
         if constexpr (LNB) bv[i] = ok ? a.ln_b[e] : 0.0f; else bv[i] = 0.0f;
     }
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
-    if constexpr (PS) {
-        if (is_q) {
-            #pragma unroll
-            for (int g = 1; g < 4; g++) {
-                if (pre.n_past > 256 * g) {
-                    #pragma unroll
-                    for (int i = 0; i < 4; i++) kq[g][i] = kqp[(size_t) i * a.P + 256 * g];
-                }
-            }
-        }
-    }
+    if constexpr (PS) { if (rep && pre.n_past <= 256 * rep) return; }      // uniform: this copy's keys are not in the context yet
     double s1 = 0.0;
     #pragma unroll
     for (int i = 0; i < EPT; i++) if ((K % 256 == 0) || tid + 256 * i < K) s1 += (double) xv[i];
@@ -233,20 +228,17 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     }
     TRACE_T2(acc);
     acc = wave_xor_add16(acc);
-    if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    if (live && c == 0 && !rep) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (PS) {
         __shared__ float qs[16];
         if (is_q) {                                              // uniform per workgroup
-            if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stored
+            if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
             __syncthreads();
             float qb[16];
             #pragma unroll
             for (int i = 0; i < 16; i++) qb[i] = qs[i];
-            #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int j = tid + 256 * g;
-                if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq[g], qb);
-            }
+            const int j = 256 * rep + tid;
+            if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq, qb);
         }
     }
     TRACE_END(a.tr);
@@ -261,8 +253,9 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
             if (!one_wave) {
                 const dim3 g16((a.M + 15) / 16), b256(256);
                 if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
-                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), g16, b256, 0, s, a);
-                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), g16, b256, 0, s, a);
+                    const dim3 gps((a.M + 15) / 16 + 3 * (a.E / 16));      // + three copies of the q workgroups (keys 256.., 512.., 768..)
+                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a);
+                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a);
                 }
                 else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a);
                 else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a);
