@@ -6,7 +6,7 @@ SRC="$HERE/csrc"
 OUT="$HERE/lib"
 mkdir -p "$OUT" "$OUT/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function -I$HERE/../include -I$SRC"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -I$HERE/../include -I$SRC"
 # explicit object list: stale objects of renamed / split sources are never linked
 OBJS=()
 pids=()

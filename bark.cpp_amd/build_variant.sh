@@ -7,7 +7,7 @@ SUF="$1"; shift
 SRC="$HERE/csrc"; OUT="$HERE/lib"; OBJ="$OUT/obj_$SUF"
 mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wall -Wno-unused-function -Wno-pass-failed -I$HERE/../include -I$SRC $*"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-pass-failed -I$HERE/../include -I$SRC $*"
 pids=()
 for f in kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_batch.hip engine_timing.hip api.hip; do
     $HIPCC $FLAGS -c "$SRC/$f" -o "$OBJ/${f%.*}.o" & pids+=($!)

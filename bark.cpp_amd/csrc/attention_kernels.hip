@@ -2,6 +2,7 @@
 // multi-query prefill / fine kernels (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
 #include "device_utils.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -414,118 +415,119 @@ __global__ __launch_bounds__(1024) void attn_wide_kernel(const AttnDecodeArgs a)
 // ------------------------------------------------------------------------------------------------
 // Decode attention on partial scores.  The QKV kernel of the step (gemv_ln_wg_kernel<PS>) has already formed, for every cached key,
 // the four 16-d block sums of C2; this kernel adds them ((c0 + c1) + (c2 + c3)) * 0.125, scores the ONE key the step appended
-// itself, and runs softmax + mix in the value-sliced layout (workgroup = head x 64/S value dims, all 16 C5 chains local).  No K row
-// is read here except the newest: per workgroup 16 bytes of partials and 256/S bytes of V per key.
-//   NG = ceil(ctx / 256) is a template parameter chosen by a uniform branch, so every load count is static (the score of a thread
-//   does not wait behind the V stream) and waves without keys leave at once; groups below the last need no masking.
+// itself (from the fixed-address copy of its K row, so that those loads do not wait for the context length), and runs softmax + mix
+// in the value-sliced layout: workgroup = head x 4 value dims (one d-quad), all 16 C5 chains local, no cross-workgroup traffic, no K row read.
+//   thread = key: 16 bytes of partial scores + 16 bytes of V (one d-quad, read from the K-layout copy of V where the quads of
+//   consecutive keys are contiguous: with the [key][64] layout a wave's load touched 64 cache lines for 1 KB), staged in LDS.  A CU pulls
+//   only ~24 bytes/ns from the memory side, so the head's V is spread over 16 workgroups (10 KB each at 640 keys); the slices of a
+//   head share an XCD and its L2, where all but the first find the partial scores.  (Holding the V rows in the registers of
+//   the two mix waves cost those waves ~0.6 us just to ISSUE 48 loads - the memory pipeline's queue - in front of the first barrier.)
+//   mix: 16 chains x DS dims walk their keys out of LDS (values and probabilities), tree over the chains, 8 outputs.
+// leading parameters: what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel in kernels.hip)
 // ------------------------------------------------------------------------------------------------
-template <int S, int NG>
-DEVINL void attn_ps_body(const AttnDecodeArgs & a, const int h, const int s, const int ctx, float * es, float * red_f, double * red_d,
-                         float (*part)[64 / S], float * snew, [[maybe_unused]] unsigned long long (&stamp)[3]) {
-    constexpr int P = 1024, DS = 64 / S, NW = 16 * DS / 64, NKW = 4 * NG;      // mix waves, waves that own keys
+constexpr int SNEW_WAVE = 3;                                    // last wave of the first key group: owns keys in every context, never mixes
+__global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict__ ps, const float * __restrict__ vt, const StepState * __restrict__ st,
+                                                      const float * __restrict__ knew, const float * __restrict__ q, const int H, const int ng, const AttnDecodeArgs a) {
+    TRACE_T0();
+    TRACE_T1(H);
+    constexpr int P = 1024, S = 16, DS = 4;                        // 16 value slices per head = the d-quads of the K-layout copy of V
+    __shared__ __attribute__((aligned(16))) float vl[1024 * DS];     // V slice of the head: [key][4 dims]
+    __shared__ float es[1024];
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    __shared__ float part[16][DS];
+    __shared__ float snew;
+    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // slices of a head get ids congruent mod 8 (same XCD), as attn_dslice_kernel
+    const int h = x8 + 8 * (g8 / S), s = g8 % S;
+    if (h >= H) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave >= NKW) return;                                    // static bound: these waves own no key of this context
-    // every stream below is a buffer load: wave-uniform base + 32-bit lane offset + scalar offset (device_utils.h)
-    const float4 p4 = buf_ld_f4(buf_rsrc(reinterpret_cast<const float4 *>(a.ps) + (size_t) h * P), (unsigned) tid * 16u, 0u);
-    // value slice: chain = key mod 16, DS dims per chain
-    const int chain = tid / DS, d = tid % DS;                   // mix threads: tid < 16 * DS
-    float vv[16 * NG];
-    if (wave < NW) {
-        const BufRsrc vr = buf_rsrc(a.vc + (size_t) h * P * 64 + DS * s);
-        const unsigned voff = (unsigned) (chain * 64 + d) * 4u;
-        #pragma unroll
-        for (int i = 0; i < 16 * NG; i++) vv[i] = buf_ld_f32(vr, voff, (unsigned) i * 4096u);      // key chain + 16 i: 16 rows of 256 bytes further
-    }
-    // the key this step appended (position ctx - 1): lanes 0..3 of the last key wave form its four C2 blocks
+    // every stream is a buffer load: uniform base + lane offset + scalar offset (device_utils.h).  The keys below 256 ng (the launch's
+    // bound on the context, a preloaded argument) are requested at once; should the context be longer, the others follow once its
+    // length has arrived from the device-resident state.
+    const BufRsrc pr = buf_rsrc(reinterpret_cast<const float4 *>(ps) + (size_t) h * P);
+    const BufRsrc vr = buf_rsrc(reinterpret_cast<const float4 *>(vt) + ((size_t) h * 16 + s) * P);      // quad s of every key: contiguous
+    float4 p4 = {0.0f, 0.0f, 0.0f, 0.0f}, va = p4;
     float s_new = -INFINITY;
-    if (wave == NKW - 1) {
+    if (wave < 4 * ng) {
+        p4 = buf_ld_f4(pr, (unsigned) tid * 16u, 0u);
+        va = buf_ld_f4(vr, (unsigned) tid * 16u, 0u);
+    }
+    if (wave == SNEW_WAVE) {
+        // lanes 0..3 form the four C2 blocks of the newest key's score
         const int b = lane & 3;
-        const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + (ctx - 1));
-        const BufRsrc qr = buf_rsrc(a.q + h * 64);
+        const BufRsrc kr = buf_rsrc(knew + h * 64), qr = buf_rsrc(q + h * 64);
         float4 kq[4], q4[4];
         #pragma unroll
-        for (int i = 0; i < 4; i++) { kq[i] = buf_ld_f4(kr, (unsigned) (4 * b) * (P * 16u), (unsigned) i * (P * 16u)); q4[i] = buf_ld_f4(qr, (unsigned) b * 64u, (unsigned) i * 16u); }
+        for (int i = 0; i < 4; i++) { kq[i] = buf_ld_f4(kr, (unsigned) b * 64u, (unsigned) i * 16u); q4[i] = buf_ld_f4(qr, (unsigned) b * 64u, (unsigned) i * 16u); }
         const float qb[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
                               q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
         const float cb = score_block_f4(kq, qb);
         const float c0 = readlane_f32(cb, 0), c1 = readlane_f32(cb, 1), c2 = readlane_f32(cb, 2), c3 = readlane_f32(cb, 3);
         s_new = ((c0 + c1) + (c2 + c3)) * 0.125f;               // 1/sqrt(64), bark.cpp:1318
     }
+    const int ctx = st->n_past + 1;
+    if (wave >= 4 * ng && wave * 64 < ctx) {
+        p4 = buf_ld_f4(pr, (unsigned) tid * 16u, 0u);
+        va = buf_ld_f4(vr, (unsigned) tid * 16u, 0u);
+    }
     float sc = -INFINITY;
     if (tid < ctx - 1) sc = ((p4.x + p4.y) + (p4.z + p4.w)) * 0.125f;
-    TRACE_SET(stamp[0], sc);
+    *reinterpret_cast<float4 *>(vl + tid * DS) = va;
+    [[maybe_unused]] unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;     // diagnostic build: score ready, softmax statistics ready, mix done
+    TRACE_SET(stamp0, sc);
     float mx = fmaxf(wave_max(sc), s_new);
-    if (lane == 0) { red_f[wave] = mx; if (wave == NKW - 1) *snew = s_new; }
+    if (lane == 0) { red_f[wave] = mx; if (wave == SNEW_WAVE) snew = s_new; }
     __syncthreads();
     mx = red_f[0];
     #pragma unroll
-    for (int i = 1; i < NKW; i++) mx = fmaxf(mx, red_f[i]);
-    if (tid == ctx - 1) sc = *snew;
+    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
+    if (tid == ctx - 1) sc = snew;
     float e = 0.0f;
     if (tid < ctx) e = (float) exp((double) (sc - mx));
     es[tid] = e;
     const double wsum = wave_sum((double) e);
     if (lane == 0) red_d[wave] = wsum;
     __syncthreads();
-    TRACE_SET(stamp[1], e);
-    if (wave >= NW) return;
-    double sum = 0.0;                                           // fixed order: ascending waves
-    #pragma unroll
-    for (int i = 0; i < NKW; i++) sum += red_d[i];
-    const float inv = (float) (1.0 / sum);
-    // C5: groups below the last are complete (ctx > 256 (NG - 1)): plain chains; the last group drops masked terms by select
-    float acc = 0.0f;
-    #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        float pj[16];
+    TRACE_SET(stamp1, e);
+    if (tid < 16 * DS) {                                        // whole waves: 64 or 128 mix threads
+        double sum = 0.0;                                       // fixed order: ascending waves
         #pragma unroll
-        for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
-        #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float t = fmaf(vv[16 * g + i], pj[i], acc);
-            acc = (g < NG - 1 || chain + 16 * (16 * g + i) < ctx) ? t : acc;
+        for (int i = 0; i < 16; i++) sum += red_d[i];
+        const float inv = (float) (1.0 / sum);
+        // C5: chain = key mod 16 walks its keys in ascending order; keys below 16 * (ctx / 16) exist for every chain
+        const int chain = tid / DS, d = tid % DS;
+        const float * vp = vl + chain * DS + d, * ep = es + chain;
+        float acc = 0.0f;
+        const int n_full = ctx >> 4;
+        int i = 0;
+        for (; i + 8 <= n_full; i += 8) {
+            float v[8], p[8];
+            #pragma unroll
+            for (int u = 0; u < 8; u++) { v[u] = vp[(i + u) * 16 * DS]; p[u] = ep[(i + u) * 16] * inv; }    // p = e * (float)(1/sum), as ggml_soft_max scales in place
+            #pragma unroll
+            for (int u = 0; u < 8; u++) acc = fmaf(v[u], p[u], acc);
         }
+        for (; i < n_full; i++) acc = fmaf(vp[i * 16 * DS], ep[i * 16] * inv, acc);
+        if (chain + 16 * n_full < ctx) acc = fmaf(vp[n_full * 16 * DS], ep[n_full * 16] * inv, acc);
+        TRACE_SET(stamp2, acc);
+        part[chain][d] = acc;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
     }
-    TRACE_SET(stamp[2], acc);
-    part[chain][d] = acc;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0); the mix waves meet without the waves that have left
-    asm volatile("s_barrier" ::: "memory");
+    __syncthreads();
     if (tid < DS) {
         float p[16];
         #pragma unroll
         for (int c = 0; c < 16; c++) p[c] = part[c][tid];
         #pragma unroll
-        for (int st = 1; st < 16; st <<= 1)
+        for (int st2 = 1; st2 < 16; st2 <<= 1)
             #pragma unroll
-            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+            for (int c = 0; c < 16; c += 2 * st2) p[c] = p[c] + p[c + st2];
         const int o = h * 64 + DS * s + tid;
         if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
     }
-}
-
-template <int S>
-__global__ __launch_bounds__(1024) void attn_ps_kernel(const AttnDecodeArgs a) {
-    TRACE_T0();
-    TRACE_T1(a.H);
-    __shared__ float es[1024];
-    __shared__ float red_f[16];
-    __shared__ double red_d[16];
-    __shared__ float part[16][64 / S];
-    __shared__ float snew;
-    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // slices of a head get ids congruent mod 8 (same XCD), as attn_dslice_kernel
-    const int h = x8 + 8 * (g8 / S), s = g8 % S;
-    if (h >= a.H) return;
-    const int ctx = a.st->n_past + 1;
-    unsigned long long stamp[3] = {0, 0, 0};                     // diagnostic build: score ready, softmax statistics ready, mix done
-    switch ((ctx + 255) >> 8) {
-        case 1:  attn_ps_body<S, 1>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
-        case 2:  attn_ps_body<S, 2>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
-        case 3:  attn_ps_body<S, 3>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
-        default: attn_ps_body<S, 4>(a, h, s, ctx, es, red_f, red_d, part, &snew, stamp); break;
-    }
 #ifdef BARK_TRACE
-    trace_emit(a.tr, _tr0, _tr1, stamp[2], trace_clock(), stamp[0], stamp[1]);
+    trace_emit(a.tr, _tr0, _tr1, stamp2, trace_clock(), stamp0, stamp1);
 #endif
 }
 
@@ -538,8 +540,9 @@ void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts)
     }
     if (parts == 8 || parts == 9) {
         if (a.nbatch != 1 || a.P != 1024 || !a.ps) { kernel_fail("bark-hip: partial-score decode attention needs one sequence, block_size 1024 and the QKV kernel's partials"); }
-        if (parts == 8) hipLaunchKernelGGL(attn_ps_kernel<4>, dim3(8 * 4 * ((a.H + 7) / 8)), dim3(1024), 0, s, a);
-        else            hipLaunchKernelGGL(attn_ps_kernel<8>, dim3(8 * 8 * ((a.H + 7) / 8)), dim3(1024), 0, s, a);
+        if (!a.knew) kernel_fail("bark-hip: partial-score decode attention needs the fixed-address copy of the appended K row");
+        if (!a.vt) kernel_fail("bark-hip: partial-score decode attention needs the K-layout copy of V");
+        hipLaunchKernelGGL(attn_ps_kernel, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
         return;
     }
     if (parts == 6 || parts == 7) {
@@ -560,7 +563,7 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
     const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
     // BARK_HIP_ATTN_MODE (A/B timing): 5 value-sliced 256-thread kernel, 6 wide fused kernel, 7 key scores + wide mix (two launches)
-    // 8 / 9: attention on the QKV kernel's partial scores, 4 / 8 value slices per head (needs a.ps)
+    // 9: attention on the QKV kernel's partial scores, 8 value slices per head (needs a.ps)
     static const int mode = getenv("BARK_HIP_ATTN_MODE") ? atoi(getenv("BARK_HIP_ATTN_MODE")) : 6;
     static const int ps_mode = getenv("BARK_HIP_ATTN_PS") ? atoi(getenv("BARK_HIP_ATTN_PS")) : 9;
     if (can_split && a.ps && ps_mode) { launch_attn_decode_part(s, a, ps_mode); return; }

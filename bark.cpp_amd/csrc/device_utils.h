@@ -204,7 +204,8 @@ DEVINL void linear_epilogue_pre(const LinArgs & a, int n, int m, float dot, cons
             const size_t slot = a.batched ? (size_t) n * a.kv_slot_stride : 0;
             const int mm = m < 2 * E ? m - E : m - 2 * E;
             const int h = mm >> 6, d = mm & 63;
-            if (m < 2 * E) a.kc[slot + kc_index(h, d, pos, a.P)] = v; else a.vc[slot + vc_index(h, d, pos, a.P)] = v;
+            if (m < 2 * E) { a.kc[slot + kc_index(h, d, pos, a.P)] = v; if (a.knew) a.knew[mm] = v; }
+            else { a.vc[slot + vc_index(h, d, pos, a.P)] = v; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v; }
             break;
         }
         case EPI_RESID: a.res[(size_t) n * a.M + m] = v + p.res; break;                          // cur + inpL (bark.cpp:1352,1388)
@@ -226,7 +227,7 @@ DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_
             const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
             const int mm = m < 2 * E ? m - E : m - 2 * E;
             const int h = mm >> 6, d = mm & 63;
-            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else a.vc[vc_index(h, d, pos, a.P)] = v;
+            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else { a.vc[vc_index(h, d, pos, a.P)] = v; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v; }
             break;
         }
         case EPI_RESID: { float * r = a.res + (size_t) n * a.M + m; *r = v + *r; break; }       // cur + inpL (bark.cpp:1352,1388)

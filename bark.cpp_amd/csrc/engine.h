@@ -36,9 +36,13 @@ struct GptModel {
     };
     std::vector<Layer> layers;
     float * kcache = nullptr, * vcache = nullptr;       // [L][H][16][P][4] / [L][H][P][64] f32; fine model: L = 1 scratch
+    float * vtcache = nullptr;                          // second copy of V in the K layout [L][H][16][P][4] (semantic / coarse): the decode attention
+                                                        // reads 4 value dims of consecutive keys as one contiguous stream
     size_t kv_layer_stride = 0;                         // floats per layer (0 for the fine model's shared scratch)
-    hipGraphExec_t decode_graph = nullptr;              // layers -> LM head -> sample + embedding of the next token
-    hipGraphExec_t decode_graph8 = nullptr;             // eight such steps in one graph: one launch gap (6.5 us) per eight tokens
+    // layers -> LM head -> sample + embedding of the next token; [ng]: variant whose kernels request the keys below 256 ng without
+    // waiting for the context length (the host knows how many rows the cache holds when it launches a step)
+    hipGraphExec_t decode_graph[5] = {};
+    hipGraphExec_t decode_graph8[5] = {};               // eight such steps in one graph: one launch gap per eight tokens
     hipGraphExec_t bench_graph = nullptr;               // same, without advancing n_past (timing hook)
 };
 
@@ -68,6 +72,7 @@ struct bark_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool use_graph = true;
+    int decode_ng = 4;                                  // key groups (of 256) the decode kernels being enqueued may assume: ctx <= 256 ng
 
     // device memory.  The weight slab (and the codec codebooks) are immutable after load and shared by every
     // context cloned from this one (bark_hip_clone_context): replicas on one GPU stream the same bytes.
@@ -77,6 +82,7 @@ struct bark_context {
     std::vector<void *> allocs;                         // everything else (freed in destroy)
     // GPT scratch
     float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
+    float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)
     float * ps = nullptr;                               // [H][P][4] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each

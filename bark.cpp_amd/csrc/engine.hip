@@ -32,6 +32,7 @@ double weight_bytes_per_element(const GptModel & m) {
 }
 float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride * (size_t) l; }
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
+float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.kv_layer_stride * (size_t) l : nullptr; }
 
 // N > 1 rows through all layers (bark.cpp:1261-1389 causal, :1474-1562 fine); x holds the embeddings.
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0) {
@@ -49,6 +50,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
+        if (!kbase && !vbase) a.vt = detail::layer_vt(m, l);      // the context's own cache keeps the K-layout copy of V too
         launch_linear(s, a);
         AttnPrefillArgs at;
         at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
@@ -81,18 +83,18 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
-        a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
+        a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.vt = layer_vt(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
         static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
-        const bool ps = use_ps && !m.q4 && P == 1024;
-        if (ps) a.ps = c->ps;
-        BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 3 * (E / 4));
+        const bool ps = use_ps && !m.q4 && P == 1024 && m.vtcache;
+        if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
+        BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 3 * (E / 4));        // room for all three copies of the q workgroups
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
         at.att32 = m.q4 ? c->att32 : nullptr;
-        if (ps) at.ps = c->ps;
-        BARK_TRACE_SET(c, at, 8 * 8 * ((H + 7) / 8) * 16);       // up to 8 slices per head, 16 waves per workgroup
+        if (ps) { at.ps = c->ps; at.knew = c->knew; at.ng = c->decode_ng; at.vt = layer_vt(m, l); }
+        BARK_TRACE_SET(c, at, 8 * 16 * ((H + 7) / 8) * 16);      // up to 16 slices per head, 16 waves per workgroup
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = c->att32; else p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
@@ -207,42 +209,45 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
     if (sample) run_sample(c, s, n_past_add, prescale);
 }
 
-hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps) {
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps, int ng) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    const int ng_saved = c->decode_ng;
+    c->decode_ng = std::max(1, std::min(ng, 4));
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     try { for (int i = 0; i < n_steps; i++) enqueue_decode_step(c, s, true, n_past_add, false); }
-    catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+    catch (...) { c->decode_ng = ng_saved; hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+    c->decode_ng = ng_saved;
     HIP_OK(hipStreamEndCapture(c->stream, &graph));
     HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     (void) hipGraphDestroy(graph);
     return exec;
 }
 
-void decode_step_greedy(bark_context * c, const StageCfg & s) {
-    GptModel & m = c->gpt[s.which];
-    if (c->use_graph) {
-        if (!m.decode_graph) m.decode_graph = capture_decode(c, s, 1);
-        HIP_OK(hipGraphLaunch(m.decode_graph, c->stream));
-        c->stats.graph_replays++;
-    } else {
-        enqueue_decode_step(c, s, true, 1, false);
-    }
-}
-
-// n consecutive decode steps.  Between two graph launches the GPU idles ~6.5 us (in-kernel time line, tools/trace_decode.py) against
-// ~1.3 us between two kernels of one graph, so runs of steps are replayed from an eight-step graph (the state lives on the device:
-// a step needs nothing from the host) and only the remainder from the one-step graph.
-void decode_steps_greedy(bark_context * c, const StageCfg & s, int n) {
+// n consecutive decode steps; the cache holds n_past rows before the first of them (step k then attends over n_past + k + 1 keys).
+// Between two graph launches the GPU idles longer than between two kernels of one graph, so runs of steps are replayed from an
+// eight-step graph (the state lives on the device: a step needs nothing from the host) and the remainder from the one-step graph.
+// The graph variant is picked by the number of 256-key groups the launch can touch: its kernels request those keys' partial scores
+// and value rows at wave launch instead of waiting ~0.5 us for the context length to arrive from the device-resident state.
+void decode_steps_greedy(bark_context * c, const StageCfg & s, int n, int n_past) {
     GptModel & m = c->gpt[s.which];
     static const bool multi = !getenv("BARK_HIP_GRAPH_STEPS") || atoi(getenv("BARK_HIP_GRAPH_STEPS")) > 1;
-    while (c->use_graph && multi && n >= 8) {
-        if (!m.decode_graph8) m.decode_graph8 = capture_decode(c, s, 1, 8);
-        HIP_OK(hipGraphLaunch(m.decode_graph8, c->stream));
-        c->stats.graph_replays++;
-        n -= 8;
+    static const bool bucketed = !getenv("BARK_HIP_NG_BUCKETS") || atoi(getenv("BARK_HIP_NG_BUCKETS")) != 0;
+    if (!c->use_graph) {
+        for (int k = 0; k < n; k++) { c->decode_ng = bucketed ? std::min(4, (n_past + k + 256) / 256) : 4; enqueue_decode_step(c, s, true, 1, false); }
+        c->decode_ng = 4;
+        return;
     }
-    for (; n > 0; n--) decode_step_greedy(c, s);
+    int k = 0;
+    while (k < n) {
+        const int g = (multi && n - k >= 8) ? 8 : 1;
+        const int ng = bucketed ? std::min(4, (n_past + k + g + 255) / 256) : 4;      // ctx of the last step of this launch = n_past + k + g
+        hipGraphExec_t & e = g == 8 ? m.decode_graph8[ng] : m.decode_graph[ng];
+        if (!e) e = capture_decode(c, s, 1, g, ng);
+        HIP_OK(hipGraphLaunch(e, c->stream));
+        c->stats.graph_replays++;
+        k += g;
+    }
 }
 
 // ---- host-side sampling (temp > 0, or settling a near tie): bark.cpp:184-270 -------------------------
@@ -390,7 +395,7 @@ std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t
         StepState cur{};
         while (true) {
             const int batch_end = std::min(n_steps, issued + 32);
-            decode_steps_greedy(c, s, batch_end - issued);
+            decode_steps_greedy(c, s, batch_end - issued, N + issued - 1);
             for (; issued < batch_end; issued++) progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder));
             cur = get_state(c);                                        // poll the stop rule every 32 steps
             if (cur.eos_step != INT32_MAX || issued >= n_steps) break;
@@ -483,7 +488,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
             EmbedArgs e;
             e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
             launch_embed_causal(c->stream, e);
-            decode_step_greedy(c, s);
+            decode_steps_greedy(c, s, 1, L);
             c->stats.n_prefix_rows_reused += L;
         } else {
             upload_tokens(c, in.data() + L, (size_t) rows);
@@ -496,7 +501,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
                 run_sample(c, s, rows);
             }
             progress(c, COARSE, 100 * (step_idx + 1) / n_steps);
-            decode_steps_greedy(c, s, steps_here - 1);
+            decode_steps_greedy(c, s, steps_here - 1, N);
             for (int j = 1; j < steps_here; j++) progress(c, COARSE, 100 * (step_idx + j + 1) / n_steps);
             const StepState cur = get_state(c);
             std::vector<int32_t> got((size_t) steps_here);

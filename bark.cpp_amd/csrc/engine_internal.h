@@ -51,6 +51,7 @@ inline QMat q4_rows(const QMat & w, size_t row0, int K) {
 double weight_bytes_per_element(const GptModel & m);
 float * layer_k(const GptModel & m, int l);
 float * layer_v(const GptModel & m, int l);
+float * layer_vt(const GptModel & m, int l);
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0);
 void run_layers_decode(bark_context * c, GptModel & m);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
@@ -66,9 +67,8 @@ struct StageCfg {            // what differs between the semantic and the coarse
 StageCfg stage_cfg(bark_context * c, int which);
 void run_sample(bark_context * c, const StageCfg & s, int n_past_add, bool prescaled = false);
 void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int n_past_add, bool embed = true);
-hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps = 1);
-void decode_step_greedy(bark_context * c, const StageCfg & s);
-void decode_steps_greedy(bark_context * c, const StageCfg & s, int n);
+hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_add, int n_steps = 1, int ng = 4);
+void decode_steps_greedy(bark_context * c, const StageCfg & s, int n, int n_past);
 int sample_host(std::vector<float> & l, std::mt19937 & rng, float temp, float * eos_p);
 std::vector<float> fetch_logits(bark_context * c, size_t n);
 void upload_uniforms(bark_context * c, int n);

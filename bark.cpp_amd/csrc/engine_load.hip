@@ -78,8 +78,8 @@ float gelu_tanh_host(float x) {
 bark_context::~bark_context() {
     (void) hipSetDevice(device);
     for (auto & g : gpt) {
-        if (g.decode_graph) (void) hipGraphExecDestroy(g.decode_graph);
-        if (g.decode_graph8) (void) hipGraphExecDestroy(g.decode_graph8);
+        for (auto & e : g.decode_graph) if (e) (void) hipGraphExecDestroy(e);
+        for (auto & e : g.decode_graph8) if (e) (void) hipGraphExecDestroy(e);
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
@@ -101,8 +101,8 @@ void engine_invalidate_graphs(bark_context * ctx) {
     for (auto & g : ctx->batch.graph) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
     for (auto & g : ctx->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
     for (auto & g : ctx->gpt) {
-        if (g.decode_graph) { (void) hipGraphExecDestroy(g.decode_graph); g.decode_graph = nullptr; }
-        if (g.decode_graph8) { (void) hipGraphExecDestroy(g.decode_graph8); g.decode_graph8 = nullptr; }
+        for (auto & e : g.decode_graph) if (e) { (void) hipGraphExecDestroy(e); e = nullptr; }
+        for (auto & e : g.decode_graph8) if (e) { (void) hipGraphExecDestroy(e); e = nullptr; }
         if (g.bench_graph) { (void) hipGraphExecDestroy(g.bench_graph); g.bench_graph = nullptr; }
     }
 }
@@ -117,6 +117,7 @@ static void init_runtime(bark_context * ctxp) {
         m.kv_layer_stride = (size_t) m.hp.n_embd * P;
         m.kcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);     // bark.cpp:976-991
         m.vcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);
+        m.vtcache = dev_alloc<float>(ctx.get(), m.kv_layer_stride * m.hp.n_layer);
     }
     {
         GptModel & m = ctx->gpt[2];
@@ -132,6 +133,7 @@ static void init_runtime(bark_context * ctxp) {
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
     ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
     ctx->ps = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * 4);
+    ctx->knew = dev_alloc<float>(ctx.get(), (size_t) ctx->max_E);
     HIP_OK(hipMemset(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float)));
     if (ctx->any_q4) {
         ctx->att32 = dev_alloc<float>(ctx.get(), NE);
@@ -438,8 +440,10 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     ctx->vocab = src->vocab;
     for (int g = 0; g < 3; g++) {
         ctx->gpt[g] = src->gpt[g];
-        ctx->gpt[g].kcache = ctx->gpt[g].vcache = nullptr;
-        ctx->gpt[g].decode_graph = ctx->gpt[g].decode_graph8 = ctx->gpt[g].bench_graph = nullptr;
+        ctx->gpt[g].kcache = ctx->gpt[g].vcache = ctx->gpt[g].vtcache = nullptr;
+        for (auto & e : ctx->gpt[g].decode_graph) e = nullptr;
+        for (auto & e : ctx->gpt[g].decode_graph8) e = nullptr;
+        ctx->gpt[g].bench_graph = nullptr;
     }
     ctx->codec = src->codec;
     ctx->device = src->device; ctx->use_graph = src->use_graph;

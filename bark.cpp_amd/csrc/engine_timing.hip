@@ -30,9 +30,11 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     // but keep them finite: zero them once
     HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     // the graph the stage loops replay: eight steps per launch (BARK_HIP_GRAPH_STEPS=1: one); n_past does not advance here
     static const int per_graph = (getenv("BARK_HIP_GRAPH_STEPS") && atoi(getenv("BARK_HIP_GRAPH_STEPS")) <= 1) ? 1 : 8;
-    if (!m.bench_graph) m.bench_graph = capture_decode(c, s, 0, per_graph);
+    if (m.bench_graph) { (void) hipGraphExecDestroy(m.bench_graph); m.bench_graph = nullptr; }     // the variant depends on the context length
+    m.bench_graph = capture_decode(c, s, 0, per_graph, (ctxlen + 255) / 256);
     for (int i = 0; i < 3; i++) HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
     set_state(c, st);
     iters = std::max(1, iters / per_graph) * per_graph;
@@ -74,6 +76,8 @@ double engine_time_gemv(bark_context * c, int which, int op, int iters, double *
     if (attn) {
         HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
         HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+        if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
         HIP_OK(hipMemsetAsync(c->q, 0, (size_t) E * 4, c->stream));
     }
     HIP_OK(hipMemsetAsync(c->x, 0, (size_t) E * 4, c->stream));
@@ -140,18 +144,19 @@ int engine_trace_decode_step(bark_context * c, int which, int ctxlen, int replay
     StepState st = fresh_state(); st.n_past = ctxlen - 1; st.cur_token = 1;
     set_state(c, st);
     if (!c->trace_rec) {
-        c->trace_cap = 1u << 18;
+        c->trace_cap = 1u << 19;
         c->trace_rec = dev_alloc<unsigned long long>(c, (size_t) c->trace_cap * 8);
         c->trace_pos = dev_alloc<unsigned>(c, 1);
     }
     HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
+    if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     // first capture counts the waves of a step, the second bakes the per-replay stride into the kernels' arguments
     c->trace_kid = 0; c->trace_base = 0; c->trace_per_replay = 0;
-    hipGraphExec_t g = capture_decode(c, s, 0);
+    hipGraphExec_t g = capture_decode(c, s, 0, 1, (ctxlen + 255) / 256);
     (void) hipGraphExecDestroy(g);
     c->trace_per_replay = c->trace_base; c->trace_kid = 0; c->trace_base = 0;
-    g = capture_decode(c, s, 0);
+    g = capture_decode(c, s, 0, 1, (ctxlen + 255) / 256);
     HIP_OK(hipMemsetAsync(c->trace_rec, 0, (size_t) c->trace_cap * 8 * sizeof(unsigned long long), c->stream));
     for (int i = 0; i < 5; i++) { HIP_OK(hipMemsetAsync(c->trace_pos, 0, sizeof(unsigned), c->stream)); HIP_OK(hipGraphLaunch(g, c->stream)); }
     HIP_OK(hipStreamSynchronize(c->stream));

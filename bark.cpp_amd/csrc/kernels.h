@@ -71,6 +71,7 @@ struct LinArgs {
     int epi = EPI_LOGITS;
     // EPI_QKV: m < E -> q ; E <= m < 2E -> K cache ; else V cache, at position pos0 (+ st->n_past) + n
     float * q = nullptr; float * kc = nullptr; float * vc = nullptr; int E = 0, P = 0; int pos0 = 0;
+    float * vt = nullptr;                 // optional second V store in the K layout [H][16][P][4] (read by attn_ps_kernel)
     const StepState * st = nullptr;
     // EPI_RESID: res[n][m] = (dot + bias) + res[n][m]
     float * res = nullptr;
@@ -81,7 +82,9 @@ struct LinArgs {
     float * out = nullptr; int ld_out = 0;
     // EPI_QKV, decode, f16 weights: the workgroup that produces 16 consecutive q values (one C2 block of one head) also forms that
     // block's partial score against every cached key: ps[(h * P + j) * 4 + block], j < n_past (attn_ps_kernel finishes the sum)
-    float * ps = nullptr;
+    float * ps = nullptr; int ng = 4;     // ng: the context holds at most 256 ng keys (only ng - 1 copies of the q workgroups are launched)
+    float * knew = nullptr;               // with ps: the appended K row is also stored here ([E], position independent), so that the attention kernel
+                                          // can request it before it knows the context length
     float out_div = 0.0f;                 // != 0: out = (dot + bias) / out_div - the sampler's `l /= 0.7f` (bark.cpp:226-228) done where the logit is born
     // coarse LM head: only the 1024 logits of the active codebook are needed (bark.cpp:1829-1833);
     // the row window starts at parity_rows * (st->step & 1) rows into W (and bias)
@@ -120,6 +123,9 @@ struct AttnDecodeArgs {
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32
     float * scores = nullptr;             // scratch [H][P]
+    const float * vt = nullptr;           // V in the K layout [H][16][P][4] (attn_ps_kernel)
+    int ng = 4;                           // the context holds at most 256 ng keys: those keys are requested at wave launch
+    const float * knew = nullptr;         // [E] the K row this step appended (copy at a fixed address, see LinArgs::knew)
     const float * ps = nullptr;           // [H][P][4] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches

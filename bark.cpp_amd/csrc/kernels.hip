@@ -13,6 +13,7 @@
 // attention), misc_kernels.hip (embeddings, LayerNorm rows, sampling), codec_kernels.hip (EnCodec decoder).
 #include "device_utils.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdarg>
 #include <cstdio>
@@ -39,18 +40,22 @@ void kernel_fail(const char * fmt, ...) {
 // NBLK = K / 128 is a compile-time constant so that every load of a lane (weights, x, LayerNorm
 // parameters) is issued up front with no control flow in between: the kernel is one memory round
 // trip deep.  One wave per workgroup (4 output rows) spreads the rows over as many CUs as possible.
+// The operands the first loads need (weight / input pointers, row count, row window) are explicit leading kernel parameters: built
+// with -amdgpu-kernarg-preload-count the hardware delivers them in SGPRs at wave launch, so the weight stream is requested without
+// the ~0.2 us kernel-argument round trip the in-kernel time line shows in front of every kernel; the struct carries the rest.
 template <int NBLK, bool LN, bool LNB>
-__global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
+__global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W, const half_t * __restrict__ x_f16, const int M, const int parity_rows, const LinArgs a) {
     TRACE_T0();
-    TRACE_T1(a.M);
+    TRACE_T1(M);
     const int lane = threadIdx.x;
     const int c = lane & 15, rg = lane >> 4;
     const int m = blockIdx.x * 4 + rg;
     constexpr int K = NBLK * 128;
-    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
-    const bool live = m < a.M;                              // whole 16-lane groups are live or dead together
-    const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
-    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < M;                                // whole 16-lane groups are live or dead together
+    const half_t * wrow = W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    [[maybe_unused]] EpiPre pre{};
+    if constexpr (LN) pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     float acc = 0.0f;
 
     if constexpr (LN) {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
             }
         }
     } else {
-        const half_t * xrow = a.x_f16 + (c << 3);
+        const half_t * xrow = x_f16 + (c << 3);
         // every chunk of the row is requested before the first fmaf (up to 2 x 32 x 16 bytes per lane: a one-wave workgroup may
         // use all 512 registers).  The chain of a lane is K / 16 dependent fmaf long whatever the load schedule; with batches of
         // 8 chunks the K = 3072 product paid two more exposed memory round trips (1.8 us between "arguments ready" and "dot done").
@@ -114,6 +119,8 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
         half8 wv[2][G], xv[2][G];
         #pragma unroll
         for (int i = 0; i < G; i++) { wv[0][i] = ld_half8(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
+        __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
+        pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
         #pragma unroll
         for (int g = 0; g < NBLK / G; g++) {
             if (g + 1 < NBLK / G) {
@@ -149,10 +156,14 @@ __global__ __launch_bounds__(64) void gemv_kernel(const LinArgs a) {
 // score as four such blocks, so this workgroup can form its block's partial score against every cached key right here, where q is
 // born: the K stream of the attention (the per-CU bandwidth bound of every fused decode-attention kernel tried) is spread over the
 // 4 H q-workgroups of this launch, 64 bytes per key each, requested together with the weights.
+// Leading parameters = what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel): every stream of this kernel -
+// weights, the f32 row, LayerNorm parameters, the K quads of the partial scores - is requested before the argument struct is read.
 template <int NBLK, bool LNB, bool PS>
-__global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
+__global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restrict__ W, const float * __restrict__ x_f32, const float * __restrict__ ln_g,
+                                                         const float * __restrict__ ln_b, const float * __restrict__ kc, const int M, const int parity_rows,
+                                                         const int E, const LinArgs a) {
     TRACE_T0();
-    TRACE_T1(a.M);
+    TRACE_T1(M);
     constexpr int K = NBLK * 128;
     constexpr int EPT = (K + 255) / 256;                     // row elements per thread
     __shared__ __attribute__((aligned(16))) half_t xs[K];
@@ -162,24 +173,24 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     // PS: the grid carries three more copies of the q workgroups (ids behind the M / 16 main ones).  Copy r repeats the LayerNorm and
     // the 16 q rows (weights come from L2) and scores the keys 256 r .. 256 r + 255 only, so no workgroup pulls more than 16 KB of K;
     // it writes nothing but partial scores.
-    [[maybe_unused]] const int n_main = (a.M + 15) >> 4, n_q = a.E >> 4;
+    [[maybe_unused]] const int n_main = (M + 15) >> 4, n_q = E >> 4;
     [[maybe_unused]] const int rep = PS && (int) blockIdx.x >= n_main ? 1 + ((int) blockIdx.x - n_main) / n_q : 0;
     const int wg = PS && rep ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
     const int m = (wg * 4 + wave) * 4 + rg;
-    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
-    const bool live = m < a.M;
-    const half_t * wrow = a.W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
+    const bool live = m < M;
+    const half_t * wrow = W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
     half8 wv[NBLK];
     #pragma unroll
     for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
     // partial scores: key 256 rep + tid; d-quads 4 blk .. 4 blk + 3 of head hq
     [[maybe_unused]] float4 kq[4];
     [[maybe_unused]] const int m0 = wg * 16;
-    [[maybe_unused]] const bool is_q = PS && m0 < a.E;
+    [[maybe_unused]] const bool is_q = PS && m0 < E;
     [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
     if constexpr (PS) {
         if (is_q) {
-            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(a.kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + 256 * rep);     // PS implies P == 1024
+            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + 256 * rep);     // PS implies P == 1024
             #pragma unroll
             for (int i = 0; i < 4; i++) kq[i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);    // rows beyond n_past hold stale bits; their scores are not stored
         }
@@ -189,10 +200,11 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const LinArgs a) {
     for (int i = 0; i < EPT; i++) {
         const int e = tid + 256 * i;
         const bool ok = (K % 256 == 0) || e < K;
-        xv[i] = ok ? a.x_f32[e] : 0.0f;
-        gv[i] = ok ? a.ln_g[e] : 0.0f;
-        if constexpr (LNB) bv[i] = ok ? a.ln_b[e] : 0.0f; else bv[i] = 0.0f;
+        xv[i] = ok ? x_f32[e] : 0.0f;
+        gv[i] = ok ? ln_g[e] : 0.0f;
+        if constexpr (LNB) bv[i] = ok ? ln_b[e] : 0.0f; else bv[i] = 0.0f;
     }
+    __builtin_amdgcn_sched_barrier(0);                        // everything above goes out on the preloaded arguments alone
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     if constexpr (PS) { if (rep && pre.n_past <= 256 * rep) return; }      // uniform: this copy's keys are not in the context yet
     double s1 = 0.0;
@@ -252,19 +264,20 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
             static const bool one_wave = getenv("BARK_HIP_LN_ONE_WAVE") != nullptr;       // A/B: every wave normalises the row itself
             if (!one_wave) {
                 const dim3 g16((a.M + 15) / 16), b256(256);
+                const float * kc = a.kc;
                 if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
-                    const dim3 gps((a.M + 15) / 16 + 3 * (a.E / 16));      // + three copies of the q workgroups (keys 256.., 512.., 768..)
-                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a);
-                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a);
+                    const dim3 gps((a.M + 15) / 16 + (std::max(1, std::min(a.ng, 4)) - 1) * (a.E / 16));      // + one copy of the q workgroups per further 256 keys the context may hold
+                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
+                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
                 }
-                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a);
-                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a);
+                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
+                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
             }
-            else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a);
-            else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a);
+            else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+            else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
         } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
     } else {
-        hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
     }
 }
 
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
                 const int m2 = m < 2 * E ? m - E : m - 2 * E;
                 const int h = m2 >> 6, d = m2 & 63;                     // d is a multiple of 4: one d-quad of the K layout
                 if (m < 2 * E) *reinterpret_cast<float4 *>(a.kc + kc_index(h, d, pos, a.P)) = o;
-                else           *reinterpret_cast<float4 *>(a.vc + vc_index(h, d, pos, a.P)) = o;
+                else         { *reinterpret_cast<float4 *>(a.vc + vc_index(h, d, pos, a.P)) = o; if (a.vt) *reinterpret_cast<float4 *>(a.vt + kc_index(h, d, pos, a.P)) = o; }
                 break;
             }
             case EPI_RESID: {                                           // cur + inpL (bark.cpp:1352,1388)

@@ -153,9 +153,10 @@ constexpr float kTieCut = -2.98023223876953125e-08f;     // -2^-25
 constexpr float kNearTie = -4.0e-7f;
 constexpr float kEosBand = 2.0e-3f;
 
-__global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a) {
+// leading parameters: what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel in kernels.hip)
+__global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __restrict__ logits0, StepState * st0, const int n, const int ld_logits, const SampleArgs a) {
     TRACE_T0();
-    TRACE_T1(a.n);
+    TRACE_T1(n);
     __shared__ float red_f[16];
     __shared__ int red_i[16];
     __shared__ int red_c[16];
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     __shared__ float e_all[12288];                             // exact path only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x;                               // sequence slot (batched decode); 0 otherwise
-    const float * logits = a.logits + (size_t) slot * a.ld_logits;
-    StepState * st = a.st + slot;
+    const float * logits = logits0 + (size_t) slot * ld_logits;
+    StepState * st = st0 + slot;
     // everything the end of the kernel needs from memory is requested now: the stage state, and the position row of the next
     // step's embedding (its token row can only be fetched once the pick is known)
     const int np_next = st->n_past + a.n_past_add;
@@ -176,9 +177,9 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const SampleArgs a)
     #pragma unroll
     for (int k = 0; k < MAXV; k++) {
         const int i = tid + 1024 * k;
-        sv[k] = i < a.n ? logits[i] : -INFINITY;
+        sv[k] = i < n ? logits[i] : -INFINITY;
     }
-    float last_logit = logits[a.n - 1];
+    float last_logit = logits[n - 1];
     const bool embed = a.x != nullptr && tid < a.E;
     float pe_v = 0.0f;
     if (embed && np_next < a.P) pe_v = a.wpe[(size_t) np_next * a.E + tid];
@@ -431,7 +432,7 @@ void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld,
 
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
     if (a.temp > 0.0f) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a.logits, a.st, a.n, a.ld_logits, a);
 }
 
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,

@@ -29,7 +29,7 @@ def main():
     lib = pkg.load_library()
     ctx = pkg.BarkContext.load_model(ensure_model(preset, 0), pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=32), 0)
     replays = 4
-    cap = 1 << 18
+    cap = 1 << 19
     buf = np.zeros((cap, 8), np.uint64)
     lib.bark_hip_trace_decode_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     n = lib.bark_hip_trace_decode_step(ctx._h, 0, ctxlen, replays, buf.ctypes.data, cap)
@@ -92,6 +92,14 @@ def main():
         a = agg.setdefault(row["name"], {"n": 0, "span": 0.0, "gap": 0.0, "kernarg": 0.0, "operands": 0.0, "tail": 0.0, "spread": 0.0})
         a["n"] += 1; a["span"] += row["span_us"]; a["gap"] += row["gap_from_prev_us"] or 0.0
         a["kernarg"] += row["kernarg_us_med"]; a["operands"] += row["operands_us_med"]; a["tail"] += row["tail_us_med"]; a["spread"] += row["entry_spread_us"]
+    # per wave index of the workgroup (attention kernel of layer 1): which role is the late one?
+    wv = ((rec[:, 1] >> 40) & 0xFF).astype(np.int64)
+    idx = rep[6] if len(rep) > 6 else rep[1]
+    if len(idx) and tab[idx, 0].max() > 0:
+        print("kid 6 by wave index: score-ready / stats-ready / end, us after kernarg (median over workgroups)")
+        for w in sorted(set(wv[idx].tolist())):
+            ii = idx[wv[idx] == w]
+            print("  wave %2d: %.2f %.2f %.2f" % (w, np.median(tab[ii, 0] - t[ii, 1]) * tick, np.median(tab[ii, 1] - t[ii, 1]) * tick, np.median(t[ii, 3] - t[ii, 1]) * tick))
     for row in table[:12]:
         if "ta_us_med" in row:
             print("kid %d extra stamps after kernarg: score med %.2f max %.2f | exp+sum med %.2f max %.2f | mix (operands) med %.2f" % (
