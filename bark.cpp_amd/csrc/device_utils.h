@@ -105,6 +105,19 @@ DEVINL float wave_add_f32(float v) {
     v = wave_xor_add16(v);
     return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
+// a / K in double, correctly rounded, for a compile-time row length K (LayerNorm mean and variance, ggml_norm divides the double sums by
+// the float count).  Powers of two scale exactly; otherwise (K = 768) one Newton step on a correctly rounded reciprocal: q0 = RN(a y),
+// r = a - K q0 exactly (fma), q = RN(q0 + r y) is the correctly rounded quotient (Markstein) - three dependent fp64 operations instead of
+// the ~11 of the generic division sequence.  Checked against exact rational arithmetic in tests/test_canon_orders.py.
+template <int K> DEVINL double div_by_const(double a) {
+    if constexpr ((K & (K - 1)) == 0) return a * (1.0 / (double) K);
+    else {
+        constexpr double y = 1.0 / (double) K;                 // compile-time, correctly rounded
+        const double q0 = a * y;
+        const double r = __builtin_fma(-(double) K, q0, a);
+        return __builtin_fma(r, y, q0);
+    }
+}
 // order-preserving float <-> unsigned map, so that the row maximum can be kept with an integer atomicMax
 DEVINL unsigned f32_ordered(float f) { const unsigned b = __builtin_bit_cast(unsigned, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 DEVINL float f32_unordered(unsigned u) { const unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; return __builtin_bit_cast(float, b); }

@@ -88,7 +88,7 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
         const bool ps = use_ps && !m.q4 && P == 1024 && m.vtcache;
         if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
-        BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 3 * (E / 4));        // room for all three copies of the q workgroups
+        BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 4 * (E / 4));        // room for all four copies of the q workgroups
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;

@@ -160,77 +160,96 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
 // weights, the f32 row, LayerNorm parameters, the K quads of the partial scores - is requested before the argument struct is read.
 template <int NBLK, bool LNB, bool PS>
 __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restrict__ W, const float * __restrict__ x_f32, const float * __restrict__ ln_g,
-                                                         const float * __restrict__ ln_b, const float * __restrict__ kc, const int M, const int parity_rows,
-                                                         const int E, const LinArgs a) {
+                                                         const float * __restrict__ ln_b, const float * __restrict__ kc, const StepState * __restrict__ st, const int M,
+                                                         const int parity_rows, const int E, const int kpc, const LinArgs a) {
     TRACE_T0();
     TRACE_T1(M);
     constexpr int K = NBLK * 128;
-    constexpr int EPT = (K + 255) / 256;                     // row elements per thread
+    constexpr int EPT = K / 64;                              // row elements per lane of the normalising wave
     __shared__ __attribute__((aligned(16))) half_t xs[K];
-    __shared__ double red1[4], red2[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
-    // PS: the grid carries three more copies of the q workgroups (ids behind the M / 16 main ones).  Copy r repeats the LayerNorm and
-    // the 16 q rows (weights come from L2) and scores the keys 256 r .. 256 r + 255 only, so no workgroup pulls more than 16 KB of K;
-    // it writes nothing but partial scores.
+    // PS: behind the M / 16 main workgroups the grid carries copies of the q workgroups.  Copy r repeats the LayerNorm and the 16 q rows
+    // (its weights come out of the XCD's L2: ids congruent mod 8 share it with the main workgroup) and scores the keys r kpc .. r kpc +
+    // kpc - 1; it writes nothing but partial scores.  A CU pulls only ~24 bytes/ns from the memory side and the launch is as slow as its
+    // busiest CU: nobody carries both the 24 KB of weights of 16 rows and a K stream, and the host sizes kpc (256 .. 512 keys, 64 bytes
+    // each) so that main workgroups + copies do not outnumber the CUs (two workgroups on one CU were the long pole before).
     [[maybe_unused]] const int n_main = (M + 15) >> 4, n_q = E >> 4;
-    [[maybe_unused]] const int rep = PS && (int) blockIdx.x >= n_main ? 1 + ((int) blockIdx.x - n_main) / n_q : 0;
-    const int wg = PS && rep ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
+    [[maybe_unused]] const bool copy = PS && (int) blockIdx.x >= n_main;
+    [[maybe_unused]] const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
+    const int wg = copy ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
     const int m = (wg * 4 + wave) * 4 + rg;
-    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
+    const int row_off = parity_rows ? parity_rows * (st->step & 1) : 0;
     const bool live = m < M;
     const half_t * wrow = W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
+    [[maybe_unused]] unsigned long long stamp_a = 0, stamp_b = 0;       // diagnostic build: row arrived, normalised row written
+    // the row to normalise is requested FIRST: loads return in order, and behind 6 KB of weights per lane group the 3 KB row arrived
+    // after 1.3 us (in-kernel time line) - the whole LayerNorm waited for the weight stream it was meant to overlap
+    float xv[EPT], gv[EPT], bv[EPT];
+    if (wave == 0) {
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) xv[i] = x_f32[lane + 64 * i];
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            gv[i] = ln_g[lane + 64 * i];
+            if constexpr (LNB) bv[i] = ln_b[lane + 64 * i]; else bv[i] = 0.0f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     half8 wv[NBLK];
     #pragma unroll
     for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
-    // partial scores: key 256 rep + tid; d-quads 4 blk .. 4 blk + 3 of head hq
-    [[maybe_unused]] float4 kq[4];
+    // partial scores: keys rep * kpc + tid (+ 256); d-quads 4 blk .. 4 blk + 3 of head hq
+    [[maybe_unused]] float4 kq[2][4];
     [[maybe_unused]] const int m0 = wg * 16;
-    [[maybe_unused]] const bool is_q = PS && m0 < E;
+    [[maybe_unused]] const bool is_q = copy;
     [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
-    if constexpr (PS) {
-        if (is_q) {
-            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + 256 * rep);     // PS implies P == 1024
+    // the copies' K quads are requested only when the normalised row is in LDS: asked for at wave launch, 2 MB of K in front of every
+    // memory channel delayed the 3 KB row all workgroups wait for by 0.6 us (in-kernel time line: row arrived at 1.4 us against 0.8 us
+    // without the K stream); they are needed last, after the dot product
+    auto load_kq = [&] {
+        const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // PS implies P == 1024
+        #pragma unroll
+        for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);    // rows beyond n_past hold stale bits; their scores are not stored
+        if (tid + 256 < kpc) {
             #pragma unroll
-            for (int i = 0; i < 4; i++) kq[i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);    // rows beyond n_past hold stale bits; their scores are not stored
+            for (int i = 0; i < 4; i++) kq[1][i] = buf_ld_f4(kr, (unsigned) tid * 16u + 4096u, (unsigned) i * 16384u);
         }
-    }
-    float xv[EPT], gv[EPT], bv[EPT];
-    #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-        const int e = tid + 256 * i;
-        const bool ok = (K % 256 == 0) || e < K;
-        xv[i] = ok ? x_f32[e] : 0.0f;
-        gv[i] = ok ? ln_g[e] : 0.0f;
-        if constexpr (LNB) bv[i] = ok ? ln_b[e] : 0.0f; else bv[i] = 0.0f;
-    }
+    };
+    // the context length (EPI_QKV: where the K / V rows go, which copies have keys) is requested on the preloaded state pointer, not
+    // through the argument struct: two dependent scalar round trips in front of the LayerNorm cost the QKV kernel 0.6 us
+    const int n_past_now = st ? st->n_past : 0;
     __builtin_amdgcn_sched_barrier(0);                        // everything above goes out on the preloaded arguments alone
-    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
-    if constexpr (PS) { if (rep && pre.n_past <= 256 * rep) return; }      // uniform: this copy's keys are not in the context yet
-    double s1 = 0.0;
-    #pragma unroll
-    for (int i = 0; i < EPT; i++) if ((K % 256 == 0) || tid + 256 * i < K) s1 += (double) xv[i];
-    s1 = wave_sum(s1);
-    if (lane == 0) red1[wave] = s1;
-    __syncthreads();
-    const float mean = (float) (((red1[0] + red1[1]) + (red1[2] + red1[3])) / (double) K);
-    double s2 = 0.0;
-    #pragma unroll
-    for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; if ((K % 256 == 0) || tid + 256 * i < K) s2 += (double) (xv[i] * xv[i]); }
-    s2 = wave_sum(s2);
-    if (lane == 0) red2[wave] = s2;
-    __syncthreads();
-    const float var = (float) (((red2[0] + red2[1]) + (red2[2] + red2[3])) / (double) K);
-    const float scale = 1.0f / sqrtf(var + 1e-5f);
-    #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-        const int e = tid + 256 * i;
-        float v = xv[i] * scale;
-        v = v * gv[i];
-        if constexpr (LNB) v = v + bv[i];
-        if ((K % 256 == 0) || e < K) xs[e] = to_half(v);      // mul_mat converts the activation to f16 first
+    EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    if (PS || a.epi == EPI_QKV) pre.n_past = n_past_now;      // same value epilogue_prefetch reads through the struct (that load is dead now)
+    // (a copy whose keys are not in the context yet runs to the end and stores nothing: leaving early would put the arrival of the
+    // context length in front of the LayerNorm; the host launches only the copies the context bound needs)
+    if (wave == 0) {
+        // ggml_norm (+mul, +add): double sums, eps on the variance (bark.cpp:1265-1274); four partial sums per lane keep the fp64
+        // chains short (the order of a double sum of floats changes the rounded float result with probability ~2^-29)
+        double p1[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) p1[i & 3] += (double) xv[i];
+        TRACE_SET(stamp_a, (float) p1[0]);
+        const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        const float mean = (float) div_by_const<K>(s1);
+        double p2[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; p2[i & 3] += (double) (xv[i] * xv[i]); }
+        const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+        const float var = (float) div_by_const<K>(s2);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            float v = xv[i] * scale;
+            v = v * gv[i];
+            if constexpr (LNB) v = v + bv[i];
+            xs[lane + 64 * i] = to_half(v);                    // mul_mat converts the activation to f16 first
+        }
+        TRACE_SET(stamp_b, scale);
     }
     __syncthreads();
+    if constexpr (PS) { if (is_q) load_kq(); }
     float acc = 0.0f;
     #pragma unroll
     for (int b = 0; b < NBLK; b++) {
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
     }
     TRACE_T2(acc);
     acc = wave_xor_add16(acc);
-    if (live && c == 0 && !rep) linear_epilogue_pre(a, 0, m, acc, pre);
+    if (live && c == 0 && !copy) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (PS) {
         __shared__ float qs[16];
         if (is_q) {                                              // uniform per workgroup
@@ -249,11 +268,14 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
             float qb[16];
             #pragma unroll
             for (int i = 0; i < 16; i++) qb[i] = qs[i];
-            const int j = 256 * rep + tid;
-            if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq, qb);
+            const int j = rep * kpc + tid;
+            if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq[0], qb);
+            if (tid + 256 < kpc && j + 256 < pre.n_past) a.ps[((size_t) hq * a.P + j + 256) * 4 + blk] = score_block_f4(kq[1], qb);
         }
     }
-    TRACE_END(a.tr);
+#ifdef BARK_TRACE
+    trace_emit(a.tr, _tr0, _tr1, _tr2, trace_clock(), stamp_a, stamp_b);
+#endif
 }
 
 template <int NBLK>
@@ -266,12 +288,18 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
                 const dim3 g16((a.M + 15) / 16), b256(256);
                 const float * kc = a.kc;
                 if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
-                    const dim3 gps((a.M + 15) / 16 + (std::max(1, std::min(a.ng, 4)) - 1) * (a.E / 16));      // + one copy of the q workgroups per further 256 keys the context may hold
-                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
-                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
+                    // copies of the q workgroups: as many per q block as fit beside the main workgroups on 256 CUs (at most 2), each
+                    // scoring kpc = 256 or 512 of the up to 256 ng keys the context may hold
+                    const int n_main = (a.M + 15) / 16, n_q = a.E / 16, keys = 256 * std::max(1, std::min(a.ng, 4));
+                    const int fit = std::max(1, std::min(2, (256 - n_main) / n_q));
+                    const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));      // a copy scores at most 512 keys (two per thread)
+                    const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;                 // 256, 384 or 512
+                    const dim3 gps(n_main + n_copy * n_q);
+                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
+                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
                 }
-                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
-                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.M, a.parity_rows, a.E, a);
+                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
+                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
             }
             else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
             else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);

@@ -213,3 +213,23 @@ def test_c1q_all_block_formats(lib, fmt):
                 t = add32(t, f32(mw * sx))
         acc[b % 16] = add32(acc[b % 16], t)
     assert got == tree16(acc)
+
+
+@pytest.mark.parametrize("K", [768, 384, 640, 896])
+def test_division_by_the_row_length_is_correctly_rounded(K):
+    """device_utils.h div_by_const<K>: q0 = RN(a y), r = a - K q0 (exact, one fma), q = RN(q0 + r y) with y = RN(1 / K) must be the
+    correctly rounded a / K for every double a - it replaces the fp64 division of the LayerNorm sums in the decode kernels.
+    Restated with exact rationals (float(Fraction) rounds to nearest even)."""
+    rng = np.random.default_rng(K)
+    y = float(Fraction(1, K))
+    cases = [float(v) for v in rng.standard_normal(20000) * 10.0 ** rng.uniform(-6, 6, 20000)]
+    cases += [float(np.float32(v)) * K for v in rng.standard_normal(2000)]            # quotients that are floats: rounding boundaries of the later f32 cast
+    cases += [float(np.nextafter(np.float64(c), np.inf)) for c in cases[:4000]] + [0.0, 1.0, float(K), K * (1.0 + 2.0 ** -52), 2.0 ** -30, 1e300 / K]
+    for a in cases:
+        fa = Fraction(a)
+        q0 = float(fa * Fraction(y))
+        r_exact = fa - K * Fraction(q0)
+        r = float(r_exact)
+        assert Fraction(r) == r_exact, "the residual must be exact in double precision"
+        q = float(Fraction(q0) + Fraction(r) * Fraction(y))
+        assert q == float(fa / K), (a, q, float(fa / K))

@@ -100,6 +100,26 @@ def main():
         for w in sorted(set(wv[idx].tolist())):
             ii = idx[wv[idx] == w]
             print("  wave %2d: %.2f %.2f %.2f" % (w, np.median(tab[ii, 0] - t[ii, 1]) * tick, np.median(tab[ii, 1] - t[ii, 1]) * tick, np.median(t[ii, 3] - t[ii, 1]) * tick))
+    # QKV kernel of layer 1: the main workgroups against the partial-score copies of the q workgroups
+    if len(rep) > 5 and len(rep[5]):
+        idx = rep[5]
+        wgid = (rec[idx, 1] & 0xFFFFFF).astype(np.int64)
+        n_main = 144 if preset == "small" else 0
+        for name, sel in (("main", wgid < n_main), ("copies", wgid >= n_main)):
+            ii = idx[sel]
+            if len(ii):
+                print("kid 5 %-6s waves %4d: operands med %.2f max %.2f | end (after kernarg) med %.2f max %.2f" % (
+                    name, len(ii), np.median(t[ii, 2] - t[ii, 1]) * tick, (t[ii, 2] - t[ii, 1]).max() * tick,
+                    np.median(t[ii, 3] - t[ii, 1]) * tick, (t[ii, 3] - t[ii, 1]).max() * tick))
+    # LayerNorm-fused kernels of layer 1 (QKV kid 5, FC kid 8): wave 0's stamps
+    for k in (5, 8):
+        if len(rep) > k and len(rep[k]):
+            idx = rep[k]
+            ii = idx[(wv[idx] == 0) & (tab[idx, 0] > 0)]
+            if len(ii):
+                print("kid %d wave 0 (us after kernarg): row arrived %.2f | normalised row in LDS %.2f | dot done %.2f | end %.2f" % (
+                    k, np.median(tab[ii, 0] - t[ii, 1]) * tick, np.median(tab[ii, 1] - t[ii, 1]) * tick,
+                    np.median(t[ii, 2] - t[ii, 1]) * tick, np.median(t[ii, 3] - t[ii, 1]) * tick))
     for row in table[:12]:
         if "ta_us_med" in row:
             print("kid %d extra stamps after kernarg: score med %.2f max %.2f | exp+sum med %.2f max %.2f | mix (operands) med %.2f" % (
