@@ -1,5 +1,7 @@
-"""The N > 1 path of bench.py on CPU: two gloo ranks shard the synthetic prompt set without overlap and
-combine their timings the way the bench contract demands (MAX time, SUM work); no data-path collective."""
+"""The N > 1 path of bench.py (BASELINE config 5) on CPU: two gloo ranks shard the 64 synthetic prompts by length without overlap,
+all_gather the per-prompt sample counts, gather the PCM on rank 0 and combine their timings the way the bench contract demands
+(MAX time, SUM work); no collective inside an utterance.  The engine itself is exercised by the -m gpu twin of this test
+(tests/test_gpu_parity.py::test_two_ranks_gather_the_single_process_pcm)."""
 import os
 import socket
 import subprocess
@@ -15,12 +17,17 @@ import bench
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 prompts = bench.synth_prompts(64)
-mine = [bench.prompt_for(s, rank, world, prompts) for s in range(4)]
+idx = bench.shard_prompts(prompts, rank, world)
 dt, audio = bench.reduce_timing(1.0 + rank, 5.12 * 4, world)
+# stand-in for the engine: utterance i "generates" 100 + 7 i samples whose values encode (i, position)
+import numpy as np
+pcms = [(np.arange(100 + 7 * i, dtype=np.float32) + 1000.0 * i) for i in idx]
+counts, gathered = bench.gather_batch_results(pcms, idx, len(prompts), rank, world, None)
 allp = [None] * world
-dist.all_gather_object(allp, mine)
+dist.all_gather_object(allp, idx)
 if rank == 0:
-    print(json.dumps({"dt": dt, "audio": audio, "prompts": allp}))
+    ok = all(np.array_equal(gathered[i], np.arange(100 + 7 * i, dtype=np.float32) + 1000.0 * i) for i in range(len(prompts)))
+    print(json.dumps({"dt": dt, "audio": audio, "shards": allp, "counts": counts.tolist(), "n_gathered": len(gathered), "pcm_ok": bool(ok)}))
 dist.destroy_process_group()
 """
 
@@ -40,15 +47,18 @@ def test_two_rank_sharding_and_reduction(tmp_path):
     out = json.loads(line)
     assert out["dt"] == 2.0                                   # MAX over ranks
     assert abs(out["audio"] - 2 * 5.12 * 4) < 1e-9            # SUM over ranks
-    flat = out["prompts"][0] + out["prompts"][1]
-    assert len(set(flat)) == len(flat) == 8                    # disjoint shards
+    flat = out["shards"][0] + out["shards"][1]
+    assert sorted(flat) == list(range(64)) and len(out["shards"][0]) == len(out["shards"][1]) == 32      # disjoint, complete, balanced
     import bench
     prompts = bench.synth_prompts(64)
-    assert out["prompts"][0] == [prompts[0], prompts[2], prompts[4], prompts[6]]
+    lens = [len(prompts[i]) for i in flat]
+    assert lens == sorted(lens)                                # sorted by length: rank 0 holds the short half
+    assert out["counts"] == [100 + 7 * i for i in range(64)]   # all_gather of the sample counts
+    assert out["n_gathered"] == 64 and out["pcm_ok"]           # gather of the PCM on rank 0, bit for bit
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench_small_n1.json is a bench.py line from the GPU box: keys and units of the driver's contract."""
+    """profiles/r0N_bench_small_n1.json is a bench.py line from the GPU box: keys and units of the driver's contract."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
