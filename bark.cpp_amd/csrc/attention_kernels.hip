@@ -157,14 +157,17 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     #pragma unroll
     for (int g = 0; g < 4; g++) {
         if (g == 0 || ctx > 256 * g) {
+            // probabilities fetched in one batch, masked terms dropped by a select on the result (see mix_chain below): the guarded
+            // form cost one LDS round trip per key
+            float pj[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
             #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int j = chain + 16 * (16 * g + i);
-                if (j < ctx) {
-                    const float p = es[j] * inv;               // p = e * (float)(1/sum), as ggml_soft_max scales in place
-                    const float4 v = vv[16 * g + i];
-                    acc.x = fmaf(v.x, p, acc.x); acc.y = fmaf(v.y, p, acc.y); acc.z = fmaf(v.z, p, acc.z); acc.w = fmaf(v.w, p, acc.w);
-                }
+                const bool ok = chain + 16 * (16 * g + i) < ctx;
+                const float4 v = vv[16 * g + i];
+                const float tx = fmaf(v.x, pj[i], acc.x), ty = fmaf(v.y, pj[i], acc.y), tz = fmaf(v.z, pj[i], acc.z), tw = fmaf(v.w, pj[i], acc.w);
+                acc.x = ok ? tx : acc.x; acc.y = ok ? ty : acc.y; acc.z = ok ? tz : acc.z; acc.w = ok ? tw : acc.w;
             }
         }
     }

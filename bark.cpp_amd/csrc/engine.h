@@ -105,6 +105,7 @@ struct bark_context {
     hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook
     int * d_lstm_t = nullptr;                           // step counter of the replayed LSTM block
     struct LstmGraph { hipGraphExec_t exec = nullptr; int T = 0; const float * hseq = nullptr; const float * gi = nullptr; } lstm_graphs[2];
+    struct CodecGraph { hipGraphExec_t exec = nullptr; int T = 0; const float * buf = nullptr; float * out = nullptr; int n_out = 0; } codec_graph;   // conv stack behind the LSTM
 
     // batched decode (several utterances in lock step on this context, bark_hip_generate_batch): per-slot KV caches
     // and decode rows; prefill / fine / codec still run one utterance at a time on the buffers above

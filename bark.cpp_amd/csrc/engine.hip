@@ -719,26 +719,51 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
         HIP_OK(hipStreamSynchronize(s));
     };
     grab(0, B, (size_t) D * T);
-    launch_add(s, R, B, (size_t) D * T, A);                            // y + x ; A = x
-    grab(1, A, (size_t) D * T);
-    float * cur = A, * other = B;
+    // skip connection + the four upsampling blocks + final conv: ~40 launches, replayed from a hipGraph captured per frame count
+    // (the buffers are the context's own, so a graph stays valid until they are re-allocated for a longer input)
     int Tc = T;
-    for (int b = 0; b < 4; b++) {
-        const CodecModel::Block & bl = cm.blocks[b];
-        launch_act_round(s, cur, (size_t) bl.up.cin * Tc, 1, Hh);
-        if (blocked && bl.up.w32 && bl.up.k == 2 * bl.up.stride) launch_convtr1d_f32w(s, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
-        else launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
-        Tc *= bl.up.stride;
-        std::swap(cur, other);                                          // cur = upsampled x
-        // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)
-        conv(bl.c1, cur, true, Tc, nullptr, R);
-        conv(bl.c2, R, true, Tc, nullptr, other);                       // other = r
-        conv(bl.sc, cur, false, Tc, other, R);                          // R = shortcut(x) + r
-        std::swap(cur, R);
-        // keep three distinct buffers: cur (result), other, R (old x)
-        grab(2 + b, cur, (size_t) bl.up.cout * Tc);
+    float * cur = A, * other = B;
+    auto tail = [&](bool taps) {
+        float * Rb = R;
+        launch_add(s, Rb, B, (size_t) D * T, A);                       // y + x ; A = x
+        if (taps) grab(1, A, (size_t) D * T);
+        cur = A; other = B; Tc = T;
+        for (int b = 0; b < 4; b++) {
+            const CodecModel::Block & bl = cm.blocks[b];
+            launch_act_round(s, cur, (size_t) bl.up.cin * Tc, 1, Hh);
+            if (blocked && bl.up.w32 && bl.up.k == 2 * bl.up.stride) launch_convtr1d_f32w(s, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
+            else launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
+            Tc *= bl.up.stride;
+            std::swap(cur, other);                                      // cur = upsampled x
+            // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)
+            conv(bl.c1, cur, true, Tc, nullptr, Rb);
+            conv(bl.c2, Rb, true, Tc, nullptr, other);                  // other = r
+            conv(bl.sc, cur, false, Tc, other, Rb);                     // Rb = shortcut(x) + r
+            std::swap(cur, Rb);
+            // keep three distinct buffers: cur (result), other, Rb (old x)
+            if (taps) grab(2 + b, cur, (size_t) bl.up.cout * Tc);
+        }
+        conv(cm.fin, cur, true, Tc, nullptr, other);
+    };
+    if (c->use_graph && tap_stage < 0) {
+        auto & cg = c->codec_graph;
+        if (cg.exec && (cg.T != T || cg.buf != A)) { (void) hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
+        if (!cg.exec) {
+            hipGraph_t graph = nullptr;
+            HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            try { tail(false); }
+            catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(s, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+            HIP_OK(hipStreamEndCapture(s, &graph));
+            HIP_OK(hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0));
+            (void) hipGraphDestroy(graph);
+            cg.T = T; cg.buf = A; cg.out = other; cg.n_out = Tc;
+        }
+        HIP_OK(hipGraphLaunch(cg.exec, s));
+        c->stats.graph_replays++;
+        other = cg.out; Tc = cg.n_out;
+    } else {
+        tail(true);
     }
-    conv(cm.fin, cur, true, Tc, nullptr, other);
     std::vector<float> pcm((size_t) Tc);
     HIP_OK(hipMemcpyAsync(pcm.data(), other, (size_t) Tc * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));

@@ -70,41 +70,58 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
     // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
     const bool hoist = B >= 24 && !m.q4;
+    // BARK_HIP_BATCH_MFMA=1 (opt-in), B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores
+    // (gemm_slots_kernel); rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend
+    // on the route.  Measured (tools/batch_ab.py, bark-small, 256 semantic steps): 12.4 prompts/s at 32 slots on either route, 6.0
+    // against 8.8 at 8 slots - the 32 x 32 tile pulls its operands straight from L1/L2, one 16-byte chunk per MFMA quartet, and is
+    // load-bound; an LDS-staged tile is the next step before this becomes the default.
+    static const bool mfma_ok = getenv("BARK_HIP_BATCH_MFMA") && atoi(getenv("BARK_HIP_BATCH_MFMA")) != 0;
+    const bool mfma = mfma_ok && B >= 8 && !m.q4;
+    // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
+    static const int dbg = getenv("BARK_HIP_BATCH_DBG") ? atoi(getenv("BARK_HIP_BATCH_DBG")) : 0;
+    auto product = [&](LinArgs & a, const float * ln_g, const float * ln_b) {
+        if (dbg & 2) return;
+        if (mfma && (dbg & 4)) { a.x_f16 = c->xn; a.x_f32 = nullptr; a.ln_stats = nullptr; launch_linear_slots(st, a); return; }
+        if (!mfma) { a.ln_g = ln_g; a.ln_b = ln_b; launch_linear(st, a); return; }
+        if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
+        a.ln_stats = nullptr;
+        launch_linear_slots(st, a);
+    };
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
-        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+        if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs a;
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
-        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
-        launch_linear(st, a);
+        product(a, L.ln1_g, L.ln1_b);
         AttnDecodeArgs at;
         at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
         at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
-        launch_attn_decode_part(st, at, 4);
+        if (!(dbg & 1)) launch_attn_decode_part(st, at, 4);
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
-        launch_linear(st, p);
-        if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+        product(p, nullptr, nullptr);
+        if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
-        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
-        launch_linear(st, f);
+        product(f, L.ln2_g, L.ln2_b);
         LinArgs o;
         o.batched = 1; o.nbatch = B;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
-        launch_linear(st, o);
+        product(o, nullptr, nullptr);
     }
-    if (hoist) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
+    if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
     LinArgs h;
     h.batched = 1; h.nbatch = B; h.ln_stats = hoist ? bb.ln_stats : nullptr;
     if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, E); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * E;
-    h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b;
+    h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
-    launch_linear(st, h);
+    product(h, m.lnf_g, m.lnf_b);
     SampleArgs sa;
     { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
     sa.logits = bb.logits; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;

@@ -84,6 +84,7 @@ bark_context::~bark_context() {
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
     for (auto & g : lstm_graphs) if (g.exec) (void) hipGraphExecDestroy(g.exec);
+    if (codec_graph.exec) (void) hipGraphExecDestroy(codec_graph.exec);
     for (auto & g : fine_graphs) if (g) (void) hipGraphExecDestroy(g);
     for (void * p : allocs) (void) hipFree(p);
     if (stream) (void) hipStreamDestroy(stream);

@@ -95,6 +95,8 @@ struct LinArgs {
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
+// lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
+void launch_linear_slots(hipStream_t s, const LinArgs & a);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {

@@ -605,6 +605,92 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Lock-step decode product on the f32 matrix cores: y[slot][m] for up to 32 utterance slots at once, so that a step reads every weight
+// ONCE for all slots (gemv_batch_kernel re-reads them from L2 per pair of slots on the VALU: 1.6 ms per step at 32 slots).
+// Tile: 32 slots (MFMA A rows) x 32 weight rows (B rows); 8 waves, wave w owns chains 2w and 2w+1 of C1 (one accumulator = one fmaf
+// chain, as in gemm_kernel); per 128-element K block a chain is ONE 16-byte chunk per operand row = 4 MFMA k pairs.  The chain pairs
+// meet in LDS in the C1 tree order.  Rows of x are f16 (LayerNorm applied by ln_rows_kernel where the operator has one); the epilogue
+// is the per-slot one of the decode GEMVs (own KV cache and position per slot).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_slots_kernel(const LinArgs a) {
+    __shared__ float lds[8][32][33];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 32;
+    const int K = a.K, nblk = K >> 7;
+    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
+    const int nrow = min(l31, a.nbatch - 1), mrow = min(m0 + l31, a.M - 1);
+    const half_t * xrow = a.x_f16 + (size_t) nrow * K + ((2 * w) << 3);
+    const half_t * wrow = a.W + (size_t) (row_off + mrow) * K + ((2 * w) << 3);
+    floatx16 acc[2];
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int r = 0; r < 16; r++) acc[s][r] = 0.0f;
+    const unsigned sh16 = half ? 16u : 0u;                     // lanes 32-63 feed the odd element of each f16 pair (second k slot)
+    half8 xa[2][2], wb[2][2];                                  // [buffer][chain]
+    #pragma unroll
+    for (int s = 0; s < 2; s++) { xa[0][s] = ld_half8(xrow + (s << 3)); wb[0][s] = ld_half8(wrow + (s << 3)); }
+    for (int b = 0; b < nblk; b += 2) {
+        if (b + 1 < nblk) {
+            #pragma unroll
+            for (int s = 0; s < 2; s++) { xa[1][s] = ld_half8(xrow + ((b + 1) << 7) + (s << 3)); wb[1][s] = ld_half8(wrow + ((b + 1) << 7) + (s << 3)); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint4 xu = __builtin_bit_cast(uint4, xa[0][s]), wu = __builtin_bit_cast(uint4, wb[0][s]);
+            #pragma unroll
+            for (int kp = 0; kp < 4; kp++) {
+                const unsigned xr = kp == 0 ? xu.x : kp == 1 ? xu.y : kp == 2 ? xu.z : xu.w;
+                const unsigned wr = kp == 0 ? wu.x : kp == 1 ? wu.y : kp == 2 ? wu.z : wu.w;
+                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32((float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16)),
+                                                              (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16)), acc[s], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < nblk) {
+            if (b + 2 < nblk) {
+                #pragma unroll
+                for (int s = 0; s < 2; s++) { xa[0][s] = ld_half8(xrow + ((b + 2) << 7) + (s << 3)); wb[0][s] = ld_half8(wrow + ((b + 2) << 7) + (s << 3)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            #pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const uint4 xu = __builtin_bit_cast(uint4, xa[1][s]), wu = __builtin_bit_cast(uint4, wb[1][s]);
+                #pragma unroll
+                for (int kp = 0; kp < 4; kp++) {
+                    const unsigned xr = kp == 0 ? xu.x : kp == 1 ? xu.y : kp == 2 ? xu.z : xu.w;
+                    const unsigned wr = kp == 0 ? wu.x : kp == 1 ? wu.y : kp == 2 ? wu.z : wu.w;
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32((float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16)),
+                                                                  (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16)), acc[s], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // accumulator register r of lane l: row (r & 3) + 8 (r >> 2) + 4 half = slot, column l31 = weight row
+    #pragma unroll
+    for (int r = 0; r < 16; r++) lds[w][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[0][r] + acc[1][r];
+    __syncthreads();
+    #pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int idx = threadIdx.x + 512 * r;
+        const int n = idx >> 5, mm = idx & 31, m = m0 + mm;
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = lds[q][n][mm];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (n < a.nbatch && m < a.M) {
+            const EpiPre pre = epilogue_prefetch(a, n, m, row_off);
+            linear_epilogue_pre(a, n, m, v, pre);
+        }
+    }
+}
+void launch_linear_slots(hipStream_t s, const LinArgs & a) {
+    if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
+    hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a);
+}
+
 void launch_linear(hipStream_t s, const LinArgs & a) {
     if (a.wq.qs && a.wq.qt == QT_F32) { launch_linear_w32(s, a); return; }
     if (a.wq.qs) { launch_linear_q(s, a); return; }

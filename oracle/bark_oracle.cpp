@@ -202,12 +202,13 @@ struct CanonW {
     const uint8_t * q4 = nullptr;                       // quantised weights stay in file order: [M][K/32] blocks
     int qtype = 0;                                      // their ggml_type (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0)
     uint8_t * data = nullptr; size_t bytes = 0;         // [M][Kp] in chain-major order
+    const uint8_t * raw = nullptr;                      // the file's row-major [M][K] image (dot_order != 0)
     CanonW() = default;
     CanonW(const CanonW &) = delete; CanonW & operator=(const CanonW &) = delete;
-    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), q4(o.q4), qtype(o.qtype), data(o.data), bytes(o.bytes) { o.data = nullptr; }
+    CanonW(CanonW && o) noexcept : M(o.M), K(o.K), Kp(o.Kp), f16(o.f16), q4(o.q4), qtype(o.qtype), data(o.data), bytes(o.bytes), raw(o.raw) { o.data = nullptr; }
     ~CanonW() { if (data) munmap(data, bytes); }
     void build(const uint8_t * src, bool src_f16, int M_, int K_) {
-        M = M_; K = K_; Kp = canon_kp(K); f16 = src_f16;
+        M = M_; K = K_; Kp = canon_kp(K); f16 = src_f16; raw = src;
         const size_t es = f16 ? 2 : 4;
         bytes = (size_t) M * Kp * es;
         data = (uint8_t *) big_alloc(bytes);
@@ -420,6 +421,15 @@ static bool load_codec(Reader & r, Codec & c) {
 struct Numerics {
     int act_round_f16 = 1;   // mul_mat with f16 weights converts the f32 activation to f16 first
     int gelu_mode = 0;       // 0: tanh GELU through a 64K-entry f16->f16 table; 1: tanh GELU in f32; 2: erf GELU (HF)
+    // Summation order of every dot product (weight matmuls, attention scores, attention mix).  0 is the canonical order the engine
+    // reproduces bit for bit; the others exist ONLY to measure how much the greedy token stream depends on the order
+    // (tools/order_sensitivity.py, tests/test_order_sensitivity.py):
+    //   1  ggml's AVX2 order (ggml_vec_dot_f16 / ggml_vec_dot_f32 with GGML_F16_STEP = GGML_F32_STEP = 32, four 8-lane accumulators:
+    //      element k goes to chain k mod 32 and is added by fma in ascending k; reduction (a0 + a2) + (a1 + a3), then lanes
+    //      (l + l+4), then (0+1) + (2+3); a tail of K mod 32 elements is added one by one in double) - what the reference's CPU
+    //      path computes on an AVX2 host, restated from upstream ggml (not in /root/reference: SURVEY.md A.4)
+    //   2  one sequential fmaf chain over ascending k
+    int dot_order = 0;
 };
 
 struct Oracle {
@@ -557,9 +567,55 @@ static void gemm_q4(const CanonW & W, const float * B, size_t ldb, float * C, si
         for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_q_q8(W.qtype, W.q4 + (size_t) m * rb, rows[(size_t) n], K);
 }
 
+
+// ---- study orders (Numerics::dot_order != 0): the same products, other summation orders ------------------------------------------
+// ggml AVX2: 32 chains (4 accumulators x 8 lanes), step 32; w: K floats or f16 bit patterns (row-major), x: K floats
+static inline float hsum_ggml_avx2(__m256 a0, __m256 a1, __m256 a2, __m256 a3) {
+    a0 = _mm256_add_ps(a0, a2); a1 = _mm256_add_ps(a1, a3);          // GGML_F32x8_REDUCE: offset 2, then offset 1
+    a0 = _mm256_add_ps(a0, a1);
+    const __m128 t0 = _mm_add_ps(_mm256_castps256_ps128(a0), _mm256_extractf128_ps(a0, 1));
+    const __m128 t1 = _mm_hadd_ps(t0, t0);
+    return _mm_cvtss_f32(_mm_hadd_ps(t1, t1));
+}
+template <bool W16> static inline float dot_ggml_avx2(const uint8_t * w, const float * x, int K) {
+    __m256 a[4] = {_mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps(), _mm256_setzero_ps()};
+    const int np = K & ~31;
+    for (int i = 0; i < np; i += 32)
+        for (int j = 0; j < 4; j++) {
+            const __m256 wv = W16 ? _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *) (w + (size_t) (i + 8 * j) * 2))) : _mm256_loadu_ps((const float *) w + i + 8 * j);
+            a[j] = _mm256_fmadd_ps(wv, _mm256_loadu_ps(x + i + 8 * j), a[j]);
+        }
+    double sumf = (double) hsum_ggml_avx2(a[0], a[1], a[2], a[3]);
+    for (int i = np; i < K; i++) {                                    // leftovers: float product added in ggml_float (double)
+        const float wf = W16 ? h2f(((const uint16_t *) w)[i]) : ((const float *) w)[i];
+        sumf += (double) (wf * x[i]);
+    }
+    return (float) sumf;
+}
+template <bool W16> static inline float dot_sequential(const uint8_t * w, const float * x, int K) {
+    float acc = 0.0f;
+    for (int i = 0; i < K; i++) acc = fmaf(W16 ? h2f(((const uint16_t *) w)[i]) : ((const float *) w)[i], x[i], acc);
+    return acc;
+}
+static void gemm_w_alt(const Oracle & o, const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
+    const size_t rb = (size_t) K * (W.f16 ? 2 : 4);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
+    for (int m = 0; m < M; m++) {
+        const uint8_t * w = W.raw + (size_t) m * rb;
+        for (int n = 0; n < N; n++) {
+            const float * x = B + (size_t) n * ldb;
+            float y;
+            if (o.num.dot_order == 1) y = W.f16 ? dot_ggml_avx2<true>(w, x, K) : dot_ggml_avx2<false>(w, x, K);
+            else                      y = W.f16 ? dot_sequential<true>(w, x, K) : dot_sequential<false>(w, x, K);
+            C[(size_t) n * ldc + m] = y;
+        }
+    }
+}
+
 static void gemm_w(Oracle & o, const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
     assert(M == W.M && K == W.K);
     if (W.q4) { gemm_q4(W, B, ldb, C, ldc, M, N, K, nth); return; }
+    if (o.num.dot_order != 0 && W.raw) { gemm_w_alt(o, W, B, ldb, C, ldc, M, N, K, nth); return; }
     const int Kp = W.Kp;
     o.ximg.ensure((size_t) N * Kp);
     float * xi = o.ximg.p;
@@ -600,6 +656,26 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
         float * Kt = o.vt.p + (size_t) tid * D * ctx8;                    // Kt[d][j]
         for (int j = 0; j < ctx_total; j++) for (int d = 0; d < D; d++) Kt[(size_t) d * ctx8 + j] = kc[(size_t) j * E + h * D + d];
         for (int j = ctx_total; j < ctx8; j++) for (int d = 0; d < D; d++) Kt[(size_t) d * ctx8 + j] = 0.0f;
+        if (o.num.dot_order != 0) {
+            // study orders: scores = dot over d (K row x Q row), mix = dot over the keys (V_trans row x probabilities), each in the
+            // selected order (ggml: vec_dot_f32 on f32 operands, bark.cpp:1316,1333); softmax as in the canonical path
+            std::vector<float> vcol((size_t) ctx8);
+            for (int i = 0; i < N; i++) {
+                const float * qi = q + (size_t) i * ldq + h * D;
+                const int valid = causal ? std::min(ctx_total, n_past + i + 1) : ctx_total;
+                for (int j = 0; j < valid; j++) {
+                    const float * kj = kc + (size_t) j * E + h * D;
+                    row[j] = (o.num.dot_order == 1 ? dot_ggml_avx2<false>((const uint8_t *) kj, qi, D) : dot_sequential<false>((const uint8_t *) kj, qi, D)) * scale;
+                }
+                softmax_row(row, valid);
+                float * oi = out + (size_t) i * E + h * D;
+                for (int d = 0; d < D; d++) {
+                    for (int j = 0; j < valid; j++) vcol[(size_t) j] = vc[(size_t) j * E + h * D + d];
+                    oi[d] = o.num.dot_order == 1 ? dot_ggml_avx2<false>((const uint8_t *) vcol.data(), row, valid) : dot_sequential<false>((const uint8_t *) vcol.data(), row, valid);
+                }
+            }
+            continue;
+        }
         for (int i = 0; i < N; i++) {
             const float * qi = q + (size_t) i * ldq + h * D;
             const int valid = causal ? std::min(ctx_total, n_past + i + 1) : ctx_total;
@@ -1188,6 +1264,7 @@ extern "C" {
 void * orc_open(const char * path) { return oracle_open(path); }
 void   orc_close(void * h) { delete (Oracle *) h; }
 void   orc_set_numerics(void * h, int act_round_f16, int gelu_mode) { auto * o = (Oracle *) h; o->num.act_round_f16 = act_round_f16; o->num.gelu_mode = gelu_mode; }
+void   orc_set_dot_order(void * h, int dot_order) { ((Oracle *) h)->num.dot_order = dot_order; }      // study modes, see Numerics
 void   orc_seed(void * h, uint32_t seed) { ((Oracle *) h)->rng = std::mt19937(seed); }
 const uint16_t * orc_gelu_table(void * h) { return ((Oracle *) h)->gelu_table.data(); }
 

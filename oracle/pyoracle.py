@@ -46,6 +46,7 @@ class Oracle:
         lib.orc_open.argtypes = [C.c_char_p]
         lib.orc_close.argtypes = [C.c_void_p]
         lib.orc_set_numerics.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.orc_set_dot_order.argtypes = [C.c_void_p, C.c_int]
         lib.orc_seed.argtypes = [C.c_void_p, C.c_uint32]
         lib.orc_gelu_table.restype = C.POINTER(C.c_uint16)
         lib.orc_gelu_table.argtypes = [C.c_void_p]
@@ -79,6 +80,10 @@ class Oracle:
     # -- configuration --------------------------------------------------------------
     def set_numerics(self, act_round_f16: bool = True, gelu_mode: int = 0):
         self.lib.orc_set_numerics(self.h, int(act_round_f16), gelu_mode)
+
+    def set_dot_order(self, order: int = 0):
+        """0 canonical (what the engine reproduces), 1 ggml's AVX2 order, 2 one sequential chain - study modes (Numerics::dot_order)."""
+        self.lib.orc_set_dot_order(self.h, int(order))
 
     def seed(self, s: int):
         self.lib.orc_seed(self.h, s)

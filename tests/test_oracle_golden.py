@@ -74,3 +74,87 @@ def test_ggml_numerics_stay_close_to_hf(toy_oracle, gold):
     logits, _ = toy_oracle.gpt_eval(1, gold["coarse_prompt"], 0, False)
     err = float(np.max(np.abs(logits - gold["coarse_logits0"])))
     assert 0 < err < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# tanh-GELU fixtures (tools/make_hf_golden.py tanh <preset>): HF with GELU(approximate="tanh") is ggml_gelu without its f16 table,
+# so the oracle's gelu_mode=1 / act_round_f16=0 must match at 2e-4 and its DEFAULT mode (f16-rounded activations in front of every
+# weight product, GELU through the f16 table) may only add f16 rounding noise.  Bound for the default mode: logits of these synthetic
+# models are O(1); every product sees activations with relative error 2^-11 and there are 4 such products per layer, so a few 1e-3
+# absolute is the expected size.  Measured: 4e-7 / 2.4e-6 (HF-matching mode, toy / bark-small shapes), 4.2e-4 / 1.6e-3 (default mode);
+# the tests state 2e-5 for the HF-matching mode and 2e-3 (toy, 2 layers) / 5e-3 (bark-small shapes, 12 layers) for the default mode.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _gold(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+@pytest.fixture(scope="module")
+def small_oracle(small_model):
+    from oracle.pyoracle import Oracle
+    o = Oracle(small_model, n_threads=4)
+    yield o
+    o.close()
+
+
+def _tanh_checks(o, g, default_bound):
+    res = {}
+    for mode, (rnd, gelu), tol in (("hf-matching", (False, 1), 2e-5), ("default", (True, 0), default_bound)):
+        o.set_numerics(act_round_f16=rnd, gelu_mode=gelu)
+        logits, n_past = o.gpt_eval(0, g["sem_prompt"], 0, True)
+        e0 = float(np.max(np.abs(logits - g["sem_logits0"])))
+        logits, _ = o.gpt_eval(0, [4242], n_past, True)
+        e1 = float(np.max(np.abs(logits - g["sem_logits1"])))
+        logits, n_past = o.gpt_eval(1, g["coarse_prompt"], 0, False)
+        e2 = float(np.max(np.abs(logits - g["coarse_logits0"])))
+        logits, _ = o.gpt_eval(1, [10777], n_past, False)
+        e3 = float(np.max(np.abs(logits - g["coarse_logits1"])))
+        fl = o.fine_eval(g["fine_tokens"], 3)
+        e4 = float(np.max(np.abs(fl[g["fine_rows"]] - g["fine_logits_nn3"])))
+        res[mode] = (e0, e1, e2, e3, e4)
+        assert max(res[mode]) <= tol, (mode, res[mode], tol)
+    o.set_numerics(act_round_f16=True, gelu_mode=0)
+    print("max abs logit error vs HF(tanh):", res)
+    return res
+
+
+def test_toy_shapes_against_hf_with_tanh_gelu(toy_oracle):
+    _tanh_checks(toy_oracle, _gold("hf_toy_tanh_s0.npz"), 2e-3)
+
+
+def test_bark_small_shapes_against_hf_with_tanh_gelu(small_oracle):
+    """the shapes of the headline benchmark (768 / 12 / 12, real vocabulary sizes), not just the toy preset"""
+    _tanh_checks(small_oracle, _gold("hf_small_tanh_s0.npz"), 5e-3)
+
+
+def _greedy_check(o, g, rnd, gelu):
+    """64 greedy semantic steps: HF forward passes + the reference's sampling rule (fixture) against the oracle's own stage loop.
+    A step whose two leading logits are closer than the numerical distance between the two implementations cannot be expected to
+    agree; the fixture records the margins, the test demands agreement up to the first step whose margin is below `noise`."""
+    o.set_numerics(act_round_f16=rnd, gelu_mode=gelu)
+    ids = o.semantic(g["sem_prompt"], o.params(n_steps_text_encoder=len(g["greedy_margins"])))
+    o.set_numerics(act_round_f16=True, gelu_mode=0)
+    want = g["greedy_ids"]
+    n = min(len(ids), len(want))
+    diff = np.flatnonzero(ids[:n] != want[:n])
+    first = int(diff[0]) if len(diff) else (None if len(ids) == len(want) else n)
+    return first, ids, want
+
+
+@pytest.mark.parametrize("fixture,model", [("hf_toy_tanh_s0.npz", "toy"), ("hf_small_tanh_s0.npz", "small")])
+def test_greedy_semantic_loop_against_hf(fixture, model, toy_oracle, small_oracle):
+    o = toy_oracle if model == "toy" else small_oracle
+    g = _gold(fixture)
+    margins = g["greedy_margins"]
+    # (a) the HF-matching numerics: the two implementations differ by < 2e-5 in the logits, so every step with a margin above
+    #     2 x 2e-5 / 0.7 must pick the same id
+    first, ids, want = _greedy_check(o, g, False, 1)
+    safe = int(np.argmax(margins < 6e-5)) if (margins < 6e-5).any() else len(margins)
+    assert first is None or first >= safe, (first, safe, float(margins[first]))
+    # (b) the default numerics (what the GPU engine is compared with bit for bit): report how far the streams agree
+    first_d, ids_d, _ = _greedy_check(o, g, True, 0)
+    n = min(len(ids_d), len(want))
+    agree = int((ids_d[:n] == want[:n]).sum())
+    print(f"{model}: HF-matching mode first difference {first}; default mode first difference {first_d}, {agree}/{len(want)} ids equal; "
+          f"smallest top-2 margin {float(margins.min()):.2e}")
+    if first_d is not None and first_d < len(margins):
+        assert margins[first_d] < 5e-3 / 0.7 * 2, "the default mode left the HF stream at a step with a wide margin"

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B of the lock-step batch path (BARK_HIP_BATCH_MFMA=0/1): prompts/s at B = 8 and 32, each arm in a fresh process."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, os, time, json
+sys.path.insert(0, %r)
+from bark_amd_loader import load_package
+from tools.make_synth_model import ensure_model
+import bench
+pkg = load_package()
+prompts = bench.synth_prompts(64)
+out = {}
+for B in (8, 32):
+    ctx = pkg.BarkContext.load_model(ensure_model("small", 0), pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=256), 0)
+    ctx.generate_batch(prompts[:B])
+    t0 = time.perf_counter(); res = ctx.generate_batch(prompts[B:2 * B]); dt = time.perf_counter() - t0
+    st = ctx.stats()
+    out["B%%d" %% B] = {"prompts_per_s": round(B / dt, 2), "semantic_ms": st["t_semantic_us"] // 1000, "coarse_ms": st["t_coarse_us"] // 1000, "fine_ms": st["t_fine_us"] // 1000, "codec_ms": st["t_codec_us"] // 1000}
+    ctx.free()
+print("RESULT", json.dumps(out))
+''' % ROOT
+arms = [("valu", {"BARK_HIP_BATCH_MFMA": "0"}), ("mfma", {"BARK_HIP_BATCH_MFMA": "1"})]
+for a in sys.argv[1:]:
+    arms.append((a, dict(kv.split("=") for kv in a.split(","))))
+for name, env in arms:
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True)
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+    print(name, line[0][7:] if line else p.stderr[-600:], flush=True)

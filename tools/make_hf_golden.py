@@ -164,9 +164,91 @@ def build_hf_codec(hp, tens):
     return dec.eval()
 
 
+def use_tanh_gelu(model):
+    """ggml_gelu is the tanh approximation; HF Bark's MLP uses the exact erf form (modeling_bark.py:264)."""
+    import torch
+    for layer in model.layers:
+        layer.mlp.gelu = torch.nn.GELU(approximate="tanh")
+    return model
+
+
+def greedy_semantic_loop(sem, prompt, n_steps, eos_token=10000, min_eos_p=0.2):
+    """The reference's semantic loop (bark.cpp:1645-1701) driven through HF forward passes: sample over ALL logits with
+    gpt_argmax_sample's rule (l / 0.7, softmax, first maximum; eos_p = p[last]), stop on the eos id or eos_p >= min_eos_p.
+    Returns ids, per-step top-2 margins (in l / 0.7 units) and eos probabilities."""
+    import torch
+    emb = sem.input_embeds_layer(torch.from_numpy(prompt)[None])
+    merged = torch.cat([emb[:, :256] + emb[:, 256:512], emb[:, 512:]], dim=1)
+    r = sem(inputs_embeds=merged, use_cache=True)
+    pkv = r.past_key_values
+    ids, margins, eos = [], [], []
+    for _ in range(n_steps):
+        l = (r.logits[0, -1].numpy().astype(np.float32) / np.float32(0.7)).astype(np.float32)
+        e = np.exp((l - l.max()).astype(np.float64)).astype(np.float32)
+        p = e / np.float32(e.sum(dtype=np.float32))
+        nxt = int(np.argmax(p))
+        srt = np.sort(l)[::-1]
+        margins.append(float(srt[0] - srt[1])); eos.append(float(p[-1]))
+        if nxt == eos_token or p[-1] >= min_eos_p:
+            break
+        ids.append(nxt)
+        r = sem(input_ids=torch.tensor([[nxt]]), past_key_values=pkv, use_cache=True)
+        pkv = r.past_key_values
+    return np.array(ids, np.int32), np.array(margins, np.float32), np.array(eos, np.float32)
+
+
+def main_tanh(preset: str, n_greedy: int):
+    """tests/golden/hf_<preset>_tanh_s0.npz: HF forward passes with the tanh GELU (= ggml_gelu without its f16 table) on the synthetic
+    `preset` weights, plus an n_greedy-step greedy semantic loop.  The oracle is compared with gelu_mode=1, act_round_f16=0 (2e-4) and
+    in its default mode (f16 rounding noise, bound stated in tests/test_oracle_golden.py)."""
+    import torch
+    torch.set_num_threads(8)
+    mf = read_model_file(ensure_model(preset, 0))
+    rng = np.random.default_rng(4321)
+    out = {}
+    with torch.no_grad():
+        hp, tens = mf["semantic"]
+        sem = use_tanh_gelu(build_hf_gpt(hp, tens, fine=False))
+        prompt = np.concatenate([rng.integers(10048, 129595, 40), np.full(216, 129595), np.full(256, 10000), [129599]]).astype(np.int64)
+        emb = sem.input_embeds_layer(torch.from_numpy(prompt)[None])
+        merged = torch.cat([emb[:, :256] + emb[:, 256:512], emb[:, 512:]], dim=1)
+        r = sem(inputs_embeds=merged, use_cache=True)
+        out["sem_prompt"] = prompt.astype(np.int32)
+        out["sem_logits0"] = r.logits[0, -1].numpy()
+        r = sem(input_ids=torch.tensor([[4242]]), past_key_values=r.past_key_values, use_cache=True)
+        out["sem_logits1"] = r.logits[0, -1].numpy()
+        ids, margins, eos = greedy_semantic_loop(sem, prompt, n_greedy)
+        out["greedy_ids"] = ids; out["greedy_margins"] = margins; out["greedy_eos_p"] = eos
+        del sem
+        hp, tens = mf["coarse"]
+        co = use_tanh_gelu(build_hf_gpt(hp, tens, fine=False))
+        cprompt = np.concatenate([rng.integers(0, 10000, 256), [12050], rng.integers(10000, 12048, 43)]).astype(np.int64)
+        r = co(input_ids=torch.from_numpy(cprompt)[None], use_cache=True)
+        out["coarse_prompt"] = cprompt.astype(np.int32)
+        out["coarse_logits0"] = r.logits[0, -1].numpy()
+        r = co(input_ids=torch.tensor([[10777]]), past_key_values=r.past_key_values, use_cache=True)
+        out["coarse_logits1"] = r.logits[0, -1].numpy()
+        del co
+        hp, tens = mf["fine"]
+        fi = use_tanh_gelu(build_hf_gpt(hp, tens, fine=True))
+        ftok = rng.integers(0, 1024, (8, 1024)).astype(np.int64)
+        ftok[:, 900:] = 1024
+        out["fine_tokens"] = ftok.astype(np.int32)
+        rows = np.array([0, 1, 7, 100, 511, 512, 899, 900, 1023])
+        out["fine_rows"] = rows.astype(np.int32)
+        r = fi(codebook_idx=3, input_ids=torch.from_numpy(ftok.T.copy())[None])
+        out["fine_logits_nn3"] = r.logits[0, rows].numpy()
+    dst = os.path.join(ROOT, "tests", "golden", f"hf_{preset}_tanh_s0.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes;", len(out["greedy_ids"]), "greedy ids, smallest top-2 margin", float(out["greedy_margins"].min()))
+
+
 def main():
     import torch
 
+    if len(sys.argv) > 1 and sys.argv[1] == "tanh":
+        main_tanh(sys.argv[2] if len(sys.argv) > 2 else "small", int(sys.argv[3]) if len(sys.argv) > 3 else 64)
+        return
     torch.set_num_threads(4)
     path = ensure_model("toy", 0)
     mf = read_model_file(path)
