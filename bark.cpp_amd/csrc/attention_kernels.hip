@@ -448,12 +448,13 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
     // every stream is a buffer load: uniform base + lane offset + scalar offset (device_utils.h).  The keys below 256 ng (the launch's
     // bound on the context, a preloaded argument) are requested at once; should the context be longer, the others follow once its
     // length has arrived from the device-resident state.
-    const BufRsrc pr = buf_rsrc(reinterpret_cast<const float4 *>(ps) + (size_t) h * P);
+    const BufRsrc pr = buf_rsrc(ps + (size_t) h * 4 * P);                // [H][4][P]: block b of key j at b * P + j
     const BufRsrc vr = buf_rsrc(reinterpret_cast<const float4 *>(vt) + ((size_t) h * 16 + s) * P);      // quad s of every key: contiguous
     float4 p4 = {0.0f, 0.0f, 0.0f, 0.0f}, va = p4;
     float s_new = -INFINITY;
     if (wave < 4 * ng) {
-        p4 = buf_ld_f4(pr, (unsigned) tid * 16u, 0u);
+        p4.x = buf_ld_f32(pr, (unsigned) tid * 4u, 0u); p4.y = buf_ld_f32(pr, (unsigned) tid * 4u, 4096u);
+        p4.z = buf_ld_f32(pr, (unsigned) tid * 4u, 8192u); p4.w = buf_ld_f32(pr, (unsigned) tid * 4u, 12288u);
         va = buf_ld_f4(vr, (unsigned) tid * 16u, 0u);
     }
     if (wave == SNEW_WAVE) {
@@ -471,7 +472,8 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
     }
     const int ctx = st->n_past + 1;
     if (wave >= 4 * ng && wave * 64 < ctx) {
-        p4 = buf_ld_f4(pr, (unsigned) tid * 16u, 0u);
+        p4.x = buf_ld_f32(pr, (unsigned) tid * 4u, 0u); p4.y = buf_ld_f32(pr, (unsigned) tid * 4u, 4096u);
+        p4.z = buf_ld_f32(pr, (unsigned) tid * 4u, 8192u); p4.w = buf_ld_f32(pr, (unsigned) tid * 4u, 12288u);
         va = buf_ld_f4(vr, (unsigned) tid * 16u, 0u);
     }
     float sc = -INFINITY;

@@ -274,6 +274,57 @@ void launch_lstm_step(hipStream_t s, const LstmStepArgs & a) {
     hipLaunchKernelGGL(lstm_step_kernel, dim3((a.D + 3) / 4), dim3(256), 0, s, a);
 }
 
+// one unit (d) of one layer at one step: the four gates in the four 16-lane groups of the wave, C1 dots, gate non-linearities in
+// double precision rounded once (C9), state update by lane 0
+__device__ __forceinline__ float lstm_dot(const half_t * wrow, const half_t * hrow, int nblk) {
+    float acc = 0.0f;
+    for (int b = 0; b < nblk; b++) {
+        const half8 wv = *reinterpret_cast<const half8 *>(wrow + (b << 7));
+        const half8 hv = *reinterpret_cast<const half8 *>(hrow + (b << 7));
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[e], (float) hv[e], acc);
+    }
+    acc = acc + __shfl_xor(acc, 1, 64); acc = acc + __shfl_xor(acc, 2, 64);
+    acc = acc + __shfl_xor(acc, 4, 64); acc = acc + __shfl_xor(acc, 8, 64);
+    return acc;
+}
+__global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int D = a.D, nblk = D >> 7, nb1 = (D + 3) >> 2;
+    const int i = a.t_base ? a.t_base[0] + a.t : a.t;              // launch index: layer 1 at step i, layer 2 at step i - 1
+    const int T = a.t_base ? a.t_base[1] : a.T;
+    const bool second = (int) blockIdx.x >= nb1;
+    const int d = ((int) blockIdx.x - (second ? nb1 : 0)) * 4 + wave;
+    const int t = second ? i - 1 : i;
+    if (d >= D || t < 0 || t >= T) return;
+    const size_t row = (size_t) (g * D + d);
+    float gi, gh = 0.0f, bi, bh;
+    if (!second) {
+        gi = a.gi1[(size_t) t * 4 * D + row]; bi = a.b_ih1[row]; bh = a.b_hh1[row];
+        if (t) gh = lstm_dot(a.w_hh1 + row * D + (c << 3), a.h1 + (size_t) (t - 1) * D + (c << 3), nblk);
+    } else {
+        bi = a.b_ih2[row]; bh = a.b_hh2[row];
+        gi = lstm_dot(a.w_ih2 + row * D + (c << 3), a.h1 + (size_t) t * D + (c << 3), nblk);          // W_ih2 . f16(h1_t)
+        if (t) gh = lstm_dot(a.w_hh2 + row * D + (c << 3), a.h2 + (size_t) (t - 1) * D + (c << 3), nblk);
+    }
+    const float pre = (gi + bi) + (gh + bh);                   // (gi + b_ih) + (gh + b_hh)
+    const float act = g == 2 ? (float) tanh((double) pre) : 1.0f / (1.0f + (float) exp((double) (-pre)));
+    const float i_t = __shfl(act, 0, 64), f_t = __shfl(act, 16, 64), g_t = __shfl(act, 32, 64), o_t = __shfl(act, 48, 64);
+    if (lane == 0) {
+        float * cs = second ? a.c2 : a.c1;
+        const float cprev = t ? cs[d] : 0.0f;
+        const float cn = f_t * cprev + i_t * g_t;
+        const float hn = o_t * (float) tanh((double) cn);
+        cs[d] = cn;
+        (second ? a.h2 : a.h1)[(size_t) t * D + d] = to_half(hn);
+        if (second) a.out2[(size_t) d * T + t] = hn;
+    }
+}
+void launch_lstm_pair_step(hipStream_t s, const LstmPairArgs & a) {
+    hipLaunchKernelGGL(lstm_pair_step_kernel, dim3(2 * ((a.D + 3) / 4)), dim3(256), 0, s, a);
+}
+
 __global__ void add_int_kernel(int * p, int v) { *p += v; }      // p[0]: step base of the replayed LSTM block
 void launch_add_int(hipStream_t s, int * p, int v) { hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, s, p, v); }
 __global__ void add_kernel(const float * a, const float * b, size_t n, float * out) {

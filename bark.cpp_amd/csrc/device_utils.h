@@ -122,6 +122,12 @@ template <int K> DEVINL double div_by_const(double a) {
 DEVINL unsigned f32_ordered(float f) { const unsigned b = __builtin_bit_cast(unsigned, f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 DEVINL float f32_unordered(unsigned u) { const unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; return __builtin_bit_cast(float, b); }
 DEVINL half8 ld_half8(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
+// weight rows a decode step reads exactly once: non-temporal (A/B build -DBARK_NT_WEIGHTS; plain otherwise)
+#ifdef BARK_NT_WEIGHTS
+DEVINL half8 ld_half8_w(const half_t * p) { return __builtin_nontemporal_load(reinterpret_cast<const half8 *>(p)); }
+#else
+DEVINL half8 ld_half8_w(const half_t * p) { return *reinterpret_cast<const half8 *>(p); }
+#endif
 // f32 -> f16, round to nearest even, of an ALREADY ROUNDED f32 value.  The empty asm keeps hipcc from
 // folding the producing multiply/add into v_fma_mixlo_f16, which rounds the exact result once and
 // differs from the CPU's two roundings in about one of 2^13 cases.

@@ -83,7 +83,7 @@ struct bark_context {
     // GPT scratch
     float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
     float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)
-    float * ps = nullptr;                               // [H][P][4] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
+    float * ps = nullptr;                               // [H][4][P] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;
@@ -100,7 +100,7 @@ struct bark_context {
     // codec scratch (grown on demand)
     float * cbuf[3] = {nullptr, nullptr, nullptr}; size_t cbuf_elems = 0;
     barkhip::half_t * cbuf_h = nullptr; size_t cbuf_h_elems = 0;
-    float * c_gi = nullptr, * c_cell = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr; size_t c_T = 0;
+    float * c_gi = nullptr, * c_cell = nullptr, * c_cell2 = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr, * c_hseq2_h = nullptr; size_t c_T = 0;
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
     hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook
     int * d_lstm_t = nullptr;                           // step counter of the replayed LSTM block

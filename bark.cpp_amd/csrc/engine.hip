@@ -658,6 +658,8 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
         c->c_cell = dev_alloc<float>(c, (size_t) D);
         c->c_hseq_h = dev_alloc<half_t>(c, (size_t) T * D);
         c->c_xt_h = dev_alloc<half_t>(c, (size_t) T * D);
+        c->c_hseq2_h = dev_alloc<half_t>(c, (size_t) T * D);
+        c->c_cell2 = dev_alloc<float>(c, (size_t) D);
         c->c_T = (size_t) T;
     }
     if ((size_t) n_q * T > c->d_codes_elems) { c->d_codes = dev_alloc<int32_t>(c, (size_t) n_q * T); c->d_codes_elems = (size_t) n_q * T; }
@@ -675,6 +677,42 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
     launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, T, A);
     conv(cm.init, A, false, T, nullptr, B);                            // B = x [D][T]
     // 2-layer LSTM + skip (modeling_encodec.py:236-249)
+    static const bool lstm_pair = !getenv("BARK_HIP_LSTM_PAIR") || atoi(getenv("BARK_HIP_LSTM_PAIR")) != 0;
+    if (lstm_pair) {
+        // both layers as a wave front: launch i = layer 1 at step i + layer 2 at step i - 1 (its input projection formed in the same
+        // kernel): T + 1 strictly sequential launches instead of 2 T.  64 of them are captured once as a hipGraph whose nodes take
+        // their launch index from a device counter, so one graph serves every T.
+        launch_transpose_round(s, B, D, T, c->c_xt_h);
+        LinArgs g;
+        g.W = cm.lstm[0].w_ih; g.M = 4 * D; g.K = D; g.N = T; g.x_f16 = c->c_xt_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
+        launch_linear(s, g);
+        LstmPairArgs a;
+        a.gi1 = c->c_gi; a.w_hh1 = cm.lstm[0].w_hh; a.b_ih1 = cm.lstm[0].b_ih; a.b_hh1 = cm.lstm[0].b_hh; a.c1 = c->c_cell; a.h1 = c->c_hseq_h;
+        a.w_ih2 = cm.lstm[1].w_ih; a.w_hh2 = cm.lstm[1].w_hh; a.b_ih2 = cm.lstm[1].b_ih; a.b_hh2 = cm.lstm[1].b_hh; a.c2 = c->c_cell2; a.h2 = c->c_hseq2_h;
+        a.out2 = R; a.T = T; a.D = D;
+        if (!c->use_graph) {
+            for (int i = 0; i <= T; i++) { a.t = i; launch_lstm_pair_step(s, a); }
+        } else {
+            constexpr int kBlock = 64;
+            auto & slot = c->lstm_graphs[0];
+            if (slot.exec && (slot.hseq != R || slot.gi != c->c_gi || slot.T != -1)) { (void) hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+            if (!slot.exec) {
+                hipGraph_t graph = nullptr;
+                HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                a.t_base = c->d_lstm_t;
+                for (int i = 0; i < kBlock; i++) { a.t = i; launch_lstm_pair_step(s, a); }
+                launch_add_int(s, c->d_lstm_t, kBlock);
+                HIP_OK(hipStreamEndCapture(s, &graph));
+                HIP_OK(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
+                (void) hipGraphDestroy(graph);
+                slot.T = -1; slot.hseq = R; slot.gi = c->c_gi;       // T = -1 marks the wave-front graph
+            }
+            const int hdr[2] = {0, T};
+            HIP_OK(hipMemcpyAsync(c->d_lstm_t, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
+            HIP_OK(hipStreamSynchronize(s));                         // hdr is a stack object
+            for (int i0 = 0; i0 <= T; i0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
+        }
+    } else {
     const float * lin = B;
     for (int l = 0; l < 2; l++) {
         const half_t * seq_h;
@@ -712,6 +750,7 @@ std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, 
             for (int t0 = 0; t0 < T; t0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
         }
     }
+    }   // !lstm_pair
     auto grab = [&](int stage, const float * buf, size_t n) {
         if (tap_stage != stage || !tap) return;
         tap->resize(n);

@@ -81,7 +81,7 @@ struct LinArgs {
     // EPI_LOGITS: out[n*ld_out + m] = dot (+ bias)
     float * out = nullptr; int ld_out = 0;
     // EPI_QKV, decode, f16 weights: the workgroup that produces 16 consecutive q values (one C2 block of one head) also forms that
-    // block's partial score against every cached key: ps[(h * P + j) * 4 + block], j < n_past (attn_ps_kernel finishes the sum)
+    // block's partial score against every cached key: ps[(h * 4 + block) * P + j], j < n_past (attn_ps_kernel finishes the sum)
     float * ps = nullptr; int ng = 4;     // ng: the context holds at most 256 ng keys (only ng - 1 copies of the q workgroups are launched)
     float * knew = nullptr;               // with ps: the appended K row is also stored here ([E], position independent), so that the attention kernel
                                           // can request it before it knows the context length
@@ -128,7 +128,7 @@ struct AttnDecodeArgs {
     const float * vt = nullptr;           // V in the K layout [H][16][P][4] (attn_ps_kernel)
     int ng = 4;                           // the context holds at most 256 ng keys: those keys are requested at wave launch
     const float * knew = nullptr;         // [E] the K row this step appended (copy at a fixed address, see LinArgs::knew)
-    const float * ps = nullptr;           // [H][P][4] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
+    const float * ps = nullptr;           // [H][4][P] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
     BARK_TRACE_FIELD
@@ -213,6 +213,17 @@ struct LstmStepArgs {
     const int * t_base = nullptr;        // ... added to t_base[0] (device) when non-null; then t_base[1] holds T
 };
 void launch_lstm_step(hipStream_t s, const LstmStepArgs & a);
+// Both LSTM layers as a wave front: launch i runs layer 1 at step i and layer 2 at step i - 1 (whose input projection W_ih2 h1[i-1]
+// is formed in the same kernel, C1 order - the bits of the row-batched product), so a sequence of T frames takes T + 1 dependent
+// launches instead of 2 T.  Layer 1: gi1 = W_ih1 x for all t (launch_linear), w_hh1, biases, cell c1, f16 outputs h1 [T][D].
+// Layer 2: w_ih2, w_hh2, biases, cell c2, f16 outputs h2 [T][D] and the f32 sequence out2 [D][T].
+struct LstmPairArgs {
+    const float * gi1 = nullptr; const half_t * w_hh1 = nullptr; const float * b_ih1 = nullptr, * b_hh1 = nullptr; float * c1 = nullptr; half_t * h1 = nullptr;
+    const half_t * w_ih2 = nullptr, * w_hh2 = nullptr; const float * b_ih2 = nullptr, * b_hh2 = nullptr; float * c2 = nullptr; half_t * h2 = nullptr;
+    float * out2 = nullptr; int T = 0, D = 0;
+    int t = 0; const int * t_base = nullptr;          // launch index, or offset inside a replayed block added to t_base[0] (then t_base[1] holds T)
+};
+void launch_lstm_pair_step(hipStream_t s, const LstmPairArgs & a);
 void launch_add_int(hipStream_t s, int * p, int v);       // *p += v
 void launch_add(hipStream_t s, const float * a, const float * b, size_t n, float * out);
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
         constexpr int G = NBLK;                               // loads in flight per lane and operand
         half8 wv[2][G], xv[2][G];
         #pragma unroll
-        for (int i = 0; i < G; i++) { wv[0][i] = ld_half8(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
+        for (int i = 0; i < G; i++) { wv[0][i] = ld_half8_w(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
         __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
         pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
         #pragma unroll
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
     __builtin_amdgcn_sched_barrier(0);
     half8 wv[NBLK];
     #pragma unroll
-    for (int b = 0; b < NBLK; b++) wv[b] = ld_half8(wrow + (b << 7));
+    for (int b = 0; b < NBLK; b++) wv[b] = ld_half8_w(wrow + (b << 7));
     // partial scores: keys rep * kpc + tid (+ 256); d-quads 4 blk .. 4 blk + 3 of head hq
     [[maybe_unused]] float4 kq[2][4];
     [[maybe_unused]] const int m0 = wg * 16;
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
             #pragma unroll
             for (int i = 0; i < 16; i++) qb[i] = qs[i];
             const int j = rep * kpc + tid;
-            if (j < pre.n_past) a.ps[((size_t) hq * a.P + j) * 4 + blk] = score_block_f4(kq[0], qb);
-            if (tid + 256 < kpc && j + 256 < pre.n_past) a.ps[((size_t) hq * a.P + j + 256) * 4 + blk] = score_block_f4(kq[1], qb);
+            if (j < pre.n_past) a.ps[((size_t) hq * 4 + blk) * a.P + j] = score_block_f4(kq[0], qb);             // [H][4][P]: a workgroup's keys are contiguous
+            if (tid + 256 < kpc && j + 256 < pre.n_past) a.ps[((size_t) hq * 4 + blk) * a.P + j + 256] = score_block_f4(kq[1], qb);
         }
     }
 #ifdef BARK_TRACE
