@@ -62,7 +62,7 @@ def test_committed_bench_line_follows_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r01_bench_small_n1.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r02_bench_small_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
