@@ -112,14 +112,6 @@ def run_shard(ctx, prompts, idx, max_batch: int = 32):
     return pcms
 
 
-def pmc_traffic():
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemv_fc.json")) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
-    except Exception:
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,13 +239,13 @@ def main():
     # of a step, ~37 % of it; profiles/).  Its largest per-layer instance is the FC product (4 E^2 f16 weights = 4.72 MB per launch).
     # `achieved` = algorithmic bytes / average launch duration, measured here with HIP events on the engine's stream over a graph of
     # 48 launches that rotate through the layers' weights.  `traffic`: HBM bytes from PMC counters need a separate rocprofv3 pass
-    # (they cannot be read inside this run): the value is taken from the committed PMC summary of this kernel
-    # (profiles/r02_pmc_gemv_fc.json: FETCH_SIZE x2 as the gfx950 correction prescribes + WRITE_SIZE), null when that file is absent.
+    # (they cannot be read inside this run): null here; profiles/r02_pmc_gemv_fc.json is the PMC summary of this kernel, regenerated
+    # on the final build by the same gpurun call as the committed bench line (tools/collect_profiles.sh).
     try:
         us, nbytes = ctx.time_gemv(0, 2, 2400)
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_ln_wg_kernel<6> (LayerNorm + FC 3072x768 f16 + GELU, decode)",
                            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12,
-                           "traffic": pmc_traffic(), "traffic_note": "bytes per launch from profiles/r02_pmc_gemv_fc.json (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE), not re-measured by this run",
+                           "traffic": None, "traffic_note": "not measurable inside this run; PMC summary of this kernel on the final build: profiles/r02_pmc_gemv_fc.json (4.97 MB per launch = FETCH_SIZE x2 + WRITE_SIZE, against 4.72 MB algorithmic)",
                            "us_per_launch": us, "bytes_per_launch": nbytes}
         gem = {}
         for op, name in enumerate(("ln_qkv_partial_scores", "attn_proj", "ln_fc_gelu", "mlp_proj")):
