@@ -72,6 +72,7 @@ struct bark_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool use_graph = true;
+    bool fast_gemm = false;              // BARK_HIP_FAST_GEMM=1: N > 1 products on the f16 matrix cores in hardware accumulation order (non-canonical)
     int decode_ng = 4;                                  // key groups (of 256) the decode kernels being enqueued may assume: ctx <= 256 ng
 
     // device memory.  The weight slab (and the codec codebooks) are immutable after load and shared by every

@@ -38,6 +38,7 @@ float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.k
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
+    const int fast = (c->fast_gemm && !m.q4 && !m.w32) ? 1 : 0;
     // kbase / vbase: another utterance slot's cache (batched decode); default: the context's own cache
     auto layer_k = [&](const GptModel & mm, int l) { return (kbase ? kbase : mm.kcache) + mm.kv_layer_stride * (size_t) l; };
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
@@ -51,6 +52,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         if (!kbase && !vbase) a.vt = detail::layer_vt(m, l);      // the context's own cache keeps the K-layout copy of V too
+        a.fast = fast;
         launch_linear(s, a);
         AttnPrefillArgs at;
         at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
@@ -60,6 +62,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; if (m.w32) p.x_f32 = c->att32; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.fast = fast;
         launch_linear(s, p);
         if (m.w32)     launch_ln_rows_f32(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn32);
         else if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq);
@@ -67,10 +70,12 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         LinArgs f;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq = c->xq; if (m.w32) f.x_f32 = c->xn32; f.bias = L.fc_b; f.epi = EPI_GELU;
         f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
+        f.fast = fast;
         launch_linear(s, f);
         if (m.q4 && !m.w32) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq);
         LinArgs o;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq = c->xq; if (m.w32) o.x_f32 = c->h32; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.fast = fast;
         launch_linear(s, o);
     }
 }
@@ -352,6 +357,7 @@ void run_fine_forward(bark_context * c, int nn, int n_rows) {
     else           launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
     a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.fast = (c->fast_gemm && !m.q4 && !m.w32) ? 1 : 0;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace detail

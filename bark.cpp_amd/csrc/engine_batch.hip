@@ -70,22 +70,23 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
     // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
     const bool hoist = B >= 24 && !m.q4;
-    // BARK_HIP_BATCH_MFMA=1 (opt-in), B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores
-    // (gemm_slots_kernel); rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend
-    // on the route.  Measured (tools/batch_ab.py, bark-small, 256 semantic steps): 12.4 prompts/s at 32 slots on either route, 6.0
-    // against 8.8 at 8 slots - the 32 x 32 tile pulls its operands straight from L1/L2, one 16-byte chunk per MFMA quartet, and is
-    // load-bound; an LDS-staged tile is the next step before this becomes the default.
-    static const bool mfma_ok = getenv("BARK_HIP_BATCH_MFMA") && atoi(getenv("BARK_HIP_BATCH_MFMA")) != 0;
-    const bool mfma = mfma_ok && B >= 8 && !m.q4;
+    // BARK_HIP_BATCH_MFMA=1|2 (opt-in), B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores;
+    // rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route.
+    //   1: gemm_slots_kernel, 32 x 32 tiles, chains spread over the waves of a workgroup and summed through LDS.  Measured
+    //      (tools/batch_ab.py, bark-small, 256 semantic steps): 12.4 prompts/s at 32 slots on either route, 6.0 against 8.8 at 8 slots:
+    //      24 .. 96 workgroups per product, each a dependent chain of loads and MFMAs.
+    //   2: gemm_slots4_kernel, 4 x 4 x 1 blocks (one block = one chain), 4 weight rows per workgroup.
+    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 0;
+    const bool mfma = mfma_kind != 0 && B >= 8 && !m.q4;
     // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
     static const int dbg = getenv("BARK_HIP_BATCH_DBG") ? atoi(getenv("BARK_HIP_BATCH_DBG")) : 0;
     auto product = [&](LinArgs & a, const float * ln_g, const float * ln_b) {
         if (dbg & 2) return;
-        if (mfma && (dbg & 4)) { a.x_f16 = c->xn; a.x_f32 = nullptr; a.ln_stats = nullptr; launch_linear_slots(st, a); return; }
+        if (mfma && (dbg & 4)) { a.x_f16 = c->xn; a.x_f32 = nullptr; a.ln_stats = nullptr; launch_linear_slots(st, a, mfma_kind); return; }
         if (!mfma) { a.ln_g = ln_g; a.ln_b = ln_b; launch_linear(st, a); return; }
         if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
-        launch_linear_slots(st, a);
+        launch_linear_slots(st, a, mfma_kind);
     };
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];

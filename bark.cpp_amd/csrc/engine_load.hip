@@ -187,6 +187,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("BARK_HIP_DEVICE out of range");
     HIP_OK(hipSetDevice(ctx->device));
     if (const char * e = getenv("BARK_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
+    if (const char * e = getenv("BARK_HIP_FAST_GEMM")) ctx->fast_gemm = atoi(e) != 0;
     HIP_OK(hipStreamCreate(&ctx->stream));
     init_kernel_attributes();
 
@@ -447,7 +448,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
         ctx->gpt[g].bench_graph = nullptr;
     }
     ctx->codec = src->codec;
-    ctx->device = src->device; ctx->use_graph = src->use_graph;
+    ctx->device = src->device; ctx->use_graph = src->use_graph; ctx->fast_gemm = src->fast_gemm;
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
     ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4; ctx->any_w32 = src->any_w32;
     HIP_OK(hipStreamCreate(&ctx->stream));

@@ -606,6 +606,107 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Fast (non-canonical) GEMM for N > 1: v_mfma_f32_32x32x16_f16.  One wave = one 64 x 64 output tile over the whole K; no LDS and no
+// barrier.  Lane (half, l31) feeds the 16-element k step with the 16-byte chunk at k + 8 half of its x row and of its weight row - the
+// instruction's k assignment inside a step does not matter because both operands use the same one.  Products of two f16 values are
+// exact in f32; the 16 products of a step and the running sum are added in the matrix core's order instead of C1's.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gemm_f16_kernel(const LinArgs a) {
+    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
+    const int K = a.K;
+    const half_t * xp[2], * wp[2];
+    #pragma unroll
+    for (int t = 0; t < 2; t++) {
+        xp[t] = a.x_f16 + (size_t) min(n0 + t * 32 + l31, a.N - 1) * K + (half << 3);
+        wp[t] = a.W + (size_t) min(m0 + t * 32 + l31, a.M - 1) * K + (half << 3);
+    }
+    floatx16 acc[2][2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    // four k steps (64 elements) per buffer, two buffers: the loads of the next 64 elements are in flight while 16 MFMAs issue
+    half8 xa0[4][2], wb0[4][2], xa1[4][2], wb1[4][2];
+#define F16_LOAD(XA, WB, K0)                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                      \
+            XA[q][t] = ld_half8(xp[t] + (K0) + 16 * q);                                                      \
+            WB[q][t] = ld_half8(wp[t] + (K0) + 16 * q);                                                      \
+        }
+#define F16_MFMA(XA, WB)                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; i++)                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; j++)                                                    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(XA[q][i], WB[q][j], acc[i][j], 0, 0, 0);
+    F16_LOAD(xa0, wb0, 0)
+    for (int k = 0; k < K; k += 128) {                          // K is a multiple of 128
+        F16_LOAD(xa1, wb1, k + 64)
+        __builtin_amdgcn_sched_barrier(0);
+        F16_MFMA(xa0, wb0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 128 < K) { F16_LOAD(xa0, wb0, k + 128) }
+        __builtin_amdgcn_sched_barrier(0);
+        F16_MFMA(xa1, wb1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef F16_LOAD
+#undef F16_MFMA
+    // accumulator register r of lane (half, l31): x row (r & 3) + 8 (r >> 2) + 4 half of the tile, weight row l31: for a fixed r the 32
+    // lanes of a half write 32 consecutive columns of one row.  The operator switch sits outside the element loops.
+    const int n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
+    #pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int m = m0 + j * 32 + l31;
+        if (m >= a.M) continue;
+        const float bias = a.bias ? a.bias[m] : 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int nb = n0 + i * 32 + 4 * half;
+            float v[16];
+            #pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = a.bias ? acc[i][j][r] + bias : acc[i][j][r];
+            switch (a.epi) {
+                case EPI_RESID: {
+                    float old[16];
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); old[r] = n < a.N ? a.res[(size_t) n * a.M + m] : 0.0f; }
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); if (n < a.N) a.res[(size_t) n * a.M + m] = v[r] + old[r]; }
+                    break;
+                }
+                case EPI_GELU: {
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int n = nb + (r & 3) + 8 * (r >> 2);
+                        if (n < a.N) a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v[r], a.lut);
+                    }
+                    break;
+                }
+                case EPI_QKV: {
+                    const int E = a.E;
+                    const int mm = m < E ? m : m < 2 * E ? m - E : m - 2 * E;
+                    const int h = mm >> 6, d = mm & 63;
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int n = nb + (r & 3) + 8 * (r >> 2);
+                        if (n >= a.N) continue;
+                        const int pos = a.pos0 + n_past + n;
+                        if (m < E) a.q[(size_t) n * E + m] = v[r];
+                        else if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v[r];
+                        else { a.vc[vc_index(h, d, pos, a.P)] = v[r]; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v[r]; }
+                    }
+                    break;
+                }
+                default: {
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); if (n < a.N) a.out[(size_t) n * a.ld_out + m] = v[r]; }
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Lock-step decode product on the f32 matrix cores: y[slot][m] for up to 32 utterance slots at once, so that a step reads every weight
 // ONCE for all slots (gemv_batch_kernel re-reads them from L2 per pair of slots on the VALU: 1.6 ms per step at 32 slots).
 // Tile: 32 slots (MFMA A rows) x 32 weight rows (B rows); 8 waves, wave w owns chains 2w and 2w+1 of C1 (one accumulator = one fmaf
@@ -686,9 +787,123 @@ __global__ __launch_bounds__(512) void gemm_slots_kernel(const LinArgs a) {
         }
     }
 }
-void launch_linear_slots(hipStream_t s, const LinArgs & a) {
+
+// ------------------------------------------------------------------------------------------------
+// Lock-step decode product, fine-grained formulation.  v_mfma_f32_4x4x1_16b_f32 issues SIXTEEN independent 4x4x1 blocks, one fused
+// multiply-add per element and issue (tools/probes/mfma4x4_probe.hip checks layout and exactness on the device) - block b is chain b
+// of C1: lane l = 4 b + r feeds the block with weight row r and slot r of the chain's current element, and a sequence of issues walks
+// the chain's chunks (16 i + b, i ascending) element by element.  All 16 chains of a (4 rows x 4 slots) tile therefore live in ONE
+// accumulator of ONE wave and meet by a lane butterfly (xor 4, 8, 16, 32 = C1's tree) - no LDS, no barrier, and the tile is small
+// enough that even a 768-row product spreads over 192 workgroups.  (gemm_slots_kernel needs 32-row tiles: 24 workgroups for the same
+// product, each serialising 4 waves per SIMD on a dependent chain of MFMAs.)
+// Workgroup = 4 waves = 4 weight rows x 32 slots; wave w owns slots 8w .. 8w+7 as two accumulators.  The matrix cores run f32 at the
+// packed-VALU rate, so this is not about FLOPs: an issue consumes 2 operand registers for 256 multiply-adds where v_fma_f32 consumes
+// 2 for 64, and every weight is read from HBM once per step instead of once per pair of slots.
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+DEVINL float half_of(const uint4 & u, int e) {                 // element e (compile-time) of eight packed f16 values, widened
+    const unsigned word = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
+    return (float) __builtin_bit_cast(half_t, (unsigned short) ((e & 1) ? (word >> 16) : word));
+}
+DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
+
+template <int NBLK, bool ROWS_IN_LANES>
+__global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
+                                                          const LinArgs a) {
+    constexpr int K = NBLK * 128;
+    constexpr int G = NBLK < 8 ? NBLK : 8, NG = NBLK / G;        // chunk rounds per load group
+    static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = lane >> 2, r = lane & 3;
+    const int m0 = blockIdx.x * 4;
+    if (8 * w >= a.nbatch) return;                               // a wave without live slots (the kernel has no barrier)
+    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
+    const half_t * wrow = W + (size_t) (row_off + min(m0 + r, M - 1)) * K + (b << 3);
+    const half_t * xr0 = X + (size_t) min(8 * w + r, a.nbatch - 1) * K + (b << 3);
+    const half_t * xr1 = X + (size_t) min(8 * w + 4 + r, a.nbatch - 1) * K + (b << 3);
+    // after the butterfly every lane holds every total of its slot column; lanes of blocks 0..7 finish one output each
+    const int ev = b & 3, eg = (b >> 2) & 1;
+    const int en = 8 * w + 4 * eg + r, em = m0 + ev;
+    const bool elive = b < 8 && en < a.nbatch && em < M;
+    const EpiPre pre = epilogue_prefetch(a, elive ? en : 0, elive ? em : 0, row_off);
+
+    floatx4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint4 wa[G], xa0[G], xa1[G], wb[G], xb0[G], xb1[G];
+#define SLOTS4_LOAD(WV, X0, X1, GI)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
+        WV[i] = ld_u4(wrow + (((GI) * G + i) << 7));                                                         \
+        X0[i] = ld_u4(xr0 + (((GI) * G + i) << 7));                                                          \
+        X1[i] = ld_u4(xr1 + (((GI) * G + i) << 7));                                                          \
+    }
+#define SLOTS4_MFMA(WV, X0, X1)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                      \
+            const float wf = half_of(WV[i], e), x0 = half_of(X0[i], e), x1 = half_of(X1[i], e);              \
+            if constexpr (ROWS_IN_LANES) {                                                                   \
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, wf, acc0, 0, 0, 0);                            \
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, wf, acc1, 0, 0, 0);                            \
+            } else {                                                                                         \
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x0, acc0, 0, 0, 0);                            \
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x1, acc1, 0, 0, 0);                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+    SLOTS4_LOAD(wa, xa0, xa1, 0)
+    #pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) { SLOTS4_LOAD(wb, xb0, xb1, g + 1) }
+        __builtin_amdgcn_sched_barrier(0);                       // the next group's loads stay ahead of this group's MFMAs
+        SLOTS4_MFMA(wa, xa0, xa1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) {
+            if (g + 2 < NG) { SLOTS4_LOAD(wa, xa0, xa1, g + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            SLOTS4_MFMA(wb, xb0, xb1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef SLOTS4_LOAD
+#undef SLOTS4_MFMA
+    // register v of lane 4 b + r: weight row v, slot (4 g + r) of this wave, chain b
+    float t[8];
+    #pragma unroll
+    for (int v = 0; v < 4; v++) { t[v] = acc0[v]; t[4 + v] = acc1[v]; }
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        t[i] = t[i] + __shfl_xor(t[i], 4);
+        t[i] = t[i] + __shfl_xor(t[i], 8);
+        t[i] = t[i] + __shfl_xor(t[i], 16);
+        t[i] = t[i] + __shfl_xor(t[i], 32);
+    }
+    float mine = t[0];
+    #pragma unroll
+    for (int i = 1; i < 8; i++) mine = (4 * eg + ev) == i ? t[i] : mine;
+    if (elive) linear_epilogue_pre(a, en, em, mine, pre);
+}
+
+template <int NBLK>
+static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes) {
+    dim3 grid((a.M + 3) / 4), block(256);
+    if (rows_in_lanes) hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, true>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    else               hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+}
+
+void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
     if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
-    hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a);
+    if (kind == 1) { hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a); return; }
+    // with rows in lanes the two operands trade places: the result register then indexes the slot instead of the weight row
+    static const bool rows_in_lanes = getenv("BARK_HIP_MFMA4_ROWS_IN_LANES") && atoi(getenv("BARK_HIP_MFMA4_ROWS_IN_LANES")) != 0;
+    switch (a.K >> 7) {
+        case 1:  launch_slots4_n<1>(s, a, rows_in_lanes); break;
+        case 2:  launch_slots4_n<2>(s, a, rows_in_lanes); break;
+        case 4:  launch_slots4_n<4>(s, a, rows_in_lanes); break;
+        case 6:  launch_slots4_n<6>(s, a, rows_in_lanes); break;
+        case 8:  launch_slots4_n<8>(s, a, rows_in_lanes); break;
+        case 16: launch_slots4_n<16>(s, a, rows_in_lanes); break;
+        case 24: launch_slots4_n<24>(s, a, rows_in_lanes); break;
+        case 32: launch_slots4_n<32>(s, a, rows_in_lanes); break;
+        default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
+    }
 }
 
 void launch_linear(hipStream_t s, const LinArgs & a) {
@@ -730,6 +945,10 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     if (force_rows) {
         dim3 grid((a.M + 15) / 16, a.N), block(256);
         hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
+        return;
+    }
+    if (a.fast) {
+        hipLaunchKernelGGL(gemm_f16_kernel, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(64), 0, s, a);
         return;
     }
     dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);

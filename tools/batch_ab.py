@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the lock-step batch path (BARK_HIP_BATCH_MFMA=0/1): prompts/s at B = 8 and 32, each arm in a fresh process."""
+"""A/B of the lock-step batch path (BARK_HIP_BATCH_MFMA=0/1/2): prompts/s at B = 8 and 32, each arm in a fresh process."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -20,9 +20,11 @@ for B in (8, 32):
     ctx.free()
 print("RESULT", json.dumps(out))
 ''' % ROOT
-arms = [("valu", {"BARK_HIP_BATCH_MFMA": "0"}), ("mfma", {"BARK_HIP_BATCH_MFMA": "1"})]
-for a in sys.argv[1:]:
-    arms.append((a, dict(kv.split("=") for kv in a.split(","))))
+# arms: NAME[:K=V,K=V...] on the command line; default: the VALU route against the two MFMA routes
+arms = []
+for a in sys.argv[1:] or ["valu:BARK_HIP_BATCH_MFMA=0", "mfma32:BARK_HIP_BATCH_MFMA=1", "mfma4:BARK_HIP_BATCH_MFMA=2"]:
+    name, _, kv = a.partition(":")
+    arms.append((name, dict(x.split("=") for x in kv.split(",") if x)))
 for name, env in arms:
     e = dict(os.environ); e.update(env)
     p = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True)
