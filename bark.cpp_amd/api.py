@@ -69,7 +69,7 @@ EXPORTS = [
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
-    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_fine_pass", "bark_hip_describe",
+    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
 
 
@@ -127,6 +127,8 @@ def load_library() -> C.CDLL:
     lib.bark_hip_time_decode_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_time_gemv.restype = C.c_double
     lib.bark_hip_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.bark_hip_time_slots.restype = C.c_double
+    lib.bark_hip_time_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.bark_hip_time_fine_pass.restype = C.c_double
     lib.bark_hip_time_fine_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_describe.restype = C.c_char_p
@@ -361,6 +363,12 @@ class BarkContext:
         if us < 0:
             raise RuntimeError("bark_hip_time_gemv failed")
         return us, b.value
+
+    def time_slots(self, which: int, op: int, n_slots: int, kind: int, ctx: int, iters: int) -> float:
+        us = self._lib.bark_hip_time_slots(self._h, which, op, n_slots, kind, ctx, iters)
+        if us < 0:
+            raise RuntimeError("bark_hip_time_slots failed")
+        return us
 
     def time_fine_pass(self, iters: int):
         f = C.c_double(0)

@@ -274,6 +274,10 @@ double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * f
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_fine_pass", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass); });
 }
+double bark_hip_time_slots(struct bark_context * bctx, int which, int op, int n_slots, int kind, int ctx, int iters) {
+    if (!bctx) return -1.0;
+    return guarded("bark_hip_time_slots", -1.0, [&] { return engine_time_slots(bctx, which, op, n_slots, kind, ctx, iters); });
+}
 #ifdef BARK_TRACE
 __attribute__((visibility("default"))) int bark_hip_trace_decode_step(struct bark_context * bctx, int which, int ctx, int replays, unsigned long long * out6, int cap_records) {
     if (!bctx || !out6) return -1;

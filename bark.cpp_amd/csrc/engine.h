@@ -158,6 +158,7 @@ int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);
 double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass);
+double engine_time_slots(bark_context * c, int which, int op, int B, int kind, int ctxlen, int iters);
 #ifdef BARK_TRACE
 int engine_trace_decode_step(bark_context * ctx, int which, int ctxlen, int replays, unsigned long long * out6, int cap_records);
 #endif

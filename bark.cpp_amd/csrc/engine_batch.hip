@@ -70,13 +70,15 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
     // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
     const bool hoist = B >= 24 && !m.q4;
-    // BARK_HIP_BATCH_MFMA=1|2 (opt-in), B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores;
-    // rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route.
-    //   1: gemm_slots_kernel, 32 x 32 tiles, chains spread over the waves of a workgroup and summed through LDS.  Measured
-    //      (tools/batch_ab.py, bark-small, 256 semantic steps): 12.4 prompts/s at 32 slots on either route, 6.0 against 8.8 at 8 slots:
-    //      24 .. 96 workgroups per product, each a dependent chain of loads and MFMAs.
-    //   2: gemm_slots4_kernel, 4 x 4 x 1 blocks (one block = one chain), 4 weight rows per workgroup.
-    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 0;
+    // B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores; rows are normalised to f16 by
+    // ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route (tools/check_routes.py,
+    // test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA selects it:
+    //   2 (default): gemm_slots4_kernel, 4 x 4 x 1 blocks (one block = one chain), 4 weight rows per workgroup
+    //   1: gemm_slots_kernel, 32 x 32 tiles, chains spread over the waves of a workgroup and summed through LDS
+    //   0: the VALU GEMV per pair of slots (the only route for fewer than 8 slots and for quantised files)
+    // Measured per launch at 32 slots, bark-small (tools/time_slots.py; QKV / proj / FC / MLP proj, us): route 0: 17.2 / 4.4 / 22.7 / 12.7,
+    // route 1: 9.3 / 8.1 / 8.7 / 24.0, route 2: 9.5 / 5.0 / 9.1 / 12.0; whole job 13.1 -> 15.4 prompts/s (tools/batch_ab.py).
+    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 2;
     const bool mfma = mfma_kind != 0 && B >= 8 && !m.q4;
     // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
     static const int dbg = getenv("BARK_HIP_BATCH_DBG") ? atoi(getenv("BARK_HIP_BATCH_DBG")) : 0;
@@ -211,6 +213,82 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
 }
 
 }  // namespace
+
+// One lock-step decode kernel for B slots, launched back to back (hipGraph of 48 nodes) while rotating through the layers' weights.
+// op: 0 QKV, 1 attention out-proj, 2 FC + GELU, 3 MLP out-proj, 4 LayerNorm of the B rows to f16, 5 attention of every slot at context
+// `ctxlen`.  kind: route of the products - 0 the VALU GEMV (LayerNorm fused for ops 0 / 2), >= 1 launch_linear_slots(kind) on rows
+// that are already normalised.  Returns the average device time per launch in microseconds.
+double engine_time_slots(bark_context * c, int which, int op, int B, int kind, int ctxlen, int iters) {
+    if (which < 0 || which > 1 || op < 0 || op > 5 || B < 1 || B > 32) throw std::runtime_error("time_slots: bad arguments");
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    if (m.q4 || c->any_w32) throw std::runtime_error("time_slots: f16 model files only");
+    ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
+    bark_context::Batch & bb = c->batch;
+    if (B > bb.cap) throw std::runtime_error("time_slots: batch larger than the capacity fixed by the first call");
+    const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
+    ctxlen = std::max(2, std::min(ctxlen, m.hp.block_size));
+    std::vector<StepState> sts((size_t) B, fresh_state());
+    for (auto & v : sts) { v.n_past = ctxlen - 1; v.cur_token = 1; }
+    HIP_OK(hipMemcpyAsync(bb.state, sts.data(), sizeof(StepState) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemsetAsync(bb.x, 0, (size_t) B * E * 4, c->stream));
+    HIP_OK(hipMemsetAsync(bb.q, 0, (size_t) B * E * 4, c->stream));
+    HIP_OK(hipMemsetAsync(bb.att, 0, (size_t) B * E * 2, c->stream));
+    HIP_OK(hipMemsetAsync(bb.h, 0, (size_t) B * 4 * E * 2, c->stream));
+    HIP_OK(hipMemsetAsync(bb.ln_stats, 0, (size_t) B * 2 * 4, c->stream));
+    HIP_OK(hipMemsetAsync(c->xn, 0, (size_t) B * 4 * E * 2, c->stream));
+    if (op == 5) {
+        HIP_OK(hipMemsetAsync(bb.kc[which], 0, bb.slot_stride[which] * (size_t) B * 4, c->stream));
+        HIP_OK(hipMemsetAsync(bb.vc[which], 0, bb.slot_stride[which] * (size_t) B * 4, c->stream));
+    }
+    const size_t slot = bb.slot_stride[which];
+    auto launch = [&](int l) {
+        const GptModel::Layer & L = m.layers[(size_t) l];
+        float * kl = bb.kc[which] + m.kv_layer_stride * (size_t) l, * vl = bb.vc[which] + m.kv_layer_stride * (size_t) l;
+        if (op == 4) { launch_ln_rows(c->stream, bb.x, B, E, L.ln1_g, L.ln1_b, c->xn); return; }
+        if (op == 5) {
+            AttnDecodeArgs at;
+            at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
+            at.nbatch = B; at.kv_slot_stride = slot;
+            launch_attn_decode_part(c->stream, at, 4);
+            return;
+        }
+        LinArgs a;
+        a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.N = 1;
+        switch (op) {
+            case 0: a.W = L.attn_w; a.M = 3 * E; a.K = E; a.bias = L.attn_b; a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.st = bb.state;
+                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; } else a.x_f16 = c->xn;
+                    break;
+            case 1: a.W = L.proj_w; a.M = E; a.K = E; a.x_f16 = bb.att; a.bias = L.proj_b; a.epi = EPI_RESID; a.res = bb.x; break;
+            case 2: a.W = L.fc_w; a.M = 4 * E; a.K = E; a.bias = L.fc_b; a.epi = EPI_GELU; a.out_h = bb.h; a.lut = c->d_gelu_lut;
+                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; } else a.x_f16 = c->xn;
+                    break;
+            default: a.W = L.mproj_w; a.M = E; a.K = 4 * E; a.x_f16 = bb.h; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = bb.x; break;
+        }
+        if (kind == 0) launch_linear(c->stream, a); else launch_linear_slots(c->stream, a, kind);
+    };
+    const int per_graph = 48;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    try { for (int i = 0; i < per_graph; i++) launch(i % m.hp.n_layer); }
+    catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
+    HIP_OK(hipStreamEndCapture(c->stream, &graph));
+    HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void) hipGraphDestroy(graph);
+    HIP_OK(hipGraphLaunch(exec, c->stream));
+    const int reps = std::max(1, iters / per_graph);
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < reps; i++) HIP_OK(hipGraphLaunch(exec, c->stream));
+    HIP_OK(hipEventRecord(e1, c->stream));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    (void) hipGraphExecDestroy(exec);
+    return (double) ms * 1000.0 / (reps * per_graph);
+}
 
 int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds) {
     HIP_OK(hipSetDevice(c->device));

@@ -121,6 +121,12 @@ BARK_API double bark_hip_time_decode_step(struct bark_context * bctx, int which,
  * *bytes_per_launch receives the algorithmic bytes (the weight matrix in the file's format: f16, f32 or blocks). */
 BARK_API double bark_hip_time_gemv(struct bark_context * bctx, int which, int op, int iters, double * bytes_per_launch);
 
+/* Device time (us) of ONE lock-step decode kernel over n_slots utterance slots (the kernels of bark_hip_generate_batch), averaged over
+ * `iters` back-to-back launches that rotate through the layers' weights.  op: 0 QKV, 1 attention out-proj, 2 FC + GELU, 3 MLP out-proj,
+ * 4 LayerNorm of the slot rows, 5 attention of every slot at context `ctx`.  kind: route of the products (0 VALU GEMV with the LayerNorm
+ * fused, 1 = 32 x 32 MFMA tiles, 2 = 4 x 4 MFMA blocks).  f16 model files only. */
+BARK_API double bark_hip_time_slots(struct bark_context * bctx, int which, int op, int n_slots, int kind, int ctx, int iters);
+
 /* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
 BARK_API double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass);
 

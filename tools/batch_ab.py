@@ -11,7 +11,7 @@ import bench
 pkg = load_package()
 prompts = bench.synth_prompts(64)
 out = {}
-for B in (8, 32):
+for B in [int(v) for v in os.environ.get("BATCH_AB_SIZES", "8,32").split(",")]:
     ctx = pkg.BarkContext.load_model(ensure_model("small", 0), pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=256), 0)
     ctx.generate_batch(prompts[:B])
     t0 = time.perf_counter(); res = ctx.generate_batch(prompts[B:2 * B]); dt = time.perf_counter() - t0
