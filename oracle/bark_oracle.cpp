@@ -496,8 +496,9 @@ static void layer_norm_row(const float * x, float * y, int E, const float * g, c
         y[i] = v;
     }
 }
-static void round_rows(const Oracle & o, float * x, size_t n) {
+static void round_rows(const Oracle & o, float * x, size_t n, int nth = 1) {
     if (!o.num.act_round_f16) return;
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && n >= 65536)
     for (size_t i = 0; i < n; i++) x[i] = round_h(x[i]);
 }
 // ggml_soft_max over one row of `n` valid entries: max, exp, double sum, scale by (float)(1/sum).
@@ -557,14 +558,50 @@ static float dot_q_q8(int qtype, const uint8_t * wrow, const Q8Row & x, int K) {
     for (int st = 1; st < 16; st <<= 1) for (int c = 0; c < 16; c += 2 * st) acc[c] = acc[c] + acc[c + st];
     return acc[0];
 }
+// the same value as dot_q_q8 for a weight row that has been unpacked once (levels as int8, block scales as floats): the block sums are
+// exact integers and every float operation is the one dot_q_q8 performs, in the same order
+static float dot_unpacked_q8(int qtype, const int8_t * wq, const float * dws, const float * mws, const Q8Row & x, int K) {
+    float acc[16];
+    for (float & a : acc) a = 0.0f;
+    for (int b = 0; b < K / 32; b++) {
+        const int8_t * w = wq + (size_t) b * 32, * q8 = x.q.data() + (size_t) b * 32;
+        int sumi = 0;
+        for (int j = 0; j < 32; j++) sumi += (int) w[j] * (int) q8[j];
+        const float dw = dws[b], dx = x.d[(size_t) b];
+        float t;
+        if (qtype == 2) t = ((float) sumi * dw) * dx;
+        else {
+            const float dd = dw * dx;
+            t = dd * (float) sumi;
+            if (qtype == 3 || qtype == 7) { const float ms = mws[b] * x.s[(size_t) b]; t = t + ms; }
+        }
+        acc[b & 15] = acc[b & 15] + t;
+    }
+    for (int st = 1; st < 16; st <<= 1) for (int c = 0; c < 16; c += 2 * st) acc[c] = acc[c] + acc[c + st];
+    return acc[0];
+}
 static void gemm_q4(const CanonW & W, const float * B, size_t ldb, float * C, size_t ldc, int M, int N, int K, int nth) {
     std::vector<Q8Row> rows((size_t) N);
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (int n = 0; n < N; n++) quantize_row_q8(B + (size_t) n * ldb, K, rows[(size_t) n]);
-    const size_t rb = (size_t) K / 32 * (size_t) qblock_bytes(W.qtype);
-    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
-    for (int m = 0; m < M; m++)
-        for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_q_q8(W.qtype, W.q4 + (size_t) m * rb, rows[(size_t) n], K);
+    const int bb = qblock_bytes(W.qtype);
+    const size_t rb = (size_t) K / 32 * (size_t) bb;
+    #pragma omp parallel num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
+    {
+        std::vector<int8_t> wq((size_t) K);
+        std::vector<float> dws((size_t) K / 32), mws((size_t) K / 32);
+        #pragma omp for schedule(static)
+        for (int m = 0; m < M; m++) {
+            // levels of every format fit int8: q4_0 -8..7, q4_1 0..15, q5_0 -16..15, q5_1 0..31, q8_0 -128..127
+            for (int b = 0; b < K / 32; b++) {
+                int w[32]; float dw, mw;
+                qblock_unpack(W.qtype, W.q4 + (size_t) m * rb + (size_t) b * bb, w, dw, mw);
+                for (int j = 0; j < 32; j++) wq[(size_t) b * 32 + j] = (int8_t) w[j];
+                dws[(size_t) b] = dw; mws[(size_t) b] = mw;
+            }
+            for (int n = 0; n < N; n++) C[(size_t) n * ldc + m] = dot_unpacked_q8(W.qtype, wq.data(), dws.data(), mws.data(), rows[(size_t) n], K);
+        }
+    }
 }
 
 
@@ -622,6 +659,24 @@ static void gemm_w(Oracle & o, const CanonW & W, const float * B, size_t ldb, fl
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (int n = 0; n < N; n++) canon_image_f32(B + (size_t) n * ldb, K, xi + (size_t) n * Kp);
     const size_t rb = (size_t) Kp * (W.f16 ? 2 : 4);
+    if (N >= 16) {
+        // many rows: four x images (4 Kp floats, L1-sized) stay put while the weight rows stream past them; every output is still
+        // its own canon_dot chain set, so the loop order does not touch a single bit
+        constexpr int RB = 4;                                    // (6 rows per block measured the same)
+        const int nb = (N + RB - 1) / RB;
+        #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1)
+        for (int b = 0; b < nb; b++) {
+            const int n = RB * b, cnt = std::min(RB, N - n);
+            const float * xb = xi + (size_t) n * Kp;
+            float * cb = C + (size_t) n * ldc;
+            for (int m = 0; m < M; m++) {
+                const uint8_t * w = W.data + (size_t) m * rb;
+                if (cnt == RB) { if (W.f16) canon_dot<true, RB>(w, xb, Kp, Kp, cb + m, ldc); else canon_dot<false, RB>(w, xb, Kp, Kp, cb + m, ldc); }
+                else for (int r = 0; r < cnt; r++) { if (W.f16) canon_dot<true, 1>(w, xb + (size_t) r * Kp, Kp, Kp, cb + (size_t) r * ldc + m, ldc); else canon_dot<false, 1>(w, xb + (size_t) r * Kp, Kp, Kp, cb + (size_t) r * ldc + m, ldc); }
+            }
+        }
+        return;
+    }
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && (int64_t) M * N * K > 65536)
     for (int m = 0; m < M; m++) {
         const uint8_t * w = W.data + (size_t) m * rb;
@@ -649,8 +704,13 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
     o.scores.ensure((size_t) nth * ctx8);
     o.vt.ensure((size_t) nth * D * ctx8);
     assert(D == 64);                                       // C2 is stated for head_dim 64 (every Bark model)
+    // tasks = heads x blocks of query rows (a block re-transposes its head's K: 64 ctx copies against >= 64 ctx fmaf per row), so that
+    // 12 heads do not leave 8 threads waiting for a second round; every output row is computed exactly as before
+    const int RB = (N >= 256 && o.num.dot_order == 0) ? 4 : 1;
     #pragma omp parallel for schedule(dynamic, 1) num_threads(nth) if (nth > 1)
-    for (int h = 0; h < H; h++) {
+    for (int task = 0; task < H * RB; task++) {
+        const int h = task / RB, rb = task % RB;
+        const int i_lo = (int) ((int64_t) N * rb / RB), i_hi = (int) ((int64_t) N * (rb + 1) / RB);
         const int tid = omp_get_thread_num();
         float * row = o.scores.p + (size_t) tid * ctx8;
         float * Kt = o.vt.p + (size_t) tid * D * ctx8;                    // Kt[d][j]
@@ -676,7 +736,7 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
             }
             continue;
         }
-        for (int i = 0; i < N; i++) {
+        for (int i = i_lo; i < i_hi; i++) {
             const float * qi = q + (size_t) i * ldq + h * D;
             const int valid = causal ? std::min(ctx_total, n_past + i + 1) : ctx_total;
             // C2: s[j] = four chains over the 16-d blocks of fmaf(K[j][d], Q[i][d], acc), then (c0 + c1) + (c2 + c3)   (f32 x f32, bark.cpp:1316)
@@ -712,8 +772,9 @@ static void attention(Oracle & o, const float * q, size_t ldq, const float * kc,
     }
 }
 
-static void add_bias_rows(float * y, size_t ld, int N, int M, const std::vector<float> & b) {
+static void add_bias_rows(float * y, size_t ld, int N, int M, const std::vector<float> & b, int nth = 1) {
     if (b.empty()) return;
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (int i = 0; i < N; i++) for (int m = 0; m < M; m++) y[i * ld + m] += b[m];
 }
 
@@ -726,10 +787,11 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
     o.fc.ensure((size_t) N * 4 * E); o.tmp.ensure((size_t) N * E);
     float * xn = o.xn.p, * qkv = o.qkv.p, * att = o.att.p, * fc = o.fc.p, * tmp = o.tmp.p;
 
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln1_g.data(), L.ln1_b.empty() ? nullptr : L.ln1_b.data());
-    if (L.attn_w.f16) round_rows(o, xn, (size_t) N * E);     // f16 weights: activation -> f16; quantised weights: activation -> q8 inside the product; f32 weights: f32 x f32
+    if (L.attn_w.f16) round_rows(o, xn, (size_t) N * E, nth);     // f16 weights: activation -> f16; quantised weights: activation -> q8 inside the product; f32 weights: f32 x f32
     gemm_w(o, L.attn_w, xn, E, qkv, 3 * E, 3 * E, N, E, nth);
-    add_bias_rows(qkv, 3 * E, N, 3 * E, L.attn_b);
+    add_bias_rows(qkv, 3 * E, N, 3 * E, L.attn_b, nth);
 
     if (causal_cached) {
         float * kc = m.mem_k + (size_t) il * m.block_size * E, * vc = m.mem_v + (size_t) il * m.block_size * E;
@@ -749,19 +811,23 @@ static void block_forward(Oracle & o, Gpt & m, int il, float * x, int N, int n_p
         attention(o, qkv, 3 * E, kc, vc, att, N, N, 0, false, E, H, nth);
     }
 
-    if (L.proj_w.f16) round_rows(o, att, (size_t) N * E);
+    if (L.proj_w.f16) round_rows(o, att, (size_t) N * E, nth);
     gemm_w(o, L.proj_w, att, E, tmp, E, E, N, E, nth);
-    add_bias_rows(tmp, E, N, E, L.proj_b);
+    add_bias_rows(tmp, E, N, E, L.proj_b, nth);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpL  (bark.cpp:1352)
 
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (int i = 0; i < N; i++) layer_norm_row(x + (size_t) i * E, xn + (size_t) i * E, E, L.ln2_g.data(), L.ln2_b.empty() ? nullptr : L.ln2_b.data());
-    if (L.fc_w.f16) round_rows(o, xn, (size_t) N * E);
+    if (L.fc_w.f16) round_rows(o, xn, (size_t) N * E, nth);
     gemm_w(o, L.fc_w, xn, E, fc, 4 * E, 4 * E, N, E, nth);
-    add_bias_rows(fc, 4 * E, N, 4 * E, L.fc_b);
+    add_bias_rows(fc, 4 * E, N, 4 * E, L.fc_b, nth);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (size_t i = 0; i < (size_t) N * 4 * E; i++) fc[i] = gelu_apply(o, fc[i]);
-    if (L.mproj_w.f16) round_rows(o, fc, (size_t) N * 4 * E);
+    if (L.mproj_w.f16) round_rows(o, fc, (size_t) N * 4 * E, nth);
     gemm_w(o, L.mproj_w, fc, 4 * E, tmp, E, E, N, 4 * E, nth);
-    add_bias_rows(tmp, E, N, E, L.mproj_b);
+    add_bias_rows(tmp, E, N, E, L.mproj_b, nth);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && N >= 16)
     for (size_t i = 0; i < (size_t) N * E; i++) x[i] = tmp[i] + x[i];          // cur + inpFF (bark.cpp:1388)
 }
 
