@@ -101,3 +101,24 @@ def test_f32_model_file_is_restated(toy_f32_model, toy_oracle):
         assert r["n_frames"] == 12 and np.all(np.isfinite(r["pcm"]))
     finally:
         o.close()
+
+
+@pytest.mark.parametrize("fmt", [None, "q4_0", "q5_1", "q8_0"])
+def test_many_row_and_single_row_products_agree_bit_for_bit(toy_model, quantized_model, fmt):
+    """The oracle evaluates N >= 16 rows with another loop order than one row (x images blocked in L1, quantised weight rows unpacked
+    once per row).  Loop order must not reach a single bit: a 40-token coarse prompt in one call and token by token ends in the same
+    logits - the property the engine's prefill-vs-decode parity tests lean on."""
+    from oracle.pyoracle import Oracle
+    o = Oracle(quantized_model(toy_model, fmt) if fmt else toy_model, n_threads=4)
+    try:
+        rng = np.random.default_rng(5)
+        ids = rng.integers(0, 12000, 40).astype(np.int32)
+        whole, n_past = o.gpt_eval(1, ids, 0, False)
+        assert n_past == 40
+        n_past = 0
+        for t in ids:
+            step, n_past = o.gpt_eval(1, [int(t)], n_past, False)
+        assert n_past == 40
+        assert np.array_equal(whole.view(np.uint32), step.view(np.uint32))
+    finally:
+        o.close()
