@@ -807,7 +807,13 @@ DEVINL float half_of(const uint4 & u, int e) {                 // element e (com
 }
 DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
 
-template <int NBLK, bool ROWS_IN_LANES>
+// SCHED (instruction order only - every accumulator sees the same MFMA sequence, so the bits cannot depend on it):
+//   0  conversions interleaved with the MFMAs, the two accumulators alternating (the validated default)
+//   1  a chunk's 24 conversions first, then its 16 MFMAs with no other instruction between them (hipcc pairs them acc0, acc1, s_nop)
+// The microarchitecture guide prices one VALU instruction between two MFMAs on the same accumulator at ~43 cycles (the accumulator
+// forwarding is lost); order 0 measures ~110 cycles per chain element.  Order 1 is NOT yet measured on the device
+// (BARK_HIP_BATCH_MFMA=3, tools/time_slots.py kind 3).
+template <int NBLK, bool ROWS_IN_LANES, int SCHED>
 __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
                                                           const LinArgs a) {
     constexpr int K = NBLK * 128;
@@ -837,15 +843,26 @@ __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restr
     }
 #define SLOTS4_MFMA(WV, X0, X1)                                                                              \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
-        _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                      \
-            const float wf = half_of(WV[i], e), x0 = half_of(X0[i], e), x1 = half_of(X1[i], e);              \
-            if constexpr (ROWS_IN_LANES) {                                                                   \
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, wf, acc0, 0, 0, 0);                            \
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, wf, acc1, 0, 0, 0);                            \
-            } else {                                                                                         \
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x0, acc0, 0, 0, 0);                            \
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x1, acc1, 0, 0, 0);                            \
+        if constexpr (SCHED == 0) {                                                                          \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                  \
+                const float wf = half_of(WV[i], e), x0 = half_of(X0[i], e), x1 = half_of(X1[i], e);          \
+                if constexpr (ROWS_IN_LANES) {                                                               \
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, wf, acc0, 0, 0, 0);                        \
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, wf, acc1, 0, 0, 0);                        \
+                } else {                                                                                     \
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x0, acc0, 0, 0, 0);                        \
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x1, acc1, 0, 0, 0);                        \
+                }                                                                                            \
             }                                                                                                \
+        } else {                                                                                             \
+            float wf[8], x0[8], x1[8];                                                                       \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) { wf[e] = half_of(WV[i], e); x0[e] = half_of(X0[i], e); x1[e] = half_of(X1[i], e); } \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                  \
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x0[e], acc0, 0, 0, 0);                      \
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x1[e], acc1, 0, 0, 0);                      \
+            }                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
     }
     SLOTS4_LOAD(wa, xa0, xa1, 0)
@@ -882,10 +899,11 @@ __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restr
 }
 
 template <int NBLK>
-static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes) {
+static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes, int sched) {
     dim3 grid((a.M + 3) / 4), block(256);
-    if (rows_in_lanes) hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, true>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-    else               hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    if (sched == 1)         hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false, 1>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    else if (rows_in_lanes) hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, true, 0>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    else                    hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false, 0>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
 }
 
 void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
@@ -893,15 +911,16 @@ void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
     if (kind == 1) { hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a); return; }
     // with rows in lanes the two operands trade places: the result register then indexes the slot instead of the weight row
     static const bool rows_in_lanes = getenv("BARK_HIP_MFMA4_ROWS_IN_LANES") && atoi(getenv("BARK_HIP_MFMA4_ROWS_IN_LANES")) != 0;
+    const int sched = kind == 3 ? 1 : 0;                        // kind 3: the other instruction order of the same kernel (A/B)
     switch (a.K >> 7) {
-        case 1:  launch_slots4_n<1>(s, a, rows_in_lanes); break;
-        case 2:  launch_slots4_n<2>(s, a, rows_in_lanes); break;
-        case 4:  launch_slots4_n<4>(s, a, rows_in_lanes); break;
-        case 6:  launch_slots4_n<6>(s, a, rows_in_lanes); break;
-        case 8:  launch_slots4_n<8>(s, a, rows_in_lanes); break;
-        case 16: launch_slots4_n<16>(s, a, rows_in_lanes); break;
-        case 24: launch_slots4_n<24>(s, a, rows_in_lanes); break;
-        case 32: launch_slots4_n<32>(s, a, rows_in_lanes); break;
+        case 1:  launch_slots4_n<1>(s, a, rows_in_lanes, sched); break;
+        case 2:  launch_slots4_n<2>(s, a, rows_in_lanes, sched); break;
+        case 4:  launch_slots4_n<4>(s, a, rows_in_lanes, sched); break;
+        case 6:  launch_slots4_n<6>(s, a, rows_in_lanes, sched); break;
+        case 8:  launch_slots4_n<8>(s, a, rows_in_lanes, sched); break;
+        case 16: launch_slots4_n<16>(s, a, rows_in_lanes, sched); break;
+        case 24: launch_slots4_n<24>(s, a, rows_in_lanes, sched); break;
+        case 32: launch_slots4_n<32>(s, a, rows_in_lanes, sched); break;
         default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
     }
 }
