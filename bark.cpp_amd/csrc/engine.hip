@@ -38,7 +38,7 @@ float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.k
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
-    const int fast = (c->fast_gemm && !m.q4 && !m.w32) ? 1 : 0;
+    const int fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
     // kbase / vbase: another utterance slot's cache (batched decode); default: the context's own cache
     auto layer_k = [&](const GptModel & mm, int l) { return (kbase ? kbase : mm.kcache) + mm.kv_layer_stride * (size_t) l; };
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
@@ -357,7 +357,7 @@ void run_fine_forward(bark_context * c, int nn, int n_rows) {
     else           launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
     LinArgs a;
     a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
-    a.fast = (c->fast_gemm && !m.q4 && !m.w32) ? 1 : 0;
+    a.fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace detail

@@ -187,7 +187,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("BARK_HIP_DEVICE out of range");
     HIP_OK(hipSetDevice(ctx->device));
     if (const char * e = getenv("BARK_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
-    if (const char * e = getenv("BARK_HIP_FAST_GEMM")) ctx->fast_gemm = atoi(e) != 0;
+    if (const char * e = getenv("BARK_HIP_FAST_GEMM")) ctx->fast_gemm = atoi(e);
     HIP_OK(hipStreamCreate(&ctx->stream));
     init_kernel_attributes();
 

@@ -92,7 +92,8 @@ struct LinArgs {
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
-    // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order.  Same
+    // N > 1, f16 weights, opt-in.  2 (BARK_HIP_FAST_GEMM=2): the canonical GEMM in another instruction order (same bits).
+    // 1 (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order.  Same
     // operands and roundings as the canonical product (R1), only the ORDER of the f32 additions differs from C1: results agree to f32
     // rounding noise, not bit for bit, so this route is never the one the parity tests check.
     int fast = 0;

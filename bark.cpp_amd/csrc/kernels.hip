@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const LinArgs a) {
 // in LDS and are added in the C1 tree order.
 // ------------------------------------------------------------------------------------------------
 constexpr int GEMM_TM = 64, GEMM_TN = 64;
+// HOIST (opt-in, BARK_HIP_FAST_GEMM=2, same bits): the 32 f16 -> f32 conversions of a K block are done in front of its 32 MFMAs instead
+// of between them (the guide prices VALU fillers between MFMAs at up to ~20 cycles each in some positions); NOT yet timed on the device.
+template <bool HOIST>
 __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -500,6 +503,24 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
         }                                                                                                \
     }
 #define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
+    if constexpr (HOIST) {                                                                               \
+        float av[2][4][2], bv[2][4][2];                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; s++)                                                    \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) {                                              \
+                const uint4 xu = __builtin_bit_cast(uint4, XA[s][t]), wu = __builtin_bit_cast(uint4, WB[s][t]); \
+                const unsigned xr[4] = {xu.x, xu.y, xu.z, xu.w}, wr[4] = {wu.x, wu.y, wu.z, wu.w};        \
+                _Pragma("unroll") for (int kp = 0; kp < 4; kp++) {                                       \
+                    av[s][kp][t] = (float) __builtin_bit_cast(half_t, (unsigned short) (xr[kp] >> sh16)); \
+                    bv[s][kp][t] = (float) __builtin_bit_cast(half_t, (unsigned short) (wr[kp] >> sh16)); \
+                }                                                                                        \
+            }                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        _Pragma("unroll") for (int s = 0; s < 2; s++)                                                    \
+            _Pragma("unroll") for (int kp = 0; kp < 4; kp++)                                             \
+                _Pragma("unroll") for (int i = 0; i < 2; i++)                                            \
+                    _Pragma("unroll") for (int j = 0; j < 2; j++)                                        \
+                        acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][kp][i], bv[s][kp][j], acc[s][i][j], 0, 0, 0); \
+    } else                                                                                               \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
         uint4 xu[2], wu[2];                                                                              \
         _Pragma("unroll") for (int t = 0; t < 2; t++) { xu[t] = __builtin_bit_cast(uint4, XA[s][t]); wu[t] = __builtin_bit_cast(uint4, WB[s][t]); } \
@@ -966,16 +987,19 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
         return;
     }
-    if (a.fast) {
+    if (a.fast == 1) {
         hipLaunchKernelGGL(gemm_f16_kernel, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(64), 0, s, a);
         return;
     }
     dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);
-    hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+    if (a.fast == 2) hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+    else             hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
 }
 
 void init_kernel_attributes() {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
     init_attention_attributes();
     init_quant_attributes();
