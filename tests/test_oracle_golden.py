@@ -158,3 +158,25 @@ def test_greedy_semantic_loop_against_hf(fixture, model, toy_oracle, small_oracl
           f"smallest top-2 margin {float(margins.min()):.2e}")
     if first_d is not None and first_d < len(margins):
         assert margins[first_d] < 5e-3 / 0.7 * 2, "the default mode left the HF stream at a step with a wide margin"
+
+
+@pytest.mark.parametrize("T", [5, 40])
+def test_codec_at_encodec_24khz_dimensions_against_hf(small_oracle, T):
+    """tests/golden/hf_small_codec_s0.npz (tools/make_hf_golden.py codec small): HF EncodecDecoder on the synthetic bark-small file, whose
+    codec has EnCodec-24kHz's real dimensions (32 filters, two 512-wide LSTM layers, ratios 8-5-4-2) - the toy fixture pins the
+    structure, this one the sizes the benchmark runs.  HF-matching numerics: 2e-5 of the signal's scale (measured 1.8e-6); default numerics (f16-rounded
+    activations in front of the f16 weights): f16 rounding noise, bound stated here."""
+    g = _gold("hf_small_codec_s0.npz")
+    ref = g[f"codec_pcm_T{T}"]
+    scale = float(np.max(np.abs(ref)))
+    o = small_oracle
+    o.set_numerics(act_round_f16=False, gelu_mode=2)
+    pcm = o.codec_decode(g[f"codec_codes_T{T}"])
+    o.set_numerics(act_round_f16=True, gelu_mode=0)
+    assert pcm.shape == ref.shape
+    e_hf = float(np.max(np.abs(pcm - ref))) / scale
+    pcm_d = o.codec_decode(g[f"codec_codes_T{T}"])
+    e_def = float(np.max(np.abs(pcm_d - ref))) / scale
+    print(f"T={T}: max |pcm - HF| / scale = {e_hf:.2e} (HF-matching mode), {e_def:.2e} (default mode)")
+    assert e_hf <= 2e-5          # measured 1.8e-6
+    assert 0 < e_def <= 5e-3     # measured 9e-4

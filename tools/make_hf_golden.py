@@ -243,9 +243,34 @@ def main_tanh(preset: str, n_greedy: int):
     print("wrote", dst, os.path.getsize(dst), "bytes;", len(out["greedy_ids"]), "greedy ids, smallest top-2 margin", float(out["greedy_margins"].min()))
 
 
+def main_codec(preset: str):
+    """tests/golden/hf_<preset>_codec_s0.npz: HF EncodecDecoder (RVQ de-embedding done here, SEANet decoder by HF) on the synthetic
+    `preset` codec weights - for `small` / `large` those are EnCodec-24kHz's real dimensions (32 filters, 2 x LSTM 512, ratios 8-5-4-2)."""
+    import torch
+    torch.set_num_threads(8)
+    mf = read_model_file(ensure_model(preset, 0))
+    rng = np.random.default_rng(777)
+    out = {}
+    with torch.no_grad():
+        hp, tens = mf["codec"]
+        dec = build_hf_codec(hp, tens)
+        for T in (5, 40):
+            codes = rng.integers(0, 1024, (8, T)).astype(np.int64)
+            z = sum(torch.from_numpy(np.array(tens[f"quantizer.vq.layers.{q}._codebook.embed"]))[codes[q]] for q in range(8))
+            pcm = dec(z.T[None])[0, 0].numpy()
+            out[f"codec_codes_T{T}"] = codes.astype(np.int32)
+            out[f"codec_pcm_T{T}"] = pcm
+    dst = os.path.join(ROOT, "tests", "golden", f"hf_{preset}_codec_s0.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes", {k: v.shape for k, v in out.items()})
+
+
 def main():
     import torch
 
+    if len(sys.argv) > 1 and sys.argv[1] == "codec":
+        main_codec(sys.argv[2] if len(sys.argv) > 2 else "small")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "tanh":
         main_tanh(sys.argv[2] if len(sys.argv) > 2 else "small", int(sys.argv[3]) if len(sys.argv) > 3 else 64)
         return
