@@ -180,3 +180,33 @@ def test_codec_at_encodec_24khz_dimensions_against_hf(small_oracle, T):
     print(f"T={T}: max |pcm - HF| / scale = {e_hf:.2e} (HF-matching mode), {e_def:.2e} (default mode)")
     assert e_hf <= 2e-5          # measured 1.8e-6
     assert 0 < e_def <= 5e-3     # measured 9e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Stage loops against HF's own (tools/make_hf_golden.py stages): BarkCoarseModel.generate and BarkFineModel.generate are an
+# implementation of the sliding-window coarse loop (bark.cpp:1745-1863) and of the windowed fine loop (bark.cpp:1916-2059) that shares
+# no code with the oracle.  Greedy, tanh GELU, the same synthetic weights; the oracle in its HF-matching numerics must produce the same
+# ids.  The toy fixture runs 700 semantic ids -> 1052 frames: 36 coarse windows with full history handling and TWO fine windows (the
+# T > 1024 case where the reference's indexing is undefined behaviour and the oracle follows suno-ai/bark).
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fixture,model", [("hf_toy_stages_s0.npz", "toy"), ("hf_small_stages_s0.npz", "small")])
+def test_coarse_and_fine_stage_loops_against_hf_generate(fixture, model, toy_oracle, small_oracle):
+    o = toy_oracle if model == "toy" else small_oracle
+    g = _gold(fixture)
+    sem, want_c, want_f = g["semantic"], g["coarse"], g["fine"]
+    try:
+        o.set_numerics(act_round_f16=False, gelu_mode=1)
+        p = o.params()
+        got_c = o.coarse(sem, p)
+        assert got_c.shape == want_c.shape and np.array_equal(got_c, want_c), "coarse ids differ from HF generate"
+        got_f = o.fine(want_c, p)
+        assert got_f.shape == want_f.shape and np.array_equal(got_f, want_f), "fine ids differ from HF generate"
+        # default numerics (what the engine is compared with bit for bit): f16 rounding noise may flip near ties; report, bound loosely
+        o.set_numerics(act_round_f16=True, gelu_mode=0)
+        got_fd = o.fine(want_c, p)
+        agree = float(np.mean(got_fd == want_f))
+        print(f"{model}: HF-matching numerics: {want_c.shape[0]} coarse rows and {want_f.size} fine ids equal; default numerics: "
+              f"{agree:.4f} of the fine ids equal")
+        assert np.array_equal(got_fd[:, :2], want_c) and agree >= 0.97
+    finally:
+        o.set_numerics(act_round_f16=True, gelu_mode=0)

@@ -265,9 +265,62 @@ def main_codec(preset: str):
     print("wrote", dst, os.path.getsize(dst), "bytes", {k: v.shape for k, v in out.items()})
 
 
+def main_stages(preset: str, n_sem: int):
+    """tests/golden/hf_<preset>_stages_s0.npz: HF's own stage loops - BarkCoarseModel.generate (sliding windows of 60 tokens over 630
+    tokens of history, alternating codebooks) and BarkFineModel.generate (windows of 1024 frames hopping by 512) - greedy, tanh GELU, on
+    the synthetic `preset` weights, from n_sem random semantic ids.  An implementation of bark.cpp:1745-1863 / :1916-2059 that shares
+    no code with the oracle.  One adjustment: HF's AlternatingCodebooksLogitsProcessor leaves ids ABOVE the second codebook unmasked
+    (trained weights never produce them, random weights do); bark.cpp takes exactly one codebook's window of logits
+    (bark.cpp:1829-1833), so the fixture masks them too."""
+    import torch
+    import transformers.models.bark.modeling_bark as mb
+    from transformers.models.bark.configuration_bark import BarkCoarseConfig
+    from transformers.models.bark.generation_configuration_bark import (BarkCoarseGenerationConfig, BarkFineGenerationConfig,
+                                                                         BarkSemanticGenerationConfig)
+    orig_call = mb.AlternatingCodebooksLogitsProcessor.__call__
+
+    def call(self, input_ids, scores):
+        out = orig_call(self, input_ids, scores)
+        out[:, self.semantic_vocab_size + 2 * self.codebook_size:] = -float("inf")
+        return out
+    mb.AlternatingCodebooksLogitsProcessor.__call__ = call
+    torch.set_num_threads(8)
+    mf = read_model_file(ensure_model(preset, 0))
+    rng = np.random.default_rng(99)
+    semantic = rng.integers(0, 10000, n_sem).astype(np.int64)
+    with torch.no_grad():
+        hp, tens = mf["coarse"]
+        base = build_hf_gpt(hp, tens, fine=False)
+        cfg = BarkCoarseConfig(block_size=hp["block_size"], input_vocab_size=hp["n_in"], output_vocab_size=hp["n_out"], num_layers=hp["n_layer"],
+                               num_heads=hp["n_head"], hidden_size=hp["n_embd"], dropout=0.0, bias=False)
+        cfg._attn_implementation = "eager"
+        co = mb.BarkCoarseModel(cfg)
+        co.load_state_dict(base.state_dict())
+        co = use_tanh_gelu(co).eval()
+        sg = BarkSemanticGenerationConfig()
+        cg = BarkCoarseGenerationConfig(do_sample=False, temperature=1.0)
+        assert (sg.semantic_vocab_size, sg.semantic_rate_hz, cg.max_coarse_input_length, cg.max_coarse_history, cg.sliding_window_len,
+                cg.coarse_semantic_pad_token, cg.coarse_infer_token, cg.coarse_rate_hz) == (10000, 49.9, 256, 630, 60, 12048, 12050, 75)
+        out = co.generate(torch.from_numpy(semantic)[None].clone(), semantic_generation_config=sg, coarse_generation_config=cg, codebook_size=1024)
+        flat = out[0].numpy()
+        coarse = np.stack([flat[0::2] - 10000, flat[1::2] - 10000 - 1024], axis=1)
+        assert coarse.min() >= 0 and coarse.max() < 1024
+        hpf, tensf = mf["fine"]
+        fi = use_tanh_gelu(build_hf_gpt(hpf, tensf, fine=True))
+        fout = fi.generate(out.clone(), semantic_generation_config=sg, coarse_generation_config=cg,
+                           fine_generation_config=BarkFineGenerationConfig(temperature=None), codebook_size=1024)
+        fine = fout[0].numpy().T
+    dst = os.path.join(ROOT, "tests", "golden", f"hf_{preset}_stages_s0.npz")
+    np.savez_compressed(dst, semantic=semantic.astype(np.int32), coarse=coarse.astype(np.int32), fine=fine.astype(np.int32))
+    print("wrote", dst, os.path.getsize(dst), "bytes:", n_sem, "semantic ids ->", coarse.shape, "coarse,", fine.shape, "fine")
+
+
 def main():
     import torch
 
+    if len(sys.argv) > 1 and sys.argv[1] == "stages":
+        main_stages(sys.argv[2] if len(sys.argv) > 2 else "small", int(sys.argv[3]) if len(sys.argv) > 3 else 256)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "codec":
         main_codec(sys.argv[2] if len(sys.argv) > 2 else "small")
         return
