@@ -126,6 +126,23 @@ def test_bark_small_shapes_against_hf_with_tanh_gelu(small_oracle):
     _tanh_checks(small_oracle, _gold("hf_small_tanh_s0.npz"), 5e-3)
 
 
+@pytest.fixture(scope="module")
+def large_oracle():
+    from oracle.pyoracle import Oracle
+    from tools.make_synth_model import ensure_model
+    o = Oracle(ensure_model("large", 0), n_threads=8)
+    yield o
+    o.close()
+
+
+def test_bark_large_shapes_against_hf_with_tanh_gelu(large_oracle):
+    """BASELINE config 3's shapes (1024 / 24 layers / 16 heads): forward passes and a 24-step greedy semantic loop against HF"""
+    g = _gold("hf_large_tanh_s0.npz")
+    _tanh_checks(large_oracle, g, 5e-3)          # measured 2.4e-6 (HF-matching mode) / 1.8e-3 (default mode)
+    first, ids, want = _greedy_check(large_oracle, g, False, 1)
+    assert first is None, (first, ids[:8], want[:8])
+
+
 def _greedy_check(o, g, rnd, gelu):
     """64 greedy semantic steps: HF forward passes + the reference's sampling rule (fixture) against the oracle's own stage loop.
     A step whose two leading logits are closer than the numerical distance between the two implementations cannot be expected to
