@@ -17,8 +17,12 @@
 //      semantics (f16 weights x f16-rounded activations with f32 accumulation, f16-LUT tanh
 //      GELU, double-accumulated LayerNorm / softmax sums) and the EnCodec 24 kHz decoder
 //      (HF transformers modeling_encodec.py:82-450, the model convert.py converts from).
-//  It is cross-checked at f32 against HF transformers' Bark / EnCodec modules on the same
-//  synthetic weights (tests/golden/, tools/make_hf_golden.py).
+//  What it IS checked against (tests/test_oracle_golden.py, fixtures made by tools/make_hf_golden.py from HF transformers' Bark /
+//  EnCodec - the PyTorch models convert.py converts from - on the same synthetic weights): forward passes of all three GPTs at toy,
+//  bark-small and bark-large shapes (2.4e-6 on the logits with ggml's rounding points switched off, f16 rounding noise with them
+//  on), a greedy semantic loop, HF's own coarse and fine `generate` loops id for id (incl. more than 1024 frames), and the EnCodec
+//  decoder at its real dimensions (1.8e-6 of full scale).  That pins architecture, layouts, stage loops and windowing; it cannot pin
+//  ggml's rounding points or its summation order - tests/test_order_sensitivity.py measures how much those matter.
 //
 //  Build: see oracle/Makefile (g++ -O3 -mavx2 -mfma -mf16c -fopenmp, -ffp-contract=off).
 // =====================================================================================
