@@ -200,19 +200,27 @@ def test_codec_at_encodec_24khz_dimensions_against_hf(small_oracle, T):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# Stage loops against HF's own (tools/make_hf_golden.py stages): BarkCoarseModel.generate and BarkFineModel.generate are an
+# Stage loops against HF's own (tools/make_hf_golden.py stages): BarkSemanticModel / BarkCoarseModel / BarkFineModel.generate are an
 # implementation of the sliding-window coarse loop (bark.cpp:1745-1863) and of the windowed fine loop (bark.cpp:1916-2059) that shares
 # no code with the oracle.  Greedy, tanh GELU, the same synthetic weights; the oracle in its HF-matching numerics must produce the same
 # ids.  The toy fixture runs 700 semantic ids -> 1052 frames: 36 coarse windows with full history handling and TWO fine windows (the
 # T > 1024 case where the reference's indexing is undefined behaviour and the oracle follows suno-ai/bark).
 # ------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fixture,model", [("hf_toy_stages_s0.npz", "toy"), ("hf_small_stages_s0.npz", "small")])
-def test_coarse_and_fine_stage_loops_against_hf_generate(fixture, model, toy_oracle, small_oracle):
+def test_stage_loops_against_hf_generate(fixture, model, toy_oracle, small_oracle):
     o = toy_oracle if model == "toy" else small_oracle
     g = _gold(fixture)
     sem, want_c, want_f = g["semantic"], g["coarse"], g["fine"]
     try:
         o.set_numerics(act_round_f16=False, gelu_mode=1)
+        # semantic stage: HF's BarkSemanticModel.generate builds its input from raw word-piece ids (offset, padding, history merged row by
+        # row, infer token).  The prompt here is laid out as bark.cpp:617-647 does; the stop rule is argmax == eos on both sides (min_eos_p
+        # off: HF evaluates it at temperature 1, the reference at 0.7) and, like the reference (bark.cpp:1682 hands gpt_sample the full
+        # logit vector), the fixture does not suppress the ids above the semantic vocabulary.
+        t = g["text_ids"].astype(np.int64)
+        prompt = np.concatenate([t + 10048, np.full(256 - len(t), 129595), np.full(256, 10000), [129599]]).astype(np.int32)
+        got_s = o.semantic(prompt, o.params(n_steps_text_encoder=int(g["n_semantic_steps"]), min_eos_p=2.0))
+        assert np.array_equal(got_s, g["semantic_from_text"]), "semantic ids differ from HF generate"
         p = o.params()
         got_c = o.coarse(sem, p)
         assert got_c.shape == want_c.shape and np.array_equal(got_c, want_c), "coarse ids differ from HF generate"

@@ -289,6 +289,36 @@ def main_stages(preset: str, n_sem: int):
     rng = np.random.default_rng(99)
     semantic = rng.integers(0, 10000, n_sem).astype(np.int64)
     with torch.no_grad():
+        # ---- semantic stage through HF's own generate: raw word-piece ids in, HF adds the offset, pads, merges the history row by row.
+        #      Two adjustments: (1) the reference hands gpt_sample the FULL logit vector (bark.cpp:1682 passes `logits`, the
+        #      `relevant_logits` built two lines above are never used), so HF's suppression of the ids 10001 .. 10047 is switched off;
+        #      (2) min_eos_p off (HF evaluates it at temperature 1, the reference at 0.7 - not comparable under greedy decoding), so
+        #      the only stop rule is argmax == eos
+        class _NoSuppress:
+            def __init__(self, *a, **k): pass
+            def __call__(self, input_ids, scores): return scores
+        mb.SuppressTokensLogitsProcessor = _NoSuppress
+        hps, tenss = mf["semantic"]
+        sbase = build_hf_gpt(hps, tenss, fine=False)
+        scfg = mb.BarkSemanticConfig(block_size=hps["block_size"], input_vocab_size=hps["n_in"], output_vocab_size=hps["n_out"], num_layers=hps["n_layer"],
+                                     num_heads=hps["n_head"], hidden_size=hps["n_embd"], dropout=0.0, bias=False)
+        scfg._attn_implementation = "eager"
+        sm = mb.BarkSemanticModel(scfg)
+        sm.load_state_dict(sbase.state_dict())
+        sm = use_tanh_gelu(sm).eval()
+        n_text = 37
+        text_ids = rng.integers(0, 100000, n_text).astype(np.int64)
+        ids256 = np.zeros(256, np.int64); ids256[:n_text] = text_ids
+        mask = np.zeros(256, np.int64); mask[:n_text] = 1
+        n_sem_steps = 48
+        sgen = BarkSemanticGenerationConfig(do_sample=False, temperature=1.0, min_eos_p=None, max_new_tokens=n_sem_steps)
+        assert (sgen.text_encoding_offset, sgen.text_pad_token, sgen.semantic_pad_token, sgen.semantic_infer_token, sgen.max_input_semantic_length,
+                sgen.eos_token_id) == (10048, 129595, 10000, 129599, 256, 10000)
+        sout = sm.generate(torch.from_numpy(ids256)[None], semantic_generation_config=sgen, attention_mask=torch.from_numpy(mask)[None])
+        sem_ids = sout[0].numpy()
+        if (sem_ids == 10000).any():
+            sem_ids = sem_ids[: int(np.argmax(sem_ids == 10000))]
+        del sm, sbase
         hp, tens = mf["coarse"]
         base = build_hf_gpt(hp, tens, fine=False)
         cfg = BarkCoarseConfig(block_size=hp["block_size"], input_vocab_size=hp["n_in"], output_vocab_size=hp["n_out"], num_layers=hp["n_layer"],
@@ -311,7 +341,8 @@ def main_stages(preset: str, n_sem: int):
                            fine_generation_config=BarkFineGenerationConfig(temperature=None), codebook_size=1024)
         fine = fout[0].numpy().T
     dst = os.path.join(ROOT, "tests", "golden", f"hf_{preset}_stages_s0.npz")
-    np.savez_compressed(dst, semantic=semantic.astype(np.int32), coarse=coarse.astype(np.int32), fine=fine.astype(np.int32))
+    np.savez_compressed(dst, semantic=semantic.astype(np.int32), coarse=coarse.astype(np.int32), fine=fine.astype(np.int32),
+                        text_ids=text_ids.astype(np.int32), semantic_from_text=sem_ids.astype(np.int32), n_semantic_steps=np.int32(n_sem_steps))
     print("wrote", dst, os.path.getsize(dst), "bytes:", n_sem, "semantic ids ->", coarse.shape, "coarse,", fine.shape, "fine")
 
 
