@@ -112,6 +112,32 @@ def run_shard(ctx, prompts, idx, max_batch: int = 32):
     return pcms
 
 
+def cpu_baseline_leg(model_path: str, prompt: str, n_semantic: int) -> dict:
+    """The CPU oracle (a restatement of the reference's algorithm, NOT the reference: ggml / encodec.cpp are absent) on 4 pinned cores
+    like BASELINE config 1 (`-t 4`), on the SAME workload as the headline: same prompt, same n_steps_text_encoder (about 17 s of CPU on
+    the GPU box's host).  `value` is the RTF of that run - no extrapolation."""
+    from oracle.pyoracle import Oracle
+    cores = min(os.cpu_count() or 4, 4)
+    try:
+        os.sched_setaffinity(0, set(range(cores)))              # taskset -c 0-3
+    except (AttributeError, OSError):
+        pass
+    orc = Oracle(model_path, n_threads=cores)
+    t1 = time.perf_counter()
+    ref = orc.generate(prompt, orc.params(n_steps_text_encoder=n_semantic))
+    cdt = time.perf_counter() - t1
+    orc.close()
+    audio_s = ref["n_samples"] / 24000.0
+    return {"value": audio_s / cdt, "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"the headline workload itself: same prompt, n_steps_text_encoder={n_semantic} ({audio_s:.2f} s audio, {cdt:.1f} s CPU wall, "
+                      f"threads pinned to cores 0-{cores - 1})",
+            "label": "CPU restatement of the reference (oracle/), about 2x slower per token than the reference's own README transcript "
+                     "(README.md:55, hardware unstated); a reported baseline, not a target",
+            "stage_ms_per_token": {"semantic": ref["t_predict_semantic_us"] / 1000.0 / max(1, ref["n_sample_semantic"]),
+                                   "coarse": ref["t_predict_coarse_us"] / 1000.0 / max(1, ref["n_sample_coarse"]),
+                                   "fine": ref["t_predict_fine_us"] / 1000.0 / max(1, ref["n_sample_fine"])}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,35 +339,7 @@ def main():
         except Exception as e:      # noqa: BLE001
             out["q4_0"] = {"error": str(e)}
     if not a.no_cpu_baseline:
-        # The CPU oracle (a restatement of the reference's algorithm, NOT the reference: ggml / encodec.cpp are absent) on 4 pinned
-        # cores like BASELINE config 1 (`-t 4`), on a bounded sample of the same prompt: n_steps_text_encoder = 24 instead of 256
-        # (the full workload takes ~2 min of CPU).  `value` is the RTF of that sample; `extrapolated_rtf_256_steps` applies the
-        # measured per-token / per-pass rates to the headline workload (the fine stage always runs 6 passes over 1024 rows).
-        from oracle.pyoracle import Oracle
-        cores = min(os.cpu_count() or 4, 4)
-        try:
-            os.sched_setaffinity(0, set(range(cores)))              # taskset -c 0-3
-        except (AttributeError, OSError):
-            pass
-        orc = Oracle(path, n_threads=cores)
-        n_small = 24
-        t1 = time.perf_counter()
-        ref = orc.generate(prompts[a.warmup % len(prompts)], orc.params(n_steps_text_encoder=n_small))
-        cdt = time.perf_counter() - t1
-        sem = ref["t_predict_semantic_us"] / 1000.0 / max(1, ref["n_sample_semantic"])
-        coa = ref["t_predict_coarse_us"] / 1000.0 / max(1, ref["n_sample_coarse"])
-        fin_total = ref["t_predict_fine_us"] / 1000.0
-        other = cdt * 1e3 - (ref["t_predict_semantic_us"] + ref["t_predict_coarse_us"] + ref["t_predict_fine_us"]) / 1000.0
-        frames_small = max(1, ref["n_frames"])
-        full_ms = 256 * sem + 768 * coa + fin_total + other * (384.0 / frames_small)
-        out["cpu_baseline"] = {"value": ref["n_samples"] / 24000.0 / cdt, "unit": "audio-s/s", "cores": cores, "kind": "port",
-                               "sample": f"same prompt, n_steps_text_encoder={n_small} ({ref['n_samples'] / 24000.0:.2f} s audio, {cdt:.1f} s CPU wall, "
-                                         f"threads pinned to cores 0-{cores - 1})",
-                               "extrapolated_rtf_256_steps": 5.12 / (full_ms / 1000.0),
-                               "label": "untuned CPU restatement of the reference (oracle/), about 3x slower per token than the reference's own README "
-                                        "transcript (README.md:55, hardware unstated); a reported baseline, not a target",
-                               "stage_ms_per_token": {"semantic": sem, "coarse": coa, "fine": fin_total / max(1, ref["n_sample_fine"])}}
-        orc.close()
+        out["cpu_baseline"] = cpu_baseline_leg(path, prompts[a.warmup % len(prompts)], a.n_semantic)
     print(json.dumps(out))
     ctx.free()
 

@@ -73,3 +73,17 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_cpu_baseline_leg_reports_the_contract_keys(toy_model):
+    """bench.py's cpu_baseline leg (the oracle on pinned cores, same workload as the headline) - here on the toy model"""
+    import os
+    import bench
+    before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    try:
+        c = bench.cpu_baseline_leg(toy_model, bench.synth_prompts(2)[1], 16)
+    finally:
+        if before is not None:
+            os.sched_setaffinity(0, before)
+    assert c["kind"] == "port" and c["unit"] == "audio-s/s" and 1 <= c["cores"] <= 4 and c["value"] > 0 and "n_steps_text_encoder=16" in c["sample"]
+    assert set(c["stage_ms_per_token"]) == {"semantic", "coarse", "fine"}
