@@ -16,7 +16,8 @@ synthetic weights / synthetic prompts (no checkpoints offline), n_steps_text_enc
   python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched under torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel against HBM) and, at N = 1, `cpu_baseline` (the CPU oracle timed on
-this host on a bounded sample; test infrastructure used as the measured-beside baseline only, never on the product path).
+this host, 4 pinned threads, on the headline workload itself - about 20 s; test infrastructure used as the measured-beside baseline
+only, never on the product path).
 """
 import argparse
 import json
