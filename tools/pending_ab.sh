@@ -7,7 +7,6 @@
 # Adopt a variant only if it is faster AND its equality / parity line says so.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R; mkdir -p gpurun_out
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma16x16x4_probe tools/probes/mfma16x16x4_probe.hip 2>/dev/null && timeout 30 /tmp/mfma16x16x4_probe | tee gpurun_out/pending_mfma16x16x4_probe.txt
 timeout 100 python tools/time_slots.py small 32 0,2,3 640 2>&1 | tail -1 | tee gpurun_out/pending_time_slots_b32.txt
 timeout 100 python tools/time_slots.py small 8 0,2,3 640 2>&1 | tail -1 | tee gpurun_out/pending_time_slots_b8.txt
 timeout 200 python tools/check_routes.py batch small 32 48 valu:BARK_HIP_BATCH_MFMA=0 route2:BARK_HIP_BATCH_MFMA=2 route3:BARK_HIP_BATCH_MFMA=3 2>&1 | tail -1 | tee gpurun_out/pending_check_batch.txt
