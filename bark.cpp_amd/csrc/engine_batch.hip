@@ -75,6 +75,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     // test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA selects it:
     //   2 (default): gemm_slots4_kernel, 4 x 4 x 1 blocks (one block = one chain), 4 weight rows per workgroup
     //   3: route 2 with another instruction order (conversions hoisted out of the MFMA runs) - same bits by construction, not yet timed
+    //   5: gemm_slots16_kernel, 16 x 16 x 4 MFMA tiles (16 rows x 16 slots per workgroup, chains over its waves) - not yet run on the device
     //   1: gemm_slots_kernel, 32 x 32 tiles, chains spread over the waves of a workgroup and summed through LDS
     //   0: the VALU GEMV per pair of slots (the only route for fewer than 8 slots and for quantised files)
     // Measured per launch at 32 slots, bark-small (tools/time_slots.py; QKV / proj / FC / MLP proj, us): route 0: 17.2 / 4.4 / 22.7 / 12.7,

@@ -919,6 +919,95 @@ __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restr
     if (elive) linear_epilogue_pre(a, en, em, mine, pre);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lock-step decode product on v_mfma_f32_16x16x4_f32 (route 5; written at the end of round 2, NOT yet run on the device - see
+// tools/pending_ab.sh).  The instruction is an ascending-k fmaf chain over its four products (tools/probes/mfma16x16x4_probe.hip,
+// confirmed on the device), issues every 32 cycles and hands a dependent accumulator on after 40: a C1 chain advances at 10 cycles
+// per element where 32x32x2 needs 32 and the 4x4x1 kernel measures ~55.
+// Workgroup = 8 waves = 16 weight rows x 16 slots (blockIdx.y: slots 0-15 / 16-31); wave w owns chains 2w and 2w+1 (two independent
+// accumulators, alternating).  Lane (g = lane / 16, r = lane % 16): weight row r and slot r; of a chain's 8-element chunk it feeds
+// element g to the first MFMA (k = 0..3) and element 4 + g to the second.  Every chunk of the row is requested before the first
+// conversion (K <= 1024) or in groups of four chunk rounds, two groups in flight; a round's conversions come before its four MFMAs.
+// The chain pairs meet in LDS in the C1 tree order, as in gemm_slots_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+__global__ __launch_bounds__(512) void gemm_slots16_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
+                                                           const LinArgs a) {
+    __shared__ float lds[8][16][17];
+    constexpr int K = NBLK * 128;
+    constexpr int G = NBLK <= 8 ? NBLK : 4, NG = NBLK / G;       // chunk rounds per load group
+    static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 4");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int m0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
+    if (s0 >= a.nbatch) return;                                  // the whole workgroup (uniform, before any barrier)
+    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
+    const half_t * wrow = W + (size_t) (row_off + min(m0 + r, M - 1)) * K + ((2 * w) << 3);
+    const half_t * xrow = X + (size_t) min(s0 + r, a.nbatch - 1) * K + ((2 * w) << 3);
+    // the epilogue's operands: threads 0..255 finish output (row idx & 15, slot idx >> 4)
+    const int emm = threadIdx.x & 15, en = (threadIdx.x >> 4) & 15;
+    const bool elive = threadIdx.x < 256 && s0 + en < a.nbatch && m0 + emm < M;
+    const EpiPre pre = epilogue_prefetch(a, elive ? s0 + en : 0, elive ? m0 + emm : 0, row_off);
+
+    floatx4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool hi = g >= 2;
+    const unsigned sh = (g & 1) ? 16u : 0u;
+    uint4 wa[G][2], xa[G][2], wb[G][2], xb[G][2];                 // [round][chain]
+#define SLOTS16_LOAD(WV, XV, GI)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < G; i++)                                                            \
+        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                      \
+            WV[i][c] = ld_u4(wrow + (((GI) * G + i) << 7) + (c << 3));                                       \
+            XV[i][c] = ld_u4(xrow + (((GI) * G + i) << 7) + (c << 3));                                       \
+        }
+#define SLOTS16_MFMA(WV, XV)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
+        float wf[2][2], xf[2][2];                                  /* [chain][first / second half of the chunk] */ \
+        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                      \
+            const unsigned w01 = hi ? WV[i][c].y : WV[i][c].x, w23 = hi ? WV[i][c].w : WV[i][c].z;            \
+            const unsigned x01 = hi ? XV[i][c].y : XV[i][c].x, x23 = hi ? XV[i][c].w : XV[i][c].z;            \
+            wf[c][0] = (float) __builtin_bit_cast(half_t, (unsigned short) (w01 >> sh));                     \
+            wf[c][1] = (float) __builtin_bit_cast(half_t, (unsigned short) (w23 >> sh));                     \
+            xf[c][0] = (float) __builtin_bit_cast(half_t, (unsigned short) (x01 >> sh));                     \
+            xf[c][1] = (float) __builtin_bit_cast(half_t, (unsigned short) (x23 >> sh));                     \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][0], xf[0][0], acc0, 0, 0, 0);                      \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][0], xf[1][0], acc1, 0, 0, 0);                      \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][1], xf[0][1], acc0, 0, 0, 0);                      \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][1], xf[1][1], acc1, 0, 0, 0);                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+    SLOTS16_LOAD(wa, xa, 0)
+    #pragma unroll
+    for (int gi = 0; gi < NG; gi += 2) {
+        if (gi + 1 < NG) { SLOTS16_LOAD(wb, xb, gi + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        SLOTS16_MFMA(wa, xa)
+        if (gi + 1 < NG) {
+            if (gi + 2 < NG) { SLOTS16_LOAD(wa, xa, gi + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            SLOTS16_MFMA(wb, xb)
+        }
+    }
+#undef SLOTS16_LOAD
+#undef SLOTS16_MFMA
+    // accumulator register v of lane (g, r): weight row 4 g + v of the tile, slot r
+    #pragma unroll
+    for (int v = 0; v < 4; v++) lds[w][4 * g + v][r] = acc0[v] + acc1[v];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        float p[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) p[q] = lds[q][emm][en];
+        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (elive) linear_epilogue_pre(a, s0 + en, m0 + emm, v, pre);
+    }
+}
+template <int NBLK>
+static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
+    hipLaunchKernelGGL((gemm_slots16_kernel<NBLK>), dim3((a.M + 15) / 16, a.nbatch > 16 ? 2 : 1), dim3(512), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+}
+
 template <int NBLK>
 static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes, int sched) {
     dim3 grid((a.M + 3) / 4), block(256);
@@ -930,6 +1019,20 @@ static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes
 void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
     if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
     if (kind == 1) { hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a); return; }
+    if (kind == 5) {
+        switch (a.K >> 7) {
+            case 1:  launch_slots16_n<1>(s, a); break;
+            case 2:  launch_slots16_n<2>(s, a); break;
+            case 4:  launch_slots16_n<4>(s, a); break;
+            case 6:  launch_slots16_n<6>(s, a); break;
+            case 8:  launch_slots16_n<8>(s, a); break;
+            case 16: launch_slots16_n<16>(s, a); break;
+            case 24: launch_slots16_n<24>(s, a); break;
+            case 32: launch_slots16_n<32>(s, a); break;
+            default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
+        }
+        return;
+    }
     // with rows in lanes the two operands trade places: the result register then indexes the slot instead of the weight row
     static const bool rows_in_lanes = getenv("BARK_HIP_MFMA4_ROWS_IN_LANES") && atoi(getenv("BARK_HIP_MFMA4_ROWS_IN_LANES")) != 0;
     const int sched = kind == 3 ? 1 : 0;                        // kind 3: the other instruction order of the same kernel (A/B)
