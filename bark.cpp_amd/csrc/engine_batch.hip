@@ -91,7 +91,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         // products whose input rows are f16 already (the two out-projections): the VALU GEMV per pair of slots is the faster route for
         // K = n_embd at any batch size (4.4 against 5.0 us at 32 slots, 2.9 against 3.6 at 8) and for K = 4 n_embd below ~24 slots
         // (5.2 against 7.0 us at 8 slots, 12.8 against 12.0 at 32) - tools/time_slots.py
-        if (!ln_g && mfma_kind >= 2 && (a.K == a.M || B < 24)) { launch_linear(st, a); return; }
+        if (!ln_g && (mfma_kind == 2 || mfma_kind == 3) && (a.K == a.M || B < 24)) { launch_linear(st, a); return; }
         if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
         launch_linear_slots(st, a, mfma_kind);
