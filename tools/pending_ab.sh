@@ -8,6 +8,9 @@
 # Adopt a variant only if it is faster AND its equality / parity line says so.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R; mkdir -p gpurun_out
+# 0. can the kernel boundaries of the decode chain be hidden? (overlap_probe.hip said no with fences: 26.7 us against 2.99 us per kernel;
+#    overlap_probe2.hip uses the fence-free granule hand-off of the programming guide, three variants, bounded waits)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/overlap_probe2 tools/probes/overlap_probe2.hip 2>/dev/null && timeout 30 /tmp/overlap_probe2 | tee gpurun_out/pending_overlap_probe2.txt
 timeout 100 python tools/time_slots.py small 32 0,2,3,5 640 2>&1 | tail -1 | tee gpurun_out/pending_time_slots_b32.txt
 timeout 100 python tools/time_slots.py small 8 0,2,3,5 640 2>&1 | tail -1 | tee gpurun_out/pending_time_slots_b8.txt
 timeout 60 python tools/check_routes.py batch toy 17 32 valu:BARK_HIP_BATCH_MFMA=0 route3:BARK_HIP_BATCH_MFMA=3 route5:BARK_HIP_BATCH_MFMA=5 2>&1 | tail -1 | tee gpurun_out/pending_check_batch_toy.txt
