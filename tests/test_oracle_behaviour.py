@@ -124,7 +124,7 @@ def test_many_row_and_single_row_products_agree_bit_for_bit(toy_model, quantized
         o.close()
 
 
-@pytest.mark.parametrize("fmt", ["f16", "q4_0"])
+@pytest.mark.parametrize("fmt", ["f16", "q4_0", "large"])
 def test_committed_bench_workload_fixture_is_what_the_oracle_generates(fmt):
     """tests/golden/oracle_small_bench_<fmt>.npz stands in for a live oracle run in the -m gpu test of the benchmark workload
     (test_bench_workload_matches_the_oracle); here the oracle re-derives it, so the two cannot drift apart."""
@@ -133,7 +133,7 @@ def test_committed_bench_workload_fixture_is_what_the_oracle_generates(fmt):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import make_oracle_golden
-    want = np.load(os.path.join(root, "tests", "golden", f"oracle_small_bench_{fmt}.npz"))
+    want = np.load(os.path.join(root, "tests", "golden", "oracle_large_64.npz" if fmt == "large" else f"oracle_small_bench_{fmt}.npz"))
     got = make_oracle_golden.workload(fmt)
     assert set(got) == set(want.files)
     for k in want.files:
