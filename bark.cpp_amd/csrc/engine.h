@@ -72,8 +72,7 @@ struct bark_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool use_graph = true;
-    int fast_gemm = 0;                   // BARK_HIP_FAST_GEMM: 1 = N > 1 products on the f16 matrix cores in hardware accumulation order (non-canonical);
-                                         // 2 = the canonical f32-MFMA GEMM with its conversions hoisted out of the MFMA runs (same bits, A/B)
+    int fast_gemm = 0;                   // BARK_HIP_FAST_GEMM=1: N > 1 products on the f16 matrix cores in hardware accumulation order (non-canonical, tolerance mode)
     int decode_ng = 4;                                  // key groups (of 256) the decode kernels being enqueued may assume: ctx <= 256 ng
 
     // device memory.  The weight slab (and the codec codebooks) are immutable after load and shared by every

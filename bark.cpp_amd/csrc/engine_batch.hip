@@ -72,14 +72,11 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     const bool hoist = B >= 24 && !m.q4;
     // B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores; rows are normalised to f16 by
     // ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route (tools/check_routes.py,
-    // test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA selects it:
-    //   2 (default): gemm_slots4_kernel, 4 x 4 x 1 blocks (one block = one chain), 4 weight rows per workgroup
-    //   3: route 2 with another instruction order (conversions hoisted out of the MFMA runs) - same bits by construction, not yet timed
-    //   5: gemm_slots16_kernel, 16 x 16 x 4 MFMA tiles (16 rows x 16 slots per workgroup, chains over its waves) - not yet run on the device
-    //   1: gemm_slots_kernel, 32 x 32 tiles, chains spread over the waves of a workgroup and summed through LDS
-    //   0: the VALU GEMV per pair of slots (the only route for fewer than 8 slots and for quantised files)
-    // Measured per launch at 32 slots, bark-small (tools/time_slots.py; QKV / proj / FC / MLP proj, us): route 0: 17.2 / 4.4 / 22.7 / 12.7,
-    // route 1: 9.3 / 8.1 / 8.7 / 24.0, route 2: 9.5 / 5.0 / 9.1 / 12.0; whole job 13.1 -> 15.4 prompts/s (tools/batch_ab.py).
+    // test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA=0 forces the VALU GEMV per pair of slots
+    // (the cross-check route, and the only one for fewer than 8 slots and for quantised files); anything else: gemm_slots4_kernel.
+    // Measured per launch at 32 slots, bark-small (tools/time_slots.py; QKV / proj / FC / MLP proj, us): VALU 17.0 / 4.4 / 22.7 / 12.7,
+    // 4 x 4 x 1 blocks 9.2 / 4.9 / 9.1 / 11.2 (profiles/r03_pending_ab.txt; the 32 x 32 x 2 and 16 x 16 x 4 tilings of rounds 2 were
+    // slower and are gone).
     static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 2;
     const bool mfma = mfma_kind != 0 && B >= 8 && !m.q4;
     // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
@@ -91,7 +88,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         // products whose input rows are f16 already (the two out-projections): the VALU GEMV per pair of slots is the faster route for
         // K = n_embd at any batch size (4.4 against 5.0 us at 32 slots, 2.9 against 3.6 at 8) and for K = 4 n_embd below ~24 slots
         // (5.2 against 7.0 us at 8 slots, 12.8 against 12.0 at 32) - tools/time_slots.py
-        if (!ln_g && (mfma_kind == 2 || mfma_kind == 3) && (a.K == a.M || B < 24)) { launch_linear(st, a); return; }
+        if (!ln_g && (a.K == a.M || B < 24)) { launch_linear(st, a); return; }
         if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
         launch_linear_slots(st, a, mfma_kind);

@@ -92,8 +92,7 @@ struct LinArgs {
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
-    // N > 1, f16 weights, opt-in.  2 (BARK_HIP_FAST_GEMM=2): the canonical GEMM in another instruction order (same bits).
-    // 1 (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order.  Same
+    // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order.  Same
     // operands and roundings as the canonical product (R1), only the ORDER of the f32 additions differs from C1: results agree to f32
     // rounding noise, not bit for bit, so this route is never the one the parity tests check.
     int fast = 0;
@@ -101,7 +100,7 @@ struct LinArgs {
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
-void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind);      // kind 1: 32 x 32 tiles (gemm_slots_kernel), 2: 4 x 4 blocks (gemm_slots4_kernel)
+void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind);      // kind != 0: 4 x 4 x 1 blocks (gemm_slots4_kernel)
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
@@ -148,7 +147,7 @@ struct AttnPrefillArgs {
     float * scores = nullptr;              // scratch [H][N][P]
     half_t * att = nullptr; int ld_att = 0;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32 (same leading dimension)
-    int dbg = 0;                          // timing experiments only (BARK_HIP_ATTN_DBG): 1 skip scores, 2 skip exp, 4 skip mix
+    int dbg = 0;                          // timing experiments only (BARK_HIP_ATTN_DBG): 1 skip scores, 2 skip exp, 4 skip mix (results are wrong)
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 

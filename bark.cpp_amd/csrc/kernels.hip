@@ -470,9 +470,6 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const LinArgs a) {
 // in LDS and are added in the C1 tree order.
 // ------------------------------------------------------------------------------------------------
 constexpr int GEMM_TM = 64, GEMM_TN = 64;
-// HOIST (opt-in, BARK_HIP_FAST_GEMM=2, same bits): the 32 f16 -> f32 conversions of a K block are done in front of its 32 MFMAs instead
-// of between them (the guide prices VALU fillers between MFMAs at up to ~20 cycles each in some positions); NOT yet timed on the device.
-template <bool HOIST>
 __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -503,24 +500,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
         }                                                                                                \
     }
 #define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
-    if constexpr (HOIST) {                                                                               \
-        float av[2][4][2], bv[2][4][2];                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 2; s++)                                                    \
-            _Pragma("unroll") for (int t = 0; t < 2; t++) {                                              \
-                const uint4 xu = __builtin_bit_cast(uint4, XA[s][t]), wu = __builtin_bit_cast(uint4, WB[s][t]); \
-                const unsigned xr[4] = {xu.x, xu.y, xu.z, xu.w}, wr[4] = {wu.x, wu.y, wu.z, wu.w};        \
-                _Pragma("unroll") for (int kp = 0; kp < 4; kp++) {                                       \
-                    av[s][kp][t] = (float) __builtin_bit_cast(half_t, (unsigned short) (xr[kp] >> sh16)); \
-                    bv[s][kp][t] = (float) __builtin_bit_cast(half_t, (unsigned short) (wr[kp] >> sh16)); \
-                }                                                                                        \
-            }                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        _Pragma("unroll") for (int s = 0; s < 2; s++)                                                    \
-            _Pragma("unroll") for (int kp = 0; kp < 4; kp++)                                             \
-                _Pragma("unroll") for (int i = 0; i < 2; i++)                                            \
-                    _Pragma("unroll") for (int j = 0; j < 2; j++)                                        \
-                        acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][kp][i], bv[s][kp][j], acc[s][i][j], 0, 0, 0); \
-    } else                                                                                               \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
         uint4 xu[2], wu[2];                                                                              \
         _Pragma("unroll") for (int t = 0; t < 2; t++) { xu[t] = __builtin_bit_cast(uint4, XA[s][t]); wu[t] = __builtin_bit_cast(uint4, WB[s][t]); } \
@@ -728,95 +707,12 @@ __global__ __launch_bounds__(64) void gemm_f16_kernel(const LinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lock-step decode product on the f32 matrix cores: y[slot][m] for up to 32 utterance slots at once, so that a step reads every weight
-// ONCE for all slots (gemv_batch_kernel re-reads them from L2 per pair of slots on the VALU: 1.6 ms per step at 32 slots).
-// Tile: 32 slots (MFMA A rows) x 32 weight rows (B rows); 8 waves, wave w owns chains 2w and 2w+1 of C1 (one accumulator = one fmaf
-// chain, as in gemm_kernel); per 128-element K block a chain is ONE 16-byte chunk per operand row = 4 MFMA k pairs.  The chain pairs
-// meet in LDS in the C1 tree order.  Rows of x are f16 (LayerNorm applied by ln_rows_kernel where the operator has one); the epilogue
-// is the per-slot one of the decode GEMVs (own KV cache and position per slot).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_slots_kernel(const LinArgs a) {
-    __shared__ float lds[8][32][33];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 32;
-    const int K = a.K, nblk = K >> 7;
-    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
-    const int nrow = min(l31, a.nbatch - 1), mrow = min(m0 + l31, a.M - 1);
-    const half_t * xrow = a.x_f16 + (size_t) nrow * K + ((2 * w) << 3);
-    const half_t * wrow = a.W + (size_t) (row_off + mrow) * K + ((2 * w) << 3);
-    floatx16 acc[2];
-    #pragma unroll
-    for (int s = 0; s < 2; s++) for (int r = 0; r < 16; r++) acc[s][r] = 0.0f;
-    const unsigned sh16 = half ? 16u : 0u;                     // lanes 32-63 feed the odd element of each f16 pair (second k slot)
-    half8 xa[2][2], wb[2][2];                                  // [buffer][chain]
-    #pragma unroll
-    for (int s = 0; s < 2; s++) { xa[0][s] = ld_half8(xrow + (s << 3)); wb[0][s] = ld_half8(wrow + (s << 3)); }
-    for (int b = 0; b < nblk; b += 2) {
-        if (b + 1 < nblk) {
-            #pragma unroll
-            for (int s = 0; s < 2; s++) { xa[1][s] = ld_half8(xrow + ((b + 1) << 7) + (s << 3)); wb[1][s] = ld_half8(wrow + ((b + 1) << 7) + (s << 3)); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const uint4 xu = __builtin_bit_cast(uint4, xa[0][s]), wu = __builtin_bit_cast(uint4, wb[0][s]);
-            #pragma unroll
-            for (int kp = 0; kp < 4; kp++) {
-                const unsigned xr = kp == 0 ? xu.x : kp == 1 ? xu.y : kp == 2 ? xu.z : xu.w;
-                const unsigned wr = kp == 0 ? wu.x : kp == 1 ? wu.y : kp == 2 ? wu.z : wu.w;
-                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32((float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16)),
-                                                              (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16)), acc[s], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (b + 1 < nblk) {
-            if (b + 2 < nblk) {
-                #pragma unroll
-                for (int s = 0; s < 2; s++) { xa[0][s] = ld_half8(xrow + ((b + 2) << 7) + (s << 3)); wb[0][s] = ld_half8(wrow + ((b + 2) << 7) + (s << 3)); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const uint4 xu = __builtin_bit_cast(uint4, xa[1][s]), wu = __builtin_bit_cast(uint4, wb[1][s]);
-                #pragma unroll
-                for (int kp = 0; kp < 4; kp++) {
-                    const unsigned xr = kp == 0 ? xu.x : kp == 1 ? xu.y : kp == 2 ? xu.z : xu.w;
-                    const unsigned wr = kp == 0 ? wu.x : kp == 1 ? wu.y : kp == 2 ? wu.z : wu.w;
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32((float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16)),
-                                                                  (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16)), acc[s], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // accumulator register r of lane l: row (r & 3) + 8 (r >> 2) + 4 half = slot, column l31 = weight row
-    #pragma unroll
-    for (int r = 0; r < 16; r++) lds[w][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[0][r] + acc[1][r];
-    __syncthreads();
-    #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int idx = threadIdx.x + 512 * r;
-        const int n = idx >> 5, mm = idx & 31, m = m0 + mm;
-        float p[8];
-        #pragma unroll
-        for (int q = 0; q < 8; q++) p[q] = lds[q][n][mm];
-        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        if (n < a.nbatch && m < a.M) {
-            const EpiPre pre = epilogue_prefetch(a, n, m, row_off);
-            linear_epilogue_pre(a, n, m, v, pre);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Lock-step decode product, fine-grained formulation.  v_mfma_f32_4x4x1_16b_f32 issues SIXTEEN independent 4x4x1 blocks, one fused
 // multiply-add per element and issue (tools/probes/mfma4x4_probe.hip checks layout and exactness on the device) - block b is chain b
 // of C1: lane l = 4 b + r feeds the block with weight row r and slot r of the chain's current element, and a sequence of issues walks
 // the chain's chunks (16 i + b, i ascending) element by element.  All 16 chains of a (4 rows x 4 slots) tile therefore live in ONE
 // accumulator of ONE wave and meet by a lane butterfly (xor 4, 8, 16, 32 = C1's tree) - no LDS, no barrier, and the tile is small
-// enough that even a 768-row product spreads over 192 workgroups.  (gemm_slots_kernel needs 32-row tiles: 24 workgroups for the same
-// product, each serialising 4 waves per SIMD on a dependent chain of MFMAs.)
+// enough that even a 768-row product spreads over 192 workgroups.
 // Workgroup = 4 waves = 4 weight rows x 32 slots; wave w owns slots 8w .. 8w+7 as two accumulators.  The matrix cores run f32 at the
 // packed-VALU rate, so this is not about FLOPs: an issue consumes 2 operand registers for 256 multiply-adds where v_fma_f32 consumes
 // 2 for 64, and every weight is read from HBM once per step instead of once per pair of slots.
@@ -828,13 +724,10 @@ DEVINL float half_of(const uint4 & u, int e) {                 // element e (com
 }
 DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
 
-// SCHED (instruction order only - every accumulator sees the same MFMA sequence, so the bits cannot depend on it):
-//   0  conversions interleaved with the MFMAs, the two accumulators alternating (the validated default)
-//   1  a chunk's 24 conversions first, then its 16 MFMAs with no other instruction between them (hipcc pairs them acc0, acc1, s_nop)
-// The microarchitecture guide prices one VALU instruction between two MFMAs on the same accumulator at ~43 cycles (the accumulator
-// forwarding is lost); order 0 measures ~110 cycles per chain element.  Order 1 is NOT yet measured on the device
-// (BARK_HIP_BATCH_MFMA=3, tools/time_slots.py kind 3).
-template <int NBLK, bool ROWS_IN_LANES, int SCHED>
+// Instruction order: a chunk's 24 conversions first, then its 16 MFMAs with no other instruction between them (2-6 % faster on the
+// device than conversions interleaved with the MFMAs; every accumulator sees the same MFMA sequence either way, so the bits cannot
+// depend on it - profiles/r03_pending_ab.txt).
+template <int NBLK>
 __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
                                                           const LinArgs a) {
     constexpr int K = NBLK * 128;
@@ -864,27 +757,14 @@ __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restr
     }
 #define SLOTS4_MFMA(WV, X0, X1)                                                                              \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
-        if constexpr (SCHED == 0) {                                                                          \
-            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                  \
-                const float wf = half_of(WV[i], e), x0 = half_of(X0[i], e), x1 = half_of(X1[i], e);          \
-                if constexpr (ROWS_IN_LANES) {                                                               \
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, wf, acc0, 0, 0, 0);                        \
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, wf, acc1, 0, 0, 0);                        \
-                } else {                                                                                     \
-                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x0, acc0, 0, 0, 0);                        \
-                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf, x1, acc1, 0, 0, 0);                        \
-                }                                                                                            \
-            }                                                                                                \
-        } else {                                                                                             \
-            float wf[8], x0[8], x1[8];                                                                       \
-            _Pragma("unroll") for (int e = 0; e < 8; e++) { wf[e] = half_of(WV[i], e); x0[e] = half_of(X0[i], e); x1[e] = half_of(X1[i], e); } \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
-            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                  \
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x0[e], acc0, 0, 0, 0);                      \
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x1[e], acc1, 0, 0, 0);                      \
-            }                                                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                               \
+        float wf[8], x0[8], x1[8];                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) { wf[e] = half_of(WV[i], e); x0[e] = half_of(X0[i], e); x1[e] = half_of(X1[i], e); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                      \
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x0[e], acc0, 0, 0, 0);                          \
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x1[e], acc1, 0, 0, 0);                          \
         }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     SLOTS4_LOAD(wa, xa0, xa1, 0)
     #pragma unroll
@@ -919,132 +799,23 @@ __global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restr
     if (elive) linear_epilogue_pre(a, en, em, mine, pre);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Lock-step decode product on v_mfma_f32_16x16x4_f32 (route 5; written at the end of round 2, NOT yet run on the device - see
-// tools/pending_ab.sh).  The instruction is an ascending-k fmaf chain over its four products (tools/probes/mfma16x16x4_probe.hip,
-// confirmed on the device), issues every 32 cycles and hands a dependent accumulator on after 40: a C1 chain advances at 10 cycles
-// per element where 32x32x2 needs 32 and the 4x4x1 kernel measures ~55.
-// Workgroup = 8 waves = 16 weight rows x 16 slots (blockIdx.y: slots 0-15 / 16-31); wave w owns chains 2w and 2w+1 (two independent
-// accumulators, alternating).  Lane (g = lane / 16, r = lane % 16): weight row r and slot r; of a chain's 8-element chunk it feeds
-// element g to the first MFMA (k = 0..3) and element 4 + g to the second.  Every chunk of the row is requested before the first
-// conversion (K <= 1024) or in groups of four chunk rounds, two groups in flight; a round's conversions come before its four MFMAs.
-// The chain pairs meet in LDS in the C1 tree order, as in gemm_slots_kernel.
-// ------------------------------------------------------------------------------------------------
 template <int NBLK>
-__global__ __launch_bounds__(512) void gemm_slots16_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
-                                                           const LinArgs a) {
-    __shared__ float lds[8][16][17];
-    constexpr int K = NBLK * 128;
-    constexpr int G = NBLK <= 8 ? NBLK : 4, NG = NBLK / G;       // chunk rounds per load group
-    static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 4");
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int g = lane >> 4, r = lane & 15;
-    const int m0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
-    if (s0 >= a.nbatch) return;                                  // the whole workgroup (uniform, before any barrier)
-    const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
-    const half_t * wrow = W + (size_t) (row_off + min(m0 + r, M - 1)) * K + ((2 * w) << 3);
-    const half_t * xrow = X + (size_t) min(s0 + r, a.nbatch - 1) * K + ((2 * w) << 3);
-    // the epilogue's operands: threads 0..255 finish output (row idx & 15, slot idx >> 4)
-    const int emm = threadIdx.x & 15, en = (threadIdx.x >> 4) & 15;
-    const bool elive = threadIdx.x < 256 && s0 + en < a.nbatch && m0 + emm < M;
-    const EpiPre pre = epilogue_prefetch(a, elive ? s0 + en : 0, elive ? m0 + emm : 0, row_off);
-
-    floatx4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const bool hi = g >= 2;
-    const unsigned sh = (g & 1) ? 16u : 0u;
-    uint4 wa[G][2], xa[G][2], wb[G][2], xb[G][2];                 // [round][chain]
-#define SLOTS16_LOAD(WV, XV, GI)                                                                            \
-    _Pragma("unroll") for (int i = 0; i < G; i++)                                                            \
-        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                      \
-            WV[i][c] = ld_u4(wrow + (((GI) * G + i) << 7) + (c << 3));                                       \
-            XV[i][c] = ld_u4(xrow + (((GI) * G + i) << 7) + (c << 3));                                       \
-        }
-#define SLOTS16_MFMA(WV, XV)                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
-        float wf[2][2], xf[2][2];                                  /* [chain][first / second half of the chunk] */ \
-        _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                      \
-            const unsigned w01 = hi ? WV[i][c].y : WV[i][c].x, w23 = hi ? WV[i][c].w : WV[i][c].z;            \
-            const unsigned x01 = hi ? XV[i][c].y : XV[i][c].x, x23 = hi ? XV[i][c].w : XV[i][c].z;            \
-            wf[c][0] = (float) __builtin_bit_cast(half_t, (unsigned short) (w01 >> sh));                     \
-            wf[c][1] = (float) __builtin_bit_cast(half_t, (unsigned short) (w23 >> sh));                     \
-            xf[c][0] = (float) __builtin_bit_cast(half_t, (unsigned short) (x01 >> sh));                     \
-            xf[c][1] = (float) __builtin_bit_cast(half_t, (unsigned short) (x23 >> sh));                     \
-        }                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][0], xf[0][0], acc0, 0, 0, 0);                      \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][0], xf[1][0], acc1, 0, 0, 0);                      \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][1], xf[0][1], acc0, 0, 0, 0);                      \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1][1], xf[1][1], acc1, 0, 0, 0);                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-    }
-    SLOTS16_LOAD(wa, xa, 0)
-    #pragma unroll
-    for (int gi = 0; gi < NG; gi += 2) {
-        if (gi + 1 < NG) { SLOTS16_LOAD(wb, xb, gi + 1) }
-        __builtin_amdgcn_sched_barrier(0);
-        SLOTS16_MFMA(wa, xa)
-        if (gi + 1 < NG) {
-            if (gi + 2 < NG) { SLOTS16_LOAD(wa, xa, gi + 2) }
-            __builtin_amdgcn_sched_barrier(0);
-            SLOTS16_MFMA(wb, xb)
-        }
-    }
-#undef SLOTS16_LOAD
-#undef SLOTS16_MFMA
-    // accumulator register v of lane (g, r): weight row 4 g + v of the tile, slot r
-    #pragma unroll
-    for (int v = 0; v < 4; v++) lds[w][4 * g + v][r] = acc0[v] + acc1[v];
-    __syncthreads();
-    if (threadIdx.x < 256) {
-        float p[8];
-        #pragma unroll
-        for (int q = 0; q < 8; q++) p[q] = lds[q][emm][en];
-        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        if (elive) linear_epilogue_pre(a, s0 + en, m0 + emm, v, pre);
-    }
-}
-template <int NBLK>
-static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
-    hipLaunchKernelGGL((gemm_slots16_kernel<NBLK>), dim3((a.M + 15) / 16, a.nbatch > 16 ? 2 : 1), dim3(512), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-}
-
-template <int NBLK>
-static void launch_slots4_n(hipStream_t s, const LinArgs & a, bool rows_in_lanes, int sched) {
-    dim3 grid((a.M + 3) / 4), block(256);
-    if (sched == 1)         hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false, 1>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-    else if (rows_in_lanes) hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, true, 0>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-    else                    hipLaunchKernelGGL((gemm_slots4_kernel<NBLK, false, 0>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+static void launch_slots4_n(hipStream_t s, const LinArgs & a) {
+    hipLaunchKernelGGL((gemm_slots4_kernel<NBLK>), dim3((a.M + 3) / 4), dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
 }
 
 void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
+    (void) kind;                                                 // one matrix-core route survives (kind != 0); 0 = the VALU GEMV, chosen by the callers
     if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
-    if (kind == 1) { hipLaunchKernelGGL(gemm_slots_kernel, dim3((a.M + 31) / 32), dim3(512), 0, s, a); return; }
-    if (kind == 5) {
-        switch (a.K >> 7) {
-            case 1:  launch_slots16_n<1>(s, a); break;
-            case 2:  launch_slots16_n<2>(s, a); break;
-            case 4:  launch_slots16_n<4>(s, a); break;
-            case 6:  launch_slots16_n<6>(s, a); break;
-            case 8:  launch_slots16_n<8>(s, a); break;
-            case 16: launch_slots16_n<16>(s, a); break;
-            case 24: launch_slots16_n<24>(s, a); break;
-            case 32: launch_slots16_n<32>(s, a); break;
-            default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
-        }
-        return;
-    }
-    // with rows in lanes the two operands trade places: the result register then indexes the slot instead of the weight row
-    static const bool rows_in_lanes = getenv("BARK_HIP_MFMA4_ROWS_IN_LANES") && atoi(getenv("BARK_HIP_MFMA4_ROWS_IN_LANES")) != 0;
-    const int sched = kind == 3 ? 1 : 0;                        // kind 3: the other instruction order of the same kernel (A/B)
     switch (a.K >> 7) {
-        case 1:  launch_slots4_n<1>(s, a, rows_in_lanes, sched); break;
-        case 2:  launch_slots4_n<2>(s, a, rows_in_lanes, sched); break;
-        case 4:  launch_slots4_n<4>(s, a, rows_in_lanes, sched); break;
-        case 6:  launch_slots4_n<6>(s, a, rows_in_lanes, sched); break;
-        case 8:  launch_slots4_n<8>(s, a, rows_in_lanes, sched); break;
-        case 16: launch_slots4_n<16>(s, a, rows_in_lanes, sched); break;
-        case 24: launch_slots4_n<24>(s, a, rows_in_lanes, sched); break;
-        case 32: launch_slots4_n<32>(s, a, rows_in_lanes, sched); break;
+        case 1:  launch_slots4_n<1>(s, a); break;
+        case 2:  launch_slots4_n<2>(s, a); break;
+        case 4:  launch_slots4_n<4>(s, a); break;
+        case 6:  launch_slots4_n<6>(s, a); break;
+        case 8:  launch_slots4_n<8>(s, a); break;
+        case 16: launch_slots4_n<16>(s, a); break;
+        case 24: launch_slots4_n<24>(s, a); break;
+        case 32: launch_slots4_n<32>(s, a); break;
         default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
     }
 }
@@ -1095,14 +866,11 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         return;
     }
     dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);
-    if (a.fast == 2) hipLaunchKernelGGL(gemm_kernel<true>, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
-    else             hipLaunchKernelGGL(gemm_kernel<false>, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+    hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
 }
 
 void init_kernel_attributes() {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
     init_attention_attributes();
     init_quant_attributes();
