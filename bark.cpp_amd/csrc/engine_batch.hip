@@ -70,14 +70,11 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
     // ln_stats_kernel for large ones (measured cross-over on MI355X between 16 and 32 slots)
     const bool hoist = B >= 24 && !m.q4;
-    // B >= 8, f16 weights: every product of the step runs once for all slots on the f32 matrix cores; rows are normalised to f16 by
-    // ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route (tools/check_routes.py,
-    // test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA=0 forces the VALU GEMV per pair of slots
-    // (the cross-check route, and the only one for fewer than 8 slots and for quantised files); anything else: gemm_slots4_kernel.
-    // Measured per launch at 32 slots, bark-small (tools/time_slots.py; QKV / proj / FC / MLP proj, us): VALU 17.0 / 4.4 / 22.7 / 12.7,
-    // 4 x 4 x 1 blocks 9.2 / 4.9 / 9.1 / 11.2 (profiles/r03_pending_ab.txt; the 32 x 32 x 2 and 16 x 16 x 4 tilings of rounds 2 were
-    // slower and are gone).
-    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 2;
+    // B >= 8, f16 weights: the products of the step run once for all slots on the f32 matrix cores (gemm_slots16_kernel, kernels.hip);
+    // rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route
+    // (tools/check_routes.py, test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA=0 forces the VALU
+    // GEMV per pair of slots everywhere (the cross-check route, and the only one for fewer than 8 slots and for quantised files).
+    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 4;
     const bool mfma = mfma_kind != 0 && B >= 8 && !m.q4;
     // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
     static const int dbg = getenv("BARK_HIP_BATCH_DBG") ? atoi(getenv("BARK_HIP_BATCH_DBG")) : 0;
@@ -85,10 +82,10 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         if (dbg & 2) return;
         if (mfma && (dbg & 4)) { a.x_f16 = c->xn; a.x_f32 = nullptr; a.ln_stats = nullptr; launch_linear_slots(st, a, mfma_kind); return; }
         if (!mfma) { a.ln_g = ln_g; a.ln_b = ln_b; launch_linear(st, a); return; }
-        // products whose input rows are f16 already (the two out-projections): the VALU GEMV per pair of slots is the faster route for
-        // K = n_embd at any batch size (4.4 against 5.0 us at 32 slots, 2.9 against 3.6 at 8) and for K = 4 n_embd below ~24 slots
-        // (5.2 against 7.0 us at 8 slots, 12.8 against 12.0 at 32) - tools/time_slots.py
-        if (!ln_g && (a.K == a.M || B < 24)) { launch_linear(st, a); return; }
+        // the two out-projections (input rows f16 already, 768 output rows): the VALU GEMV per pair of slots stays ahead for few slots
+        // (tools/time_slots.py, us per launch VALU / matrix cores: proj 2.9 / 3.5 at 8 slots, 3.3 / 3.7 at 16, 4.4 / 3.7 at 32; MLP proj 5.1 / 8.0
+        // at 8, 9.0 / 8.8 at 16, 12.7 / 8.9 at 32)
+        if (!ln_g && (a.K == a.M ? B < 24 : B < 16)) { launch_linear(st, a); return; }
         if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
         launch_linear_slots(st, a, mfma_kind);

@@ -706,116 +706,108 @@ __global__ __launch_bounds__(64) void gemm_f16_kernel(const LinArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Lock-step decode product, fine-grained formulation.  v_mfma_f32_4x4x1_16b_f32 issues SIXTEEN independent 4x4x1 blocks, one fused
-// multiply-add per element and issue (tools/probes/mfma4x4_probe.hip checks layout and exactness on the device) - block b is chain b
-// of C1: lane l = 4 b + r feeds the block with weight row r and slot r of the chain's current element, and a sequence of issues walks
-// the chain's chunks (16 i + b, i ascending) element by element.  All 16 chains of a (4 rows x 4 slots) tile therefore live in ONE
-// accumulator of ONE wave and meet by a lane butterfly (xor 4, 8, 16, 32 = C1's tree) - no LDS, no barrier, and the tile is small
-// enough that even a 768-row product spreads over 192 workgroups.
-// Workgroup = 4 waves = 4 weight rows x 32 slots; wave w owns slots 8w .. 8w+7 as two accumulators.  The matrix cores run f32 at the
-// packed-VALU rate, so this is not about FLOPs: an issue consumes 2 operand registers for 256 multiply-adds where v_fma_f32 consumes
-// 2 for 64, and every weight is read from HBM once per step instead of once per pair of slots.
-// ------------------------------------------------------------------------------------------------
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 DEVINL float half_of(const uint4 & u, int e) {                 // element e (compile-time) of eight packed f16 values, widened
     const unsigned word = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
     return (float) __builtin_bit_cast(half_t, (unsigned short) ((e & 1) ? (word >> 16) : word));
 }
 DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
 
-// Instruction order: a chunk's 24 conversions first, then its 16 MFMAs with no other instruction between them (2-6 % faster on the
-// device than conversions interleaved with the MFMAs; every accumulator sees the same MFMA sequence either way, so the bits cannot
-// depend on it - profiles/r03_pending_ab.txt).
+// ------------------------------------------------------------------------------------------------
+// Lock-step decode product: y[slot][m] for up to 32 utterance slots at once, every weight read ONCE per step for all slots.
+// v_mfma_f32_16x16x1_4b_f32 issues FOUR independent 16 x 16 x 1 blocks, each one fused multiply-add per element: block g of wave w is
+// chain 4 w + g of C1, so a wave walks four chains of a (16 weight rows x 16 slots) tile element by element and a 256-thread
+// workgroup (one wave per SIMD) holds all 16 chains.  Measured on the device (tools/probes/mfma_rate_probe.hip, mfma_dep_probe.hip;
+// profiles/r03_mfma_*_probe.txt): this form issues every 32 cycles with ONE dependent accumulator (32 multiply-adds per clock and
+// SIMD = the f32 matrix-core peak), D register 4 b + (i % 4) of lane 16 (i / 4) + j holds element (i, j) of block b; the 4 x 4 x 1
+// form of round 2 needs 15.6 cycles per dependent issue for a quarter of the work and re-read the slots' rows for every 4 weight
+// rows.  A VALU instruction between two dependent MFMAs costs ~43 cycles, so a block's 16 conversions come first and its 8 MFMAs
+// back to back (47.6 cycles per MFMA for one wave alone, 32 when a second wave of the SIMD fills the conversion gaps).
+//   lane (g, r): weight row m0 + r and slot s0 + r of chain 4 w + g: the 16-byte chunk at block * 256 + (4 w + g) * 16 bytes of either
+//   row - a wave's load instruction covers 16 rows x 64 contiguous bytes, and nobody loads a byte twice.
+//   Chains 4 w .. 4 w + 3 meet inside a lane ((d0 + d1) + (d2 + d3) over the block registers = C1's tree levels xor 1, xor 2), the four
+//   waves through LDS (levels xor 4, xor 8); thread t then finishes output (row t % 16, slot t / 16) with the decode epilogues.
+// Every load of a lane is requested before the first conversion (K <= 1024), or in two groups in flight (K up to 4096); the in-order
+// vmcnt lets block b's MFMAs start when its two chunks have landed.  32-slot tiles (two accumulators sharing the weight conversions)
+// measured slower at every shape: half the workgroups, and the 768-row products then fill 48 CUs.
+// Per launch at 32 slots, bark-small (tools/time_slots.py, QKV / proj / FC / MLP proj): 5.7 / 3.7 / 5.5 / 8.9 us against 9.2 / 4.9 / 9.1 /
+// 11.2 for the 4 x 4 x 1 kernel and 17.1 / 4.4 / 22.7 / 12.7 for the VALU GEMV per pair of slots (profiles/r03_slots16_times.txt).
+// ------------------------------------------------------------------------------------------------
 template <int NBLK>
-__global__ __launch_bounds__(256) void gemm_slots4_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
-                                                          const LinArgs a) {
+__global__ __launch_bounds__(256) void gemm_slots16_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
+                                                           const LinArgs a) {
     constexpr int K = NBLK * 128;
-    constexpr int G = NBLK < 8 ? NBLK : 8, NG = NBLK / G;        // chunk rounds per load group
+    constexpr int G = NBLK <= 8 ? NBLK : 8, NG = NBLK / G;       // blocks per load group
     static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+    __shared__ float red[4][16][17];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = lane >> 2, r = lane & 3;
-    const int m0 = blockIdx.x * 4;
-    if (8 * w >= a.nbatch) return;                               // a wave without live slots (the kernel has no barrier)
+    const int g = lane >> 4, r = lane & 15;
+    const int m0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
     const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
-    const half_t * wrow = W + (size_t) (row_off + min(m0 + r, M - 1)) * K + (b << 3);
-    const half_t * xr0 = X + (size_t) min(8 * w + r, a.nbatch - 1) * K + (b << 3);
-    const half_t * xr1 = X + (size_t) min(8 * w + 4 + r, a.nbatch - 1) * K + (b << 3);
-    // after the butterfly every lane holds every total of its slot column; lanes of blocks 0..7 finish one output each
-    const int ev = b & 3, eg = (b >> 2) & 1;
-    const int en = 8 * w + 4 * eg + r, em = m0 + ev;
-    const bool elive = b < 8 && en < a.nbatch && em < M;
-    const EpiPre pre = epilogue_prefetch(a, elive ? en : 0, elive ? em : 0, row_off);
-
-    floatx4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint4 wa[G], xa0[G], xa1[G], wb[G], xb0[G], xb1[G];
-#define SLOTS4_LOAD(WV, X0, X1, GI)                                                                         \
+    const int coff = (4 * w + g) << 3;
+    const half_t * wrow = W + (size_t) (row_off + min(m0 + r, M - 1)) * K + coff;
+    const half_t * xrow = X + (size_t) min(s0 + r, a.nbatch - 1) * K + coff;
+    floatx16 acc;
+    #pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    uint4 wa[G], xa[G], wb[NG > 1 ? G : 1], xb[NG > 1 ? G : 1];
+#define SLOTS16_LOAD(WV, XV, GI)                                                                            \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
         WV[i] = ld_u4(wrow + (((GI) * G + i) << 7));                                                         \
-        X0[i] = ld_u4(xr0 + (((GI) * G + i) << 7));                                                          \
-        X1[i] = ld_u4(xr1 + (((GI) * G + i) << 7));                                                          \
+        XV[i] = ld_u4(xrow + (((GI) * G + i) << 7));                                                         \
     }
-#define SLOTS4_MFMA(WV, X0, X1)                                                                              \
+#define SLOTS16_MFMA(WV, XV)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
-        float wf[8], x0[8], x1[8];                                                                           \
-        _Pragma("unroll") for (int e = 0; e < 8; e++) { wf[e] = half_of(WV[i], e); x0[e] = half_of(X0[i], e); x1[e] = half_of(X1[i], e); } \
+        float wf[8], xf[8];                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) { wf[e] = half_of(WV[i], e); xf[e] = half_of(XV[i], e); } \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 8; e++) {                                                      \
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x0[e], acc0, 0, 0, 0);                          \
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wf[e], x1[e], acc1, 0, 0, 0);                          \
-        }                                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(wf[e], xf[e], acc, 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
-    SLOTS4_LOAD(wa, xa0, xa1, 0)
+    SLOTS16_LOAD(wa, xa, 0)
+    // the epilogue's operands (bias, residual, context length): thread t finishes row t % 16 of slot t / 16
+    const int em = m0 + (threadIdx.x & 15), en = s0 + (threadIdx.x >> 4);
+    const bool live = em < M && en < a.nbatch;
+    const EpiPre pre = epilogue_prefetch(a, live ? en : 0, live ? em : 0, row_off);
     #pragma unroll
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) { SLOTS4_LOAD(wb, xb0, xb1, g + 1) }
+    for (int gi = 0; gi < NG; gi += 2) {
+        if constexpr (NG > 1) { if (gi + 1 < NG) { SLOTS16_LOAD(wb, xb, gi + 1) } }
         __builtin_amdgcn_sched_barrier(0);                       // the next group's loads stay ahead of this group's MFMAs
-        SLOTS4_MFMA(wa, xa0, xa1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < NG) {
-            if (g + 2 < NG) { SLOTS4_LOAD(wa, xa0, xa1, g + 2) }
-            __builtin_amdgcn_sched_barrier(0);
-            SLOTS4_MFMA(wb, xb0, xb1)
-            __builtin_amdgcn_sched_barrier(0);
+        SLOTS16_MFMA(wa, xa)
+        if constexpr (NG > 1) {
+            if (gi + 1 < NG) {
+                if (gi + 2 < NG) { SLOTS16_LOAD(wa, xa, gi + 2) }
+                __builtin_amdgcn_sched_barrier(0);
+                SLOTS16_MFMA(wb, xb)
+            }
         }
     }
-#undef SLOTS4_LOAD
-#undef SLOTS4_MFMA
-    // register v of lane 4 b + r: weight row v, slot (4 g + r) of this wave, chain b
-    float t[8];
+#undef SLOTS16_LOAD
+#undef SLOTS16_MFMA
+    // D register 4 b + v of lane (g, r): chain 4 w + b, weight row 4 g + v, slot r
     #pragma unroll
-    for (int v = 0; v < 4; v++) { t[v] = acc0[v]; t[4 + v] = acc1[v]; }
-    #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        t[i] = t[i] + __shfl_xor(t[i], 4);
-        t[i] = t[i] + __shfl_xor(t[i], 8);
-        t[i] = t[i] + __shfl_xor(t[i], 16);
-        t[i] = t[i] + __shfl_xor(t[i], 32);
-    }
-    float mine = t[0];
-    #pragma unroll
-    for (int i = 1; i < 8; i++) mine = (4 * eg + ev) == i ? t[i] : mine;
-    if (elive) linear_epilogue_pre(a, en, em, mine, pre);
+    for (int v = 0; v < 4; v++) red[w][r][4 * g + v] = (acc[v] + acc[4 + v]) + (acc[8 + v] + acc[12 + v]);
+    __syncthreads();
+    const int row = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const float v = (red[0][sl][row] + red[1][sl][row]) + (red[2][sl][row] + red[3][sl][row]);
+    if (live) linear_epilogue_pre(a, en, em, v, pre);
 }
-
 template <int NBLK>
-static void launch_slots4_n(hipStream_t s, const LinArgs & a) {
-    hipLaunchKernelGGL((gemm_slots4_kernel<NBLK>), dim3((a.M + 3) / 4), dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
+    hipLaunchKernelGGL((gemm_slots16_kernel<NBLK>), dim3((a.M + 15) / 16, (a.nbatch + 15) / 16), dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
 }
 
 void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
-    (void) kind;                                                 // one matrix-core route survives (kind != 0); 0 = the VALU GEMV, chosen by the callers
+    (void) kind;                                                 // one matrix-core route (kind != 0); 0 = the VALU GEMV, chosen by the callers
     if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
     switch (a.K >> 7) {
-        case 1:  launch_slots4_n<1>(s, a); break;
-        case 2:  launch_slots4_n<2>(s, a); break;
-        case 4:  launch_slots4_n<4>(s, a); break;
-        case 6:  launch_slots4_n<6>(s, a); break;
-        case 8:  launch_slots4_n<8>(s, a); break;
-        case 16: launch_slots4_n<16>(s, a); break;
-        case 24: launch_slots4_n<24>(s, a); break;
-        case 32: launch_slots4_n<32>(s, a); break;
+        case 1:  launch_slots16_n<1>(s, a); break;
+        case 2:  launch_slots16_n<2>(s, a); break;
+        case 4:  launch_slots16_n<4>(s, a); break;
+        case 6:  launch_slots16_n<6>(s, a); break;
+        case 8:  launch_slots16_n<8>(s, a); break;
+        case 16: launch_slots16_n<16>(s, a); break;
+        case 24: launch_slots16_n<24>(s, a); break;
+        case 32: launch_slots16_n<32>(s, a); break;
         default: kernel_fail("bark-hip: unsupported K=%d in the lock-step MFMA product", a.K);
     }
 }
