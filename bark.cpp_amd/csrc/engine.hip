@@ -91,7 +91,7 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.vt = layer_vt(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
         static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
-        const bool ps = use_ps && !m.q4 && P == 1024 && m.vtcache;
+        const bool ps = use_ps && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
         if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
         BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 4 * (E / 4));        // room for all four copies of the q workgroups
         launch_linear(s, a);

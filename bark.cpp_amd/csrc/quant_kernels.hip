@@ -2,6 +2,7 @@
 // written by bark_model_quantize) and plain f32 (files converted without --use-f16).  Same canonical chains as kernels.hip.
 #include "device_utils.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -91,114 +92,180 @@ template <int NV> DEVINL int quantize_levels(const float (&v)[NV], float id, int
     return sum;
 }
 
-// decode (N = 1): x is an f32 row, optionally LayerNorm-ed first.  A 256-thread workgroup owns 16 output rows:
-//   1. every lane requests the weight blocks of its chain (up to 8) before anything else,
-//   2. the q8 quantisation of x (~8 VALU ops per element) is spread over the workgroup - two threads per block of 32,
-//      block maximum / level sum through one DPP exchange - and published in LDS once for the 16 rows,
-//   3. wave w dots rows 4 w .. 4 w + 3: lane c of a row walks the blocks c, c + 16, ... (chain c of C1q).
-// The first version quantised inside every 16-lane group (each lane its own blocks): 1500 VALU instructions per wave
-// for K = 3072, 8.0 us per launch; this one measures about half of that (quantised files).
-template <int QT, bool LN, bool LNB>
-__global__ __launch_bounds__(256) void gemv_q_kernel(const LinArgs a) {
-    constexpr int MAXB = 8;                                    // blocks per chain: K <= 4096
-    __shared__ int4 xq[128][2];                                // q8 levels of block b: elements 0..15 and 16..31
-    __shared__ float xd[128], xs[128];
-    __shared__ double red[2][4];
+// decode (N = 1): x is an f32 row, optionally LayerNorm-ed first.  A 256-thread workgroup owns 16 output rows and follows the
+// f16 decode GEMV of kernels.hip (gemv_ln_wg_kernel), whose structure the in-kernel time line of round 2 paid for:
+//   0. what the first loads need arrives as explicit leading parameters (preloaded into SGPRs at wave launch): the row to normalise is
+//      requested first, the weight blocks of every lane's chain (up to 8) right behind it, the argument struct is read behind both;
+//   1. LayerNorm (ggml_norm: double sums) by wave 0 alone, the normalised f32 row published in LDS - one barrier instead of the two
+//      cross-wave reductions every workgroup used to run;
+//   2. q8 quantisation of the row (ggml quantize_row_q8_0 / q8_1) by the whole workgroup: four consecutive elements per thread, the
+//      block maximum and level sum over the 8 threads of a block by three DPP steps, levels packed into LDS; second barrier;
+//   3. wave w dots rows 4 w .. 4 w + 3: lane c of a row walks the blocks c, c + 16, ... (chain c of C1q): exact integer block sums on
+//      v_dot4_i32_i8, per-format scaling, plain float adds in ascending block order, C1 tree over the 16 lanes.
+//   PS (QKV product of a decode step, block_size 1024): as in the f16 kernel, copies of the q workgroups behind the main grid repeat the
+//      16 q rows of one C2 block and score the cached keys against them (partial scores for attn_ps_kernel).
+// Lock-step batches: grid.y = slot (own x row, state, KV cache).
+// NBLK = K / 128 is a compile-time constant and every load is unconditional (lanes without a block in the last round re-read their
+// neighbour's): guarded loads compile to load / s_waitcnt vmcnt(0) / branch chains, one exposed memory round trip each (the first cut
+// of this kernel took 2.4 us to get the row into LDS that way, in-kernel time line profiles/r03_trace_q4_decode_step.txt).
+template <int QT, int NBLK, bool LN, bool LNB, bool PS>
+__global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t * __restrict__ wqs, const half_t * __restrict__ wd, const float * __restrict__ x_f32,
+                                                     const float * __restrict__ ln_g, const float * __restrict__ ln_b, const StepState * __restrict__ st,
+                                                     const int M, const int parity_rows, const int kpc, const LinArgs a) {
+    TRACE_T0();
+    TRACE_T1(M);
+    [[maybe_unused]] unsigned long long stamp_a = 0, stamp_b = 0;       // diagnostic build: LayerNorm-ed row / quantised row available
+    constexpr int K = NBLK * 128, nblk = K / 32;               // q8 blocks per row
+    constexpr int NCH = (nblk + 15) / 16;                      // blocks per chain (rounds): the last round may be partial
+    constexpr int EPT = K / 64;                                // row elements per lane of the normalising wave
+    constexpr int NQ = (K / 4 + 255) / 256;                    // quantisation rounds: four elements per thread and round
+    static_assert(!LN || K <= 1024, "LayerNorm-fused quantised GEMV: n_embd <= 1024");
+    __shared__ __attribute__((aligned(16))) float xs[LN ? K : 4];        // LayerNorm-ed row
+    __shared__ __attribute__((aligned(16))) int xq[nblk * 8];            // q8 levels, four per dword: block b = dwords 8 b .. 8 b + 7
+    __shared__ float xd[nblk], xsm[nblk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
-    const int m = blockIdx.x * 16 + wave * 4 + rg;
-    const int K = a.K, nblk = K >> 5;
-    const int slot = a.batched ? blockIdx.y : 0;              // lock-step batch: one sequence per grid.y (own x row, state, KV cache)
-    const int row_off = a.parity_rows ? a.parity_rows * (a.st->step & 1) : 0;
-    const bool live = m < a.M;
+    const int slot = blockIdx.y;                              // lock-step batch: one sequence per grid.y (a single sequence: grid.y == 1)
+    [[maybe_unused]] const int n_main = (M + 15) >> 4, n_q = K >> 4;     // PS: the QKV product, n_embd == K
+    [[maybe_unused]] const bool copy = PS && (int) blockIdx.x >= n_main;
+    [[maybe_unused]] const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
+    const int wg = copy ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
+    const int m = wg * 16 + wave * 4 + rg;
+    const int row_off = parity_rows ? parity_rows * (st->step & 1) : 0;
+    const bool live = m < M;
     const size_t wrow = (size_t) (row_off + (live ? m : 0)) * nblk;
-    RawBlock<QT> wb[MAXB];
-    #pragma unroll
-    for (int i = 0; i < MAXB; i++) {
-        const int b = c + 16 * i;
-        if (b < nblk) wb[i] = load_raw<QT>(a.wq, wrow + b);
-    }
-    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, row_off);
-
-    // ---- x -> q8: thread t quantises elements [16 (t & 1), +16) of block t >> 1
-    const int qb = tid >> 1, qh = tid & 1;
-    const bool mine = qb < nblk;
-    const int k0 = mine ? (qb << 5) + (qh << 4) : 0;
-    float v[16];
-    {
-        const float4 * xp = reinterpret_cast<const float4 *>(a.x_f32 + (size_t) slot * K + k0);
-        #pragma unroll
-        for (int i = 0; i < 4; i++) { const float4 f = xp[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
-    }
+    const float * xrow = x_f32 + (size_t) slot * K;
+    // ---- 0. requests: the row first (loads return in order), then the weights
+    [[maybe_unused]] float xv[EPT], gv[EPT], bv[EPT];
+    [[maybe_unused]] float4 xdir[NQ];                         // no LayerNorm: thread t quantises elements 4 (t + 256 r) .. + 3
     if constexpr (LN) {
-        float g[16], bb[16];
-        {
-            const float4 * gp = reinterpret_cast<const float4 *>(a.ln_g + k0);
-            const float4 * bp = reinterpret_cast<const float4 *>((LNB ? a.ln_b : a.ln_g) + k0);
+        if (wave == 0) {
             #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float4 f = gp[i]; g[4 * i] = f.x; g[4 * i + 1] = f.y; g[4 * i + 2] = f.z; g[4 * i + 3] = f.w;
-                if constexpr (LNB) { const float4 h = bp[i]; bb[4 * i] = h.x; bb[4 * i + 1] = h.y; bb[4 * i + 2] = h.z; bb[4 * i + 3] = h.w; }
+            for (int i = 0; i < EPT; i++) xv[i] = xrow[lane + 64 * i];
+            #pragma unroll
+            for (int i = 0; i < EPT; i++) { gv[i] = ln_g[lane + 64 * i]; if constexpr (LNB) bv[i] = ln_b[lane + 64 * i]; else bv[i] = 0.0f; }
+        }
+    } else {
+        #pragma unroll
+        for (int r = 0; r < NQ; r++) xdir[r] = *reinterpret_cast<const float4 *>(xrow + 4 * min(tid + 256 * r, K / 4 - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    RawBlock<QT> wb[NCH];
+    #pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const size_t bi = wrow + min(c + 16 * i, nblk - 1);
+        if constexpr (QTraits<QT>::wide) { const uint4 * p = reinterpret_cast<const uint4 *>(wqs) + 2 * bi; wb[i].qs = p[0]; wb[i].qs2 = p[1]; }
+        else wb[i].qs = reinterpret_cast<const uint4 *>(wqs)[bi];
+        wb[i].d = wd[bi];
+    }
+    const int n_past_now = st ? st[slot].n_past : 0;          // on the preloaded state pointer, not through the argument struct
+    __builtin_amdgcn_sched_barrier(0);                        // everything above goes out on the preloaded arguments alone
+    #pragma unroll
+    for (int i = 0; i < NCH; i++) {
+        const size_t bi = wrow + min(c + 16 * i, nblk - 1);
+        if constexpr (QTraits<QT>::has_h) wb[i].qh = a.wq.qh[bi];
+        if constexpr (QTraits<QT>::has_m) wb[i].m = a.wq.m[bi];
+    }
+    EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, row_off);
+    if (PS || a.epi == EPI_QKV) pre.n_past = n_past_now;
+    // partial scores (copies only): keys rep * kpc + tid (+ 256); d-quads 4 blk .. 4 blk + 3 of head hq; requested once the row is in LDS
+    [[maybe_unused]] float4 kq[2][4];
+    [[maybe_unused]] const int m0 = wg * 16;
+    [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
+
+    // ---- 1. LayerNorm by wave 0 (ggml_norm: double sums, eps on the variance; bark.cpp:1265-1274)
+    if constexpr (LN) {
+        if (wave == 0) {
+            double p1[4] = {0.0, 0.0, 0.0, 0.0};
+            #pragma unroll
+            for (int i = 0; i < EPT; i++) p1[i & 3] += (double) xv[i];
+            const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+            const float mean = (float) div_by_const<K>(s1);
+            double p2[4] = {0.0, 0.0, 0.0, 0.0};
+            #pragma unroll
+            for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; p2[i & 3] += (double) (xv[i] * xv[i]); }
+            const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+            const float var = (float) div_by_const<K>(s2);
+            const float scale = 1.0f / sqrtf(var + 1e-5f);
+            #pragma unroll
+            for (int i = 0; i < EPT; i++) {
+                float u = xv[i] * scale;
+                u = u * gv[i];
+                if constexpr (LNB) u = u + bv[i];
+                xs[lane + 64 * i] = u;
             }
         }
-        // ggml_norm: double sums over the row (bark.cpp:1265-1274)
-        double s1 = 0.0;
-        if (mine) {
+        __syncthreads();
+        TRACE_SET(stamp_a, xs[0]);
+    }
+    if constexpr (PS) {
+        if (copy) {
+            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(a.kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // PS implies P == 1024
             #pragma unroll
-            for (int j = 0; j < 16; j++) s1 += (double) v[j];
-        }
-        s1 = wave_sum(s1);
-        if (lane == 0) red[0][wave] = s1;
-        __syncthreads();
-        const float mean = (float) (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double) K);
-        double s2 = 0.0;
-        #pragma unroll
-        for (int j = 0; j < 16; j++) { const float u = v[j] - mean; v[j] = u; if (mine) s2 += (double) (u * u); }
-        s2 = wave_sum(s2);
-        if (lane == 0) red[1][wave] = s2;
-        __syncthreads();
-        const float var = (float) (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double) K);
-        const float scale = 1.0f / sqrtf(var + 1e-5f);
-        #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            float u = v[j] * scale;
-            u = u * g[j];
-            if constexpr (LNB) u = u + bb[j];
-            v[j] = u;
+            for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);
+            if (tid + 256 < kpc) {
+                #pragma unroll
+                for (int i = 0; i < 4; i++) kq[1][i] = buf_ld_f4(kr, (unsigned) tid * 16u + 4096u, (unsigned) i * 16384u);
+            }
         }
     }
-    {
-        float amax = 0.0f;
-        #pragma unroll
-        for (int j = 0; j < 16; j++) amax = fmaxf(amax, fabsf(v[j]));
-        amax = fmaxf(amax, dpp_f32<DPP_XOR1>(amax));           // the other half of the block sits in the neighbouring lane
+    // ---- 2. q8 quantisation: thread t owns elements 4 t' .. 4 t' + 3 (t' = t + 256 r), the 8 threads 8 b .. 8 b + 7 own block b
+    #pragma unroll
+    for (int r = 0; r < NQ; r++) {
+        const int t4 = tid + 256 * r;
+        float4 f;
+        if constexpr (LN) f = *reinterpret_cast<const float4 *>(xs + 4 * min(t4, K / 4 - 1)); else f = xdir[r];
+        const float v[4] = {f.x, f.y, f.z, f.w};
+        float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        amax = fmaxf(amax, dpp_f32<DPP_XOR1>(amax)); amax = fmaxf(amax, dpp_f32<DPP_XOR2>(amax)); amax = fmaxf(amax, dpp_f32<DPP_HALF_MIRROR>(amax));
         const float d = amax / 127.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
-        int q[4];
-        int sum = quantize_levels<16>(v, id, q);
-        sum += __builtin_amdgcn_update_dpp(0, sum, DPP_XOR1, 0xF, 0xF, false);
-        if (mine) {
-            xq[qb][qh] = make_int4(q[0], q[1], q[2], q[3]);
-            if (qh == 0) { xd[qb] = (float) to_half(d); xs[qb] = (float) to_half((float) sum * d); }
+        int q[1];
+        int sum = quantize_levels<4>(v, id, q);
+        if constexpr (QTraits<QT>::has_m) {
+            sum += dpp_i32<DPP_XOR1>(sum); sum += dpp_i32<DPP_XOR2>(sum); sum += dpp_i32<DPP_HALF_MIRROR>(sum);
+        }
+        if (4 * t4 < K) {                                      // K is a multiple of 32: whole 8-thread groups are in or out together
+            xq[t4] = q[0];
+            if ((t4 & 7) == 0) { xd[t4 >> 3] = (float) to_half(d); if constexpr (QTraits<QT>::has_m) xsm[t4 >> 3] = (float) to_half((float) sum * d); }
         }
     }
     __syncthreads();
+    TRACE_SET(stamp_b, xd[0]);
 
+    // ---- 3. dot
     float acc = 0.0f;
     #pragma unroll
-    for (int i = 0; i < MAXB; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int b = c + 16 * i;
-        if (b < nblk) {
-            const int4 q0 = xq[b][0], q1 = xq[b][1];
-            const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            int w[8]; unpack_raw<QT>(wb[i], w);
-            const int sumi = dot_q4_q8(w, q);
-            const float tb = block_term<QT>(sumi, (float) wb[i].d, QTraits<QT>::has_m ? (float) wb[i].m : 0.0f, xd[b], xs[b]);
-            acc = acc + tb;
+        const int bl = min(b, nblk - 1);
+        const int4 q0 = *reinterpret_cast<const int4 *>(xq + 8 * bl), q1 = *reinterpret_cast<const int4 *>(xq + 8 * bl + 4);
+        const int q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        int w[8]; unpack_raw<QT>(wb[i], w);
+        const int sumi = dot_q4_q8(w, q);
+        const float tb = block_term<QT>(sumi, (float) wb[i].d, QTraits<QT>::has_m ? (float) wb[i].m : 0.0f, xd[bl], QTraits<QT>::has_m ? xsm[bl] : 0.0f);
+        const float nxt = acc + tb;
+        acc = ((i + 1) * 16 <= nblk || b < nblk) ? nxt : acc;  // a lane without a block in the last round keeps its sum
+    }
+    TRACE_T2(acc);
+    acc = wave_xor_add16(acc);
+    if (live && c == 0 && !copy) linear_epilogue_pre(a, slot, m, acc, pre);
+    if constexpr (PS) {
+        __shared__ float qsh[16];
+        if (copy) {                                              // uniform per workgroup
+            if (c == 0) qsh[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
+            __syncthreads();
+            float qb[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) qb[i] = qsh[i];
+            const int j = rep * kpc + tid;
+            if (j < pre.n_past) a.ps[((size_t) hq * 4 + blk) * a.P + j] = score_block_f4(kq[0], qb);
+            if (tid + 256 < kpc && j + 256 < pre.n_past) a.ps[((size_t) hq * 4 + blk) * a.P + j + 256] = score_block_f4(kq[1], qb);
         }
     }
-    acc = wave_xor_add16(acc);
-    if (live && c == 0) linear_epilogue_pre(a, slot, m, acc, pre);
+#ifdef BARK_TRACE
+    trace_emit(a.tr, _tr0, _tr1, _tr2, trace_clock(), stamp_a, stamp_b);
+#endif
 }
 
 // rows (N > 1): q8 quantisation of the activation rows once (optionally with the LayerNorm in front), one wave per row
@@ -396,17 +463,45 @@ void launch_q8_rows(hipStream_t s, const float * x, int N, int K, const float * 
     hipLaunchKernelGGL(q8_rows_kernel, dim3(N), dim3(64), 0, s, a);
 }
 
+template <int QT, int NBLK>
+static void launch_gemv_q_n(hipStream_t s, const LinArgs & a) {
+    // lock-step batch: grid.y walks the sequences; grid.x rounded up to a multiple of 8 so that every grid.y of a row group
+    // lands on the same XCD and re-reads the weight blocks from its L2
+    const int gx = (a.M + 15) / 16;
+    dim3 grid(a.batched ? (gx + 7) / 8 * 8 : gx, a.batched ? a.nbatch : 1), block(256);
+    const float * xr = a.x_f32;
+    if (a.ln_g) {
+        if constexpr (NBLK <= 8) {
+            if (a.ps && a.epi == EPI_QKV && a.P == 1024 && !a.batched) {
+                // copies of the q workgroups that score the cached keys: sized as in launch_gemv_n (kernels.hip)
+                const int n_main = gx, n_q = a.E / 16, keys = 256 * std::max(1, std::min(a.ng, 4));
+                const int fit = std::max(1, std::min(2, (256 - n_main) / n_q));
+                const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));
+                const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;
+                const dim3 gps(n_main + n_copy * n_q);
+                if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, NBLK, true, true, true>), gps, block, 0, s, a.wq.qs, a.wq.d, xr, a.ln_g, a.ln_b, a.st, a.M, a.parity_rows, kpc, a);
+                else        hipLaunchKernelGGL((gemv_q_kernel<QT, NBLK, true, false, true>), gps, block, 0, s, a.wq.qs, a.wq.d, xr, a.ln_g, a.ln_b, a.st, a.M, a.parity_rows, kpc, a);
+            }
+            else if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, NBLK, true, true, false>), grid, block, 0, s, a.wq.qs, a.wq.d, xr, a.ln_g, a.ln_b, a.st, a.M, a.parity_rows, 0, a);
+            else             hipLaunchKernelGGL((gemv_q_kernel<QT, NBLK, true, false, false>), grid, block, 0, s, a.wq.qs, a.wq.d, xr, a.ln_g, a.ln_b, a.st, a.M, a.parity_rows, 0, a);
+        } else { kernel_fail("bark-hip: LayerNorm-fused quantised GEMV supports n_embd <= 1024"); }
+    } else hipLaunchKernelGGL((gemv_q_kernel<QT, NBLK, false, false, false>), grid, block, 0, s, a.wq.qs, a.wq.d, xr, a.ln_g, a.ln_b, a.st, a.M, a.parity_rows, 0, a);
+}
+
 template <int QT>
 static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
     if (a.N == 1) {
-        // lock-step batch: grid.y walks the sequences; grid.x rounded up to a multiple of 8 so that every grid.y of a row group
-        // lands on the same XCD and re-reads the weight blocks from its L2
-        const int gx = (a.M + 15) / 16;
-        dim3 grid(a.batched ? (gx + 7) / 8 * 8 : gx, a.batched ? a.nbatch : 1), block(256);
-        if (a.ln_g) {
-            if (a.ln_b) hipLaunchKernelGGL((gemv_q_kernel<QT, true, true>), grid, block, 0, s, a);
-            else        hipLaunchKernelGGL((gemv_q_kernel<QT, true, false>), grid, block, 0, s, a);
-        } else hipLaunchKernelGGL((gemv_q_kernel<QT, false, false>), grid, block, 0, s, a);
+        switch (a.K >> 7) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
+            case 1:  launch_gemv_q_n<QT, 1>(s, a); break;
+            case 2:  launch_gemv_q_n<QT, 2>(s, a); break;
+            case 4:  launch_gemv_q_n<QT, 4>(s, a); break;
+            case 6:  launch_gemv_q_n<QT, 6>(s, a); break;
+            case 8:  launch_gemv_q_n<QT, 8>(s, a); break;
+            case 16: launch_gemv_q_n<QT, 16>(s, a); break;
+            case 24: launch_gemv_q_n<QT, 24>(s, a); break;
+            case 32: launch_gemv_q_n<QT, 32>(s, a); break;
+            default: kernel_fail("bark-hip: unsupported K=%d in quantised decode GEMV", a.K);
+        }
         return;
     }
     static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, the cross-check path
@@ -431,6 +526,7 @@ void init_quant_attributes() {
 
 void launch_linear_q(hipStream_t s, const LinArgs & a) {
     if ((a.K & 31) != 0 || a.K > 4096) { kernel_fail("bark-hip: quantised rows must be a multiple of 32 and at most 4096 long"); }
+    if (a.N == 1 && (a.K & 127) != 0) { kernel_fail("bark-hip: quantised decode GEMV needs rows that are a multiple of 128 long"); }
     if (a.batched && (a.N != 1 || a.ln_stats)) { kernel_fail("bark-hip: batched quantised products take one row per sequence and in-kernel LayerNorm statistics"); }
     if (a.N == 1 && !a.x_f32) { kernel_fail("bark-hip: quantised GEMV needs an f32 activation row"); }
     if (a.N > 1 && (!a.xq.q || a.parity_rows)) { kernel_fail("bark-hip: quantised row product needs pre-quantised rows"); }

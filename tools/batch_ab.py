@@ -22,7 +22,7 @@ print("RESULT", json.dumps(out))
 ''' % ROOT
 # arms: NAME[:K=V,K=V...] on the command line; default: the VALU route against the two MFMA routes
 arms = []
-for a in sys.argv[1:] or ["valu:BARK_HIP_BATCH_MFMA=0", ""mfma4:BARK_HIP_BATCH_MFMA=2"]:
+for a in sys.argv[1:] or ["valu:BARK_HIP_BATCH_MFMA=0", "mfma"]:
     name, _, kv = a.partition(":")
     arms.append((name, dict(x.split("=") for x in kv.split(",") if x)))
 for name, env in arms:

@@ -5,7 +5,7 @@ Every wave of the decode kernels logs s_memrealtime (100 MHz) at entry, after it
 operands have arrived (dot product done) and at its end.  Per kernel of the captured step this prints, in microseconds relative to
 the step's first wave: first entry, last exit, the gap to the previous kernel's last exit, and the medians of the three phases.
 
-  python tools/trace_decode.py [small] [ctx] [out.json]
+  python tools/trace_decode.py [small] [ctx] [out.json] [f16 | q4_0 | ...]
 """
 import ctypes as C
 import json
@@ -25,9 +25,16 @@ def main():
     preset = sys.argv[1] if len(sys.argv) > 1 else "small"
     ctxlen = int(sys.argv[2]) if len(sys.argv) > 2 else 640
     out_path = sys.argv[3] if len(sys.argv) > 3 else None
+    fmt = sys.argv[4] if len(sys.argv) > 4 else "f16"     # or a block format: the model file is quantised first
     pkg = load_package()
     lib = pkg.load_library()
-    ctx = pkg.BarkContext.load_model(ensure_model(preset, 0), pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=32), 0)
+    path = ensure_model(preset, 0)
+    if fmt != "f16":
+        qpath = path[:-4] + "_%s.bin" % fmt
+        if not os.path.exists(qpath):
+            assert lib.bark_model_quantize(path.encode(), qpath.encode(), {"q4_0": 2, "q4_1": 3, "q8_0": 7, "q5_0": 8, "q5_1": 9}[fmt])
+        path = qpath
+    ctx = pkg.BarkContext.load_model(path, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=32), 0)
     replays = 4
     cap = 1 << 19
     buf = np.zeros((cap, 8), np.uint64)
