@@ -105,8 +105,9 @@ struct bark_context {
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
     hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook
     int * d_lstm_t = nullptr;                           // step counter of the replayed LSTM block
-    struct LstmGraph { hipGraphExec_t exec = nullptr; int T = 0; const float * hseq = nullptr; const float * gi = nullptr; } lstm_graphs[2];
-    struct CodecGraph { hipGraphExec_t exec = nullptr; int T = 0; const float * buf = nullptr; float * out = nullptr; int n_out = 0; } codec_graph;   // conv stack behind the LSTM
+    int * d_codec_T = nullptr;                          // frame counts of the utterances being decoded and their prefix sums (CodecBatch)
+    struct LstmGraph { hipGraphExec_t exec = nullptr; int B = 0; const float * out = nullptr; const float * gi = nullptr; } lstm_graph;    // 64 wave-front steps
+    struct CodecGraph { hipGraphExec_t exec = nullptr; std::vector<int> T; const float * buf = nullptr; float * out = nullptr; int tmul = 0; } codec_graph;   // conv stack behind the LSTM
 
     // batched decode (several utterances in lock step on this context, bark_hip_generate_batch): per-slot KV caches
     // and decode rows; prefill / fine / codec still run one utterance at a time on the buffers above
@@ -151,6 +152,9 @@ std::vector<int32_t> engine_coarse(bark_context * ctx, const std::vector<int32_t
 std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> & coarse_Tx2);          // [T][8]
 // tap_stage >= 0: *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
 std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap);
+// all utterances of a batch in one pass (codes[b]: [n_q][T[b]]); the launches of one utterance serve all of them
+std::vector<std::vector<float>> engine_codec_decode_many(bark_context * ctx, const std::vector<const int32_t *> & codes, int n_q, const std::vector<int> & T,
+                                                         int tap_stage, std::vector<float> * tap);
 bool engine_generate(bark_context * ctx, const char * text);
 // seeds: one std::mt19937 seed per utterance (temp > 0); nullptr: drawn from the context's generator, in order.  Returns #ok
 int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n, const uint32_t * seeds);

@@ -641,182 +641,6 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// EnCodec decode (encodec_decompress_audio call site, bark.cpp:2143-2167)
-// ---------------------------------------------------------------------------------------------------
-std::vector<float> engine_codec_decode(bark_context * c, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap) {
-    HIP_OK(hipSetDevice(c->device));
-    CodecModel & cm = c->codec;
-    if (n_q <= 0 || n_q > cm.n_q || T <= 0 || T > 4096) throw std::runtime_error("codec: bad code matrix shape");
-    for (size_t i = 0; i < (size_t) n_q * T; i++) if (codes[i] < 0 || codes[i] >= cm.hp.n_bins) throw std::runtime_error("codec: code out of range");
-    hipStream_t s = c->stream;
-    const int D = cm.D;
-    int hop = 1; for (auto & b : cm.blocks) hop *= b.up.stride;
-    // largest activation: channels x time at every stage
-    size_t need = (size_t) std::max(cm.hp.hidden_dim, D) * T;
-    { int ch = D, tt = T; for (auto & b : cm.blocks) { ch = b.up.cout; tt *= b.up.stride; need = std::max(need, (size_t) ch * tt); } }
-    if (need > c->cbuf_elems) {
-        for (auto & b : c->cbuf) b = dev_alloc<float>(c, need);
-        c->cbuf_h = dev_alloc<half_t>(c, need);
-        c->cbuf_elems = need;
-    }
-    if ((size_t) T > c->c_T) {
-        c->c_gi = dev_alloc<float>(c, (size_t) T * 4 * D);
-        c->c_cell = dev_alloc<float>(c, (size_t) D);
-        c->c_hseq_h = dev_alloc<half_t>(c, (size_t) T * D);
-        c->c_xt_h = dev_alloc<half_t>(c, (size_t) T * D);
-        c->c_hseq2_h = dev_alloc<half_t>(c, (size_t) T * D);
-        c->c_cell2 = dev_alloc<float>(c, (size_t) D);
-        c->c_T = (size_t) T;
-    }
-    if ((size_t) n_q * T > c->d_codes_elems) { c->d_codes = dev_alloc<int32_t>(c, (size_t) n_q * T); c->d_codes_elems = (size_t) n_q * T; }
-    HIP_OK(hipMemcpyAsync(c->d_codes, codes, (size_t) n_q * T * 4, hipMemcpyHostToDevice, s));
-    float * A = c->cbuf[0], * B = c->cbuf[1], * R = c->cbuf[2];
-    half_t * Hh = c->cbuf_h;
-    static const bool blocked = !getenv("BARK_HIP_CODEC_NAIVE");      // register-blocked convs (default) vs the one-output-per-thread kernels
-
-    auto conv = [&](const CodecModel::Conv & cv, const float * in, bool elu, int Tc, const float * add, float * out) {
-        launch_act_round(s, in, (size_t) cv.cin * Tc, elu ? 1 : 0, Hh);
-        if (blocked && cv.w32 && conv1d_f32w_supported(cv.k)) launch_conv1d_f32w(s, cv.w32, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
-        else launch_conv1d(s, cv.w, cv.b, cv.cout, cv.cin, cv.k, Hh, Tc, add, out);
-    };
-    // RVQ de-embedding, first conv
-    launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, T, A);
-    conv(cm.init, A, false, T, nullptr, B);                            // B = x [D][T]
-    // 2-layer LSTM + skip (modeling_encodec.py:236-249)
-    static const bool lstm_pair = !getenv("BARK_HIP_LSTM_PAIR") || atoi(getenv("BARK_HIP_LSTM_PAIR")) != 0;
-    if (lstm_pair) {
-        // both layers as a wave front: launch i = layer 1 at step i + layer 2 at step i - 1 (its input projection formed in the same
-        // kernel): T + 1 strictly sequential launches instead of 2 T.  64 of them are captured once as a hipGraph whose nodes take
-        // their launch index from a device counter, so one graph serves every T.
-        launch_transpose_round(s, B, D, T, c->c_xt_h);
-        LinArgs g;
-        g.W = cm.lstm[0].w_ih; g.M = 4 * D; g.K = D; g.N = T; g.x_f16 = c->c_xt_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
-        launch_linear(s, g);
-        LstmPairArgs a;
-        a.gi1 = c->c_gi; a.w_hh1 = cm.lstm[0].w_hh; a.b_ih1 = cm.lstm[0].b_ih; a.b_hh1 = cm.lstm[0].b_hh; a.c1 = c->c_cell; a.h1 = c->c_hseq_h;
-        a.w_ih2 = cm.lstm[1].w_ih; a.w_hh2 = cm.lstm[1].w_hh; a.b_ih2 = cm.lstm[1].b_ih; a.b_hh2 = cm.lstm[1].b_hh; a.c2 = c->c_cell2; a.h2 = c->c_hseq2_h;
-        a.out2 = R; a.T = T; a.D = D;
-        if (!c->use_graph) {
-            for (int i = 0; i <= T; i++) { a.t = i; launch_lstm_pair_step(s, a); }
-        } else {
-            constexpr int kBlock = 64;
-            auto & slot = c->lstm_graphs[0];
-            if (slot.exec && (slot.hseq != R || slot.gi != c->c_gi || slot.T != -1)) { (void) hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
-            if (!slot.exec) {
-                hipGraph_t graph = nullptr;
-                HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                a.t_base = c->d_lstm_t;
-                for (int i = 0; i < kBlock; i++) { a.t = i; launch_lstm_pair_step(s, a); }
-                launch_add_int(s, c->d_lstm_t, kBlock);
-                HIP_OK(hipStreamEndCapture(s, &graph));
-                HIP_OK(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
-                (void) hipGraphDestroy(graph);
-                slot.T = -1; slot.hseq = R; slot.gi = c->c_gi;       // T = -1 marks the wave-front graph
-            }
-            const int hdr[2] = {0, T};
-            HIP_OK(hipMemcpyAsync(c->d_lstm_t, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
-            HIP_OK(hipStreamSynchronize(s));                         // hdr is a stack object
-            for (int i0 = 0; i0 <= T; i0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
-        }
-    } else {
-    const float * lin = B;
-    for (int l = 0; l < 2; l++) {
-        const half_t * seq_h;
-        if (l == 0) { launch_transpose_round(s, lin, D, T, c->c_xt_h); seq_h = c->c_xt_h; }
-        else { HIP_OK(hipMemcpyAsync(c->c_xt_h, c->c_hseq_h, (size_t) T * D * sizeof(half_t), hipMemcpyDeviceToDevice, s)); seq_h = c->c_xt_h; }
-        LinArgs g;
-        g.W = cm.lstm[l].w_ih; g.M = 4 * D; g.K = D; g.N = T; g.x_f16 = seq_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
-        launch_linear(s, g);
-        float * hseq = (l == 0) ? A : R;                                // layer outputs [D][T]
-        // T strictly sequential steps.  64 of them are captured once per context and layer as a hipGraph whose nodes
-        // take their step index from a device counter (base) + the node's offset, so one graph serves every T.
-        LstmStepArgs a;
-        a.w_hh = cm.lstm[l].w_hh; a.b_ih = cm.lstm[l].b_ih; a.b_hh = cm.lstm[l].b_hh; a.gi = c->c_gi;
-        a.c = c->c_cell; a.hseq_h = c->c_hseq_h; a.hseq = hseq; a.T = T; a.D = D;
-        if (!c->use_graph) {
-            for (int t = 0; t < T; t++) { a.t = t; launch_lstm_step(s, a); }
-        } else {
-            constexpr int kBlock = 64;
-            auto & slot = c->lstm_graphs[l];
-            if (slot.exec && (slot.hseq != hseq || slot.gi != c->c_gi)) { (void) hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
-            if (!slot.exec) {
-                hipGraph_t graph = nullptr;
-                HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                a.t_base = c->d_lstm_t;
-                for (int i = 0; i < kBlock; i++) { a.t = i; launch_lstm_step(s, a); }
-                launch_add_int(s, c->d_lstm_t, kBlock);
-                HIP_OK(hipStreamEndCapture(s, &graph));
-                HIP_OK(hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0));
-                (void) hipGraphDestroy(graph);
-                slot.T = T; slot.hseq = hseq; slot.gi = c->c_gi;
-            }
-            const int hdr[2] = {0, T};
-            HIP_OK(hipMemcpyAsync(c->d_lstm_t, hdr, sizeof(hdr), hipMemcpyHostToDevice, s));
-            HIP_OK(hipStreamSynchronize(s));                         // hdr is a stack object
-            for (int t0 = 0; t0 < T; t0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
-        }
-    }
-    }   // !lstm_pair
-    auto grab = [&](int stage, const float * buf, size_t n) {
-        if (tap_stage != stage || !tap) return;
-        tap->resize(n);
-        HIP_OK(hipMemcpyAsync(tap->data(), buf, n * 4, hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-    };
-    grab(0, B, (size_t) D * T);
-    // skip connection + the four upsampling blocks + final conv: ~40 launches, replayed from a hipGraph captured per frame count
-    // (the buffers are the context's own, so a graph stays valid until they are re-allocated for a longer input)
-    int Tc = T;
-    float * cur = A, * other = B;
-    auto tail = [&](bool taps) {
-        float * Rb = R;
-        launch_add(s, Rb, B, (size_t) D * T, A);                       // y + x ; A = x
-        if (taps) grab(1, A, (size_t) D * T);
-        cur = A; other = B; Tc = T;
-        for (int b = 0; b < 4; b++) {
-            const CodecModel::Block & bl = cm.blocks[b];
-            launch_act_round(s, cur, (size_t) bl.up.cin * Tc, 1, Hh);
-            if (blocked && bl.up.w32 && bl.up.k == 2 * bl.up.stride) launch_convtr1d_f32w(s, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
-            else launch_convtr1d(s, bl.up.w, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tc, other);
-            Tc *= bl.up.stride;
-            std::swap(cur, other);                                      // cur = upsampled x
-            // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)
-            conv(bl.c1, cur, true, Tc, nullptr, Rb);
-            conv(bl.c2, Rb, true, Tc, nullptr, other);                  // other = r
-            conv(bl.sc, cur, false, Tc, other, Rb);                     // Rb = shortcut(x) + r
-            std::swap(cur, Rb);
-            // keep three distinct buffers: cur (result), other, Rb (old x)
-            if (taps) grab(2 + b, cur, (size_t) bl.up.cout * Tc);
-        }
-        conv(cm.fin, cur, true, Tc, nullptr, other);
-    };
-    if (c->use_graph && tap_stage < 0) {
-        auto & cg = c->codec_graph;
-        if (cg.exec && (cg.T != T || cg.buf != A)) { (void) hipGraphExecDestroy(cg.exec); cg.exec = nullptr; }
-        if (!cg.exec) {
-            hipGraph_t graph = nullptr;
-            HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            try { tail(false); }
-            catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(s, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
-            HIP_OK(hipStreamEndCapture(s, &graph));
-            HIP_OK(hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0));
-            (void) hipGraphDestroy(graph);
-            cg.T = T; cg.buf = A; cg.out = other; cg.n_out = Tc;
-        }
-        HIP_OK(hipGraphLaunch(cg.exec, s));
-        c->stats.graph_replays++;
-        other = cg.out; Tc = cg.n_out;
-    } else {
-        tail(true);
-    }
-    std::vector<float> pcm((size_t) Tc);
-    HIP_OK(hipMemcpyAsync(pcm.data(), other, (size_t) Tc * 4, hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    (void) hop;
-    return pcm;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // bark_generate_audio (bark.cpp:2125-2172)
 // ---------------------------------------------------------------------------------------------------
 bool engine_generate(bark_context * c, const char * text) {

@@ -462,8 +462,10 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     }
     c->stats.t_coarse_us = now_us() - t;
 
-    // ---- fine + codec, one utterance at a time ------------------------------------------------------------
+    // ---- fine: one utterance at a time (a pass is compute-bound on its own: 214 GFLOP of exact f32 products) --------------------
     int good = 0;
+    std::vector<int> live;                                           // utterances that reach the codec
+    std::vector<std::vector<int32_t>> codes;
     for (int b = 0; b < B; b++) {
         bark_context::BatchResult & r = c->batch_results[(size_t) b];
         if (r.coarse.empty()) continue;
@@ -473,13 +475,24 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         std::swap(c->rng, slot_rng[(size_t) b]);
         c->stats.t_fine_us += now_us() - t;
         const int T = (int) r.fine.size() / 8;
-        std::vector<int32_t> codes((size_t) 8 * T);
-        for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) codes[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];
+        std::vector<int32_t> cd((size_t) 8 * T);
+        for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) cd[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];      // bark.cpp:2153-2159
+        codes.push_back(std::move(cd)); live.push_back(b);
+        c->stats.n_frames += T; c->stats.n_semantic += (int32_t) r.semantic.size();
+    }
+    // ---- codec: every utterance of the batch in one pass (engine_codec.hip) ----------------------------------------------------
+    if (!live.empty()) {
         t = now_us();
-        r.audio = engine_codec_decode(c, codes.data(), 8, T, -1, nullptr);
+        std::vector<const int32_t *> cp; std::vector<int> Ts;
+        for (size_t k = 0; k < live.size(); k++) { cp.push_back(codes[k].data()); Ts.push_back((int) codes[k].size() / 8); }
+        std::vector<std::vector<float>> pcm = engine_codec_decode_many(c, cp, 8, Ts, -1, nullptr);
         c->stats.t_codec_us += now_us() - t;
-        c->stats.n_frames += T; c->stats.n_samples += (int32_t) r.audio.size(); c->stats.n_semantic += (int32_t) r.semantic.size();
-        r.ok = true; good++;
+        for (size_t k = 0; k < live.size(); k++) {
+            bark_context::BatchResult & r = c->batch_results[(size_t) live[k]];
+            r.audio = std::move(pcm[k]);
+            c->stats.n_samples += (int32_t) r.audio.size();
+            r.ok = true; good++;
+        }
     }
     c->stats.t_eval_us = now_us() - t0;
     return good;

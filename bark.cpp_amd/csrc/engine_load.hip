@@ -83,7 +83,7 @@ bark_context::~bark_context() {
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
     for (auto & g : batch.graph) if (g) (void) hipGraphExecDestroy(g);
-    for (auto & g : lstm_graphs) if (g.exec) (void) hipGraphExecDestroy(g.exec);
+    if (lstm_graph.exec) (void) hipGraphExecDestroy(lstm_graph.exec);
     if (codec_graph.exec) (void) hipGraphExecDestroy(codec_graph.exec);
     for (auto & g : fine_graphs) if (g) (void) hipGraphExecDestroy(g);
     for (void * p : allocs) (void) hipFree(p);
@@ -285,6 +285,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         auto conv = [&](const std::string & p, CodecModel::Conv & cv) {
             const TensorRef & w = codec_weight(p + ".weight", 0, 0);
             if (w.n_dims != 3 || w.ne[3] != 1 || w.ne[0] > 64 || w.ne[1] > 4096 || w.ne[2] > 4096) throw std::runtime_error("codec conv weight '" + p + "' has an unexpected shape");
+            if (!conv1d_f32w_supported((int) w.ne[0])) throw std::runtime_error("codec conv '" + p + "': kernel sizes 1, 3 and 7 are implemented (EnCodec's)");
             cv.k = (int) w.ne[0]; cv.cin = (int) w.ne[1]; cv.cout = (int) w.ne[2];
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
@@ -294,6 +295,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         auto convt = [&](const std::string & p, CodecModel::ConvT & cv, int stride) {
             const TensorRef & w = codec_weight(p + ".weight", 0, 0);
             if (w.n_dims != 3 || w.ne[3] != 1 || w.ne[0] < stride || w.ne[0] > 64 || w.ne[1] > 4096 || w.ne[2] > 4096) throw std::runtime_error("codec transposed-conv weight '" + p + "' has an unexpected shape");
+            if (w.ne[0] != 2 * stride) throw std::runtime_error("codec transposed conv '" + p + "': kernel size must be twice the stride (EnCodec's)");
             cv.k = (int) w.ne[0]; cv.cout = (int) w.ne[1]; cv.cin = (int) w.ne[2]; cv.stride = stride;
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);

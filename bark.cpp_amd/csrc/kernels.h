@@ -189,43 +189,34 @@ void launch_linear_w32(hipStream_t s, const LinArgs & a);
 // Activations are channel-major [C][T] f32; every conv / LSTM matmul consumes them rounded to f16
 // (ggml im2col / mul_mat) and accumulates in f32 as ONE fmaf chain in
 // (ci, k) order, bias added last - the order the oracle uses.
-void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, float * z);
+// Several utterances in one launch (grid.z = utterance): utterance z has T[z] frames and every activation is the utterances' compact
+// [C][tmul T[z]] arrays back to back (utterance z starts at element C tmul Tpre[z]; Tpre = exclusive prefix sums of T, tmul = the stage's
+// upsampling factor).  T == nullptr: one utterance whose length is the launch's T argument.
+struct CodecBatch { const int * T = nullptr; const int * Tpre = nullptr; int B = 1; };
+void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, float * z, const CodecBatch & cb);
 // out_h = f16(elu ? ELU(x) : x), n elements
 void launch_act_round(hipStream_t s, const float * x, size_t n, int elu, half_t * out_h);
-// causal stride-1 conv with reflect padding on the left (k-1): y[co][t] = b[co] + chain(w[co][ci][k] * xh[ci][t+k-(K-1)]) (+ add[co][t])
-void launch_conv1d(hipStream_t s, const half_t * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
-                   const float * add, float * y);
-// causal transposed conv, stride s, output trimmed to T*s: y[co][to] = b[co] + chain over (ci, t) of w[ci][co][to - t*s] * xh[ci][t]
-void launch_convtr1d(hipStream_t s, const half_t * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
-                     int T, float * y);
-// register-blocked variants reading f32 copies of the (f16-valued) weights; same per-element chain order
+// causal stride-1 conv with reflect padding on the left (k-1): y[co][t] = b[co] + chain(w[co][ci][k] * xh[ci][t+k-(K-1)]) (+ add[co][t]);
+// register-blocked, f32 copies of the (f16-valued) weights, K in {1, 3, 7}.  T: frames of the longest utterance at this stage
 void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
-                        const float * add, float * y);
+                        const float * add, float * y, const CodecBatch & cb, int tmul);
 bool conv1d_f32w_supported(int K);
+// causal transposed conv, stride s, kernel 2 s, output trimmed to T*s: y[co][to] = b[co] + chain over (ci, t) of w[ci][co][to - t*s] * xh[ci][t]
 void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
-                          int T, float * y);
+                          int T, float * y, const CodecBatch & cb, int tmul);
 // xt[t][c] = f16(x[c][t])
-void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt);
-// one LSTM time step for all D units (PyTorch gate order i,f,g,o); hprev_h: f16 h_{t-1} [D] or nullptr at t = 0
-struct LstmStepArgs {
-    const half_t * w_hh = nullptr; const float * b_ih = nullptr; const float * b_hh = nullptr;
-    const float * gi = nullptr;          // W_ih x_t for every t: [T][4D]
-    float * c = nullptr;                 // cell state [D] (read from step 1 on, written every step)
-    half_t * hseq_h = nullptr;           // f16(h_t), time major [T][D]: row t-1 is this step's recurrent input
-    float * hseq = nullptr; int T = 0, D = 0;     // hseq[d*T + t] = h_t
-    int t = 0;                           // this launch's step, or its offset inside a replayed block of steps ...
-    const int * t_base = nullptr;        // ... added to t_base[0] (device) when non-null; then t_base[1] holds T
-};
-void launch_lstm_step(hipStream_t s, const LstmStepArgs & a);
-// Both LSTM layers as a wave front: launch i runs layer 1 at step i and layer 2 at step i - 1 (whose input projection W_ih2 h1[i-1]
-// is formed in the same kernel, C1 order - the bits of the row-batched product), so a sequence of T frames takes T + 1 dependent
-// launches instead of 2 T.  Layer 1: gi1 = W_ih1 x for all t (launch_linear), w_hh1, biases, cell c1, f16 outputs h1 [T][D].
-// Layer 2: w_ih2, w_hh2, biases, cell c2, f16 outputs h2 [T][D] and the f32 sequence out2 [D][T].
+void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt, const CodecBatch & cb);
+// Both LSTM layers as a wave front (PyTorch gate order i,f,g,o): launch i runs layer 1 at step i and layer 2 at step i - 1 (whose input
+// projection W_ih2 h1[i-1] is formed in the same kernel, C1 order - the bits of the row-batched product), so a sequence of T frames takes
+// T + 1 dependent launches instead of 2 T - for every utterance of the batch at once.
+// Layer 1: gi1 = W_ih1 x for all t (launch_linear), w_hh1, biases, cells c1 [B][D], f16 outputs h1 [sum T][D].
+// Layer 2: w_ih2, w_hh2, biases, cells c2, f16 outputs h2 and the f32 sequences out2 ([D][T] per utterance).
 struct LstmPairArgs {
     const float * gi1 = nullptr; const half_t * w_hh1 = nullptr; const float * b_ih1 = nullptr, * b_hh1 = nullptr; float * c1 = nullptr; half_t * h1 = nullptr;
     const half_t * w_ih2 = nullptr, * w_hh2 = nullptr; const float * b_ih2 = nullptr, * b_hh2 = nullptr; float * c2 = nullptr; half_t * h2 = nullptr;
     float * out2 = nullptr; int T = 0, D = 0;
     int t = 0; const int * t_base = nullptr;          // launch index, or offset inside a replayed block added to t_base[0] (then t_base[1] holds T)
+    CodecBatch cb;
 };
 void launch_lstm_pair_step(hipStream_t s, const LstmPairArgs & a);
 void launch_add_int(hipStream_t s, int * p, int v);       // *p += v

@@ -44,11 +44,12 @@ def prompt_for(step: int, rank: int, world: int, prompts):
 
 
 def shard_prompts(prompts, rank: int, world: int):
-    """Config 5: the prompts sorted by length (ties by index) are cut into `world` contiguous blocks, block r goes to rank r.
-    Utterances of similar length share a lock-step batch.  Returns the indices (into `prompts`) of this rank's shard."""
+    """Config 5: the prompts sorted by length (ties by index) are dealt to the ranks snake-wise - rank r takes the sorted positions
+    r, 2 world - 1 - r, 2 world + r, 4 world - 1 - r, ... - so that no rank holds all the longest utterances (the job's time is the
+    MAX over ranks), and every shard stays sorted by length (neighbours share a lock-step batch).  Returns the indices (into
+    `prompts`) of this rank's shard."""
     order = sorted(range(len(prompts)), key=lambda i: (len(prompts[i]), i))
-    per = (len(order) + world - 1) // world
-    return order[rank * per:(rank + 1) * per]
+    return [order[p] for p in range(len(order)) if p % (2 * world) in (rank, 2 * world - 1 - rank)]
 
 
 def reduce_timing(dt: float, audio_s: float, world: int, device=None):

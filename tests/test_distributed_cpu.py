@@ -49,10 +49,17 @@ def test_two_rank_sharding_and_reduction(tmp_path):
     assert abs(out["audio"] - 2 * 5.12 * 4) < 1e-9            # SUM over ranks
     flat = out["shards"][0] + out["shards"][1]
     assert sorted(flat) == list(range(64)) and len(out["shards"][0]) == len(out["shards"][1]) == 32      # disjoint, complete, balanced
+    sys.path.insert(0, ROOT)
     import bench
     prompts = bench.synth_prompts(64)
-    lens = [len(prompts[i]) for i in flat]
-    assert lens == sorted(lens)                                # sorted by length: rank 0 holds the short half
+    lens = [[len(prompts[i]) for i in sh] for sh in out["shards"]]
+    assert all(l == sorted(l) for l in lens)                   # every shard sorted by length (neighbours share a lock-step batch)
+    assert abs(sum(lens[0]) - sum(lens[1])) <= max(map(max, lens))      # dealt snake-wise: no rank holds all the long utterances
+    for world in (4, 8):                                       # the same properties for the node sizes the driver runs
+        shards = [bench.shard_prompts(prompts, r, world) for r in range(world)]
+        assert sorted(sum(shards, [])) == list(range(64)) and {len(s) for s in shards} == {64 // world}
+        tot = [sum(len(prompts[i]) for i in s) for s in shards]
+        assert max(tot) - min(tot) <= max(len(p) for p in prompts)
     assert out["counts"] == [100 + 7 * i for i in range(64)]   # all_gather of the sample counts
     assert out["n_gathered"] == 64 and out["pcm_ok"]           # gather of the PCM on rank 0, bit for bit
 

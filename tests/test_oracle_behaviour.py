@@ -138,3 +138,33 @@ def test_committed_bench_workload_fixture_is_what_the_oracle_generates(fmt):
     assert set(got) == set(want.files)
     for k in want.files:
         assert np.array_equal(np.asarray(got[k]), want[k]), k
+
+
+def test_committed_batch_fixture_is_what_the_oracle_generates():
+    """tests/golden/oracle_small_batch64.npz (config 5: every one of the 64 bench prompts, bark-small shapes, 256 steps) stands in for
+    64 live oracle runs in test_config5_rank_shard_matches_the_oracle; here the oracle re-derives one of them (a minute of CPU; the
+    index moves with the fixture's own content so that no entry is privileged)."""
+    import hashlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench
+    import make_oracle_golden
+    from oracle.pyoracle import Oracle
+    from tools.make_synth_model import ensure_model
+    want = np.load(os.path.join(root, "tests", "golden", "oracle_small_batch64.npz"))
+    assert int(want["n_prompts"]) == 64
+    path = ensure_model("small", 0)
+    assert np.array_equal(make_oracle_golden.file_sha256(path), want["model_sha256"])
+    i = int(want["pcm_sha256_0"][0]) % 64
+    orc = Oracle(path, n_threads=8)
+    try:
+        ref = orc.generate(bench.synth_prompts(64)[i], orc.params(n_steps_text_encoder=256))
+    finally:
+        orc.close()
+    pcm = np.ascontiguousarray(ref["pcm"], np.float32)
+    assert np.array_equal(ref["semantic"], want[f"semantic{i}"]) and np.array_equal(ref["coarse"], want[f"coarse{i}"]) and np.array_equal(ref["fine"], want[f"fine{i}"])
+    assert pcm.size == int(want[f"pcm_len{i}"])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), want[f"pcm_sha256_{i}"])
