@@ -155,6 +155,7 @@ class BarkContext:
         self._h = handle
         self._lib = lib
         self._cb = None
+        self._params = None
 
     # ---- bark.h ---------------------------------------------------------------------------------
     @classmethod
@@ -166,6 +167,7 @@ class BarkContext:
             raise RuntimeError(f"bark_load_model failed for {model_path}")
         ctx = cls(h, lib)
         ctx._cb = params.progress_callback      # keep the callback object alive
+        ctx._params = params
         return ctx
 
     def generate_audio(self, text: str, n_threads: int = 4) -> bool:
@@ -213,6 +215,7 @@ class BarkContext:
 
     def set_params(self, params: BarkContextParams):
         self._cb = params.progress_callback
+        self._params = params
         self._lib.bark_hip_set_params(self._h, params)
 
     def tokenize(self, text: str) -> np.ndarray:
@@ -256,7 +259,8 @@ class BarkContext:
 
     def coarse(self, semantic) -> np.ndarray:
         sem = _i32(semantic)
-        cap = int(len(sem) * 75.0 / 49.9) + 8          # T = floor(n_sem * coarse_rate / semantic_rate) with the default rates
+        p = self._params                                # T = floor(n_sem * coarse_rate / semantic_rate) with the context's own rates
+        cap = int(len(sem) * max(p.coarse_rate_hz, 1e-3) / max(p.semantic_rate_hz, 1e-3)) + 8
         out = np.zeros((cap, 2), np.int32)
         T = self._lib.bark_hip_coarse(self._h, sem.ctypes.data, len(sem), out.ctypes.data, cap)
         if T < 0:

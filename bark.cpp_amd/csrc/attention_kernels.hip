@@ -1,5 +1,10 @@
 // attention_kernels.hip - attention over the f32 KV cache: single-query decode kernels (orders C2 / C4 / C5 on VALU) and the
-// multi-query prefill / fine kernels (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
+// multi-query prefill / fine kernel (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
+//   attn_ps_kernel    decode, one sequence, block_size 1024: finishes the partial scores the QKV kernel formed (the default)
+//   attn_fused_kernel decode, any block size, one workgroup per (head, slot): lock-step batches, f32 model files, and the
+//                     cross-check route of attn_ps_kernel (BARK_HIP_CROSSCHECK bit 2)
+//   attn_rows_kernel  prefill / fine (N queries)
+// (the two-launch, value-sliced, wide and materialised variants of rounds 1-2 lost their A/Bs and are gone: git history)
 #include "device_utils.h"
 
 #include <algorithm>
@@ -17,81 +22,6 @@ template <int G> DEVINL void load_k_group(float4 (&kv)[16], const float4 * kp, i
 DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) {
     const float c0 = score_block_f4(kv, qh), c1 = score_block_f4(kv + 4, qh + 16), c2 = score_block_f4(kv + 8, qh + 32), c3 = score_block_f4(kv + 12, qh + 48);
     return ((c0 + c1) + (c2 + c3)) * 0.125f;                  // 1/sqrt(64), bark.cpp:1318
-}
-// ------------------------------------------------------------------------------------------------
-// decode attention, two launches so that the key stream is spread over the whole chip:
-//   attn_scores_kernel : one wave per 64 keys and head (grid P/64 x H); lane = key, C2 = one fmaf chain
-//                        over d; the K cache is d-quad major, so a wave's 16-byte loads are contiguous.
-//   attn_mix_kernel    : one workgroup (16 waves) per head: softmax statistics over the score row
-//                        (max, e = (float) exp((double)(s - max)), double sum), then wave c owns chain c
-//                        of C5 (keys c, c+16, ...), lane = d; the 16 chains meet in LDS (tree order).
-// Every load is issued before the arithmetic that needs the previous one.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_scores_kernel(const AttnDecodeArgs a) {
-    const int h = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
-    const int P = a.P;
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + j;     // j < P: always inside the cache
-    float4 kv[16];
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
-    const int ctx = a.st->n_past + 1;
-    const float * __restrict__ qh = a.q + h * 64;             // wave-uniform: scalar loads
-    const float sc = score_chain(kv, qh);
-    if (j < ctx) a.scores[(size_t) h * P + j] = sc;
-    // row maximum for the softmax, kept exactly with an integer atomic (a.hmax[h] is reset by attn_mix_kernel)
-    const float wmax = wave_max(j < ctx ? sc : -INFINITY);
-    if (threadIdx.x == 0 && blockIdx.x * 64 < ctx) atomicMax(a.hmax + h, f32_ordered(wmax));
-}
-
-__global__ __launch_bounds__(1024) void attn_mix_kernel(const AttnDecodeArgs a) {
-    __shared__ float es[1024];
-    __shared__ double red_d[16];
-    __shared__ float part[16][64];
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P;
-    const int ctx = a.st->n_past + 1;
-    const float sraw = a.scores[(size_t) h * P + tid];                // tid < P; garbage beyond ctx is masked below
-    const float mx = f32_unordered(a.hmax[h]);
-    const float * vp = a.vc + (size_t) h * P * 64 + lane;
-    float vv[64];
-    #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (g == 0 || ctx > 256 * g) {
-            #pragma unroll
-            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (wave + 16 * (16 * g + i)) * 64];   // row < P
-        }
-    }
-    float e = 0.0f;
-    if (tid < ctx) e = (float) exp((double) (sraw - mx));
-    es[tid] = e;
-    const double wsum = wave_sum((double) e);
-    if (lane == 0) red_d[wave] = wsum;
-    __syncthreads();
-    if (tid == 0) a.hmax[h] = 0u;                                      // below every encoded float: ready for the next layer
-    double sum = 0.0;
-    #pragma unroll
-    for (int i = 0; i < 16; i++) sum += red_d[i];
-    const float inv = (float) (1.0 / sum);
-    float acc = 0.0f;
-    #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (g == 0 || ctx > 256 * g) {
-            #pragma unroll
-            for (int i = 0; i < 16; i++) { const int j = wave + 16 * (16 * g + i); if (j < ctx) acc = fmaf(vv[16 * g + i], es[j] * inv, acc); }
-        }
-    }
-    part[wave][lane] = acc;
-    __syncthreads();
-    if (tid < 64) {
-        float p[16];
-        #pragma unroll
-        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
-        #pragma unroll
-        for (int st = 1; st < 16; st <<= 1)
-            #pragma unroll
-            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        if (a.att32) a.att32[h * 64 + tid] = p[0]; else a.att[h * 64 + tid] = to_half(p[0]);
-    }
 }
 // ------------------------------------------------------------------------------------------------
 // Fused decode attention: ONE launch, one 256-thread workgroup (4 waves, one per SIMD, up to 512
@@ -184,236 +114,6 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
         if (a.att32) a.att32[(size_t) slot * E + h * 64 + tid] = p[0]; else a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// decode attention spread over ATTN_SPLIT workgroups per head, without any cross-workgroup traffic.
-// One CU streams a head's K and V rows at only ~40-65 GB/s (attn_fused_kernel: two dependent load
-// rounds, 512 B per key), and 12 heads leave 244 CUs idle for the longest kernel of the step.
-// Workgroup (h, s) scores ALL keys of head h (every workgroup repeats the C2 chains and the softmax
-// statistics in the same order, so all of them hold identical bits) but mixes only the value dims
-// [16 s, 16 s + 16) - with all 16 C5 chains, so the tree is local.  Per workgroup that is 256 + 64
-// instead of 512 bytes per key, all of them requested up front (one memory round trip; the
-// workgroup's four waves sit alone on their SIMDs, so ~350 VGPRs per lane are available).
-// A variant that also split the keys and exchanged scores through agent-scope atomics measured
-// 10.7 us vs 8.2 us fused at ctx 641: each cross-XCD hop costs ~2 us.
-// ------------------------------------------------------------------------------------------------
-// One C5 chain over the keys chain + 16 i held in vv[]: the probabilities are fetched from LDS in one batch and masked terms are
-// dropped with a select on the RESULT (identical to skipping them, and garbage in unused cache rows never reaches acc).  The
-// in-kernel time line showed the guarded form `if (j < ctx) acc = fmaf(v, es[j] * inv, acc)` costing one LDS round trip per key.
-template <int NG> DEVINL float mix_chain(const float (&vv)[16 * NG], const float * es, float inv, int chain, int ctx) {
-    float acc = 0.0f;
-    #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        if (g == 0 || ctx > 256 * g) {
-            float pj[16];
-            #pragma unroll
-            for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
-            #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float t = fmaf(vv[16 * g + i], pj[i], acc);
-                acc = (chain + 16 * (16 * g + i) < ctx) ? t : acc;
-            }
-        }
-    }
-    return acc;
-}
-constexpr int ATTN_SPLIT = 4;
-__global__ __launch_bounds__(256) void attn_dslice_kernel(const AttnDecodeArgs a) {
-    TRACE_T0();
-    TRACE_T1(a.H);
-    __shared__ float es[1024];
-    __shared__ float red_f[4];
-    __shared__ double red_d[4];
-    __shared__ float part[16][16];
-    // workgroup id -> (head, slice) such that the ATTN_SPLIT slices of a head have ids congruent mod 8: under the round-robin
-    // workgroup -> XCD dispatch they share one XCD, so the head's K rows are fetched from HBM once and the other slices hit that
-    // L2 (FETCH_SIZE showed 2.4x the algorithmic bytes when the slices were spread over XCDs).  Speed only; any placement is correct.
-    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // id = x8 + 8 * g8, g8 = s + ATTN_SPLIT * (h / 8), x8 = h % 8
-    const int h = x8 + 8 * (g8 / ATTN_SPLIT), s = g8 % ATTN_SPLIT;
-    if (h >= a.H) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P;
-    const float * __restrict__ qh = a.q + h * 64;
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
-    const int chain = tid >> 4, d = tid & 15;
-    const float * vp = a.vc + ((size_t) h * P + chain) * 64 + 16 * s + d;        // key `chain`, value dim 16 s + d
-    const int ctx = a.st->n_past + 1;
-    float4 k0[16], k1[16], k2[16], k3[16];
-    load_k_group<0>(k0, kp, P);
-    if (ctx > 256) load_k_group<1>(k1, kp, P);
-    if (ctx > 512) load_k_group<2>(k2, kp, P);
-    if (ctx > 768) load_k_group<3>(k3, kp, P);
-    float vv[64];
-    #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (g == 0 || ctx > 256 * g) {
-            #pragma unroll
-            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];     // key chain + 16 (16 g + i)
-        }
-    }
-    float sv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    { const float v = score_chain(k0, qh); if (tid < ctx) sv[0] = v; }
-    if (ctx > 256) { const float v = score_chain(k1, qh); if (tid + 256 < ctx) sv[1] = v; }
-    if (ctx > 512) { const float v = score_chain(k2, qh); if (tid + 512 < ctx) sv[2] = v; }
-    if (ctx > 768) { const float v = score_chain(k3, qh); if (tid + 768 < ctx) sv[3] = v; }
-    float mx = wave_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
-    if (lane == 0) red_f[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
-    double lsum = 0.0;
-    #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int j = tid + 256 * i;
-        float e = 0.0f;
-        if (j < ctx) { e = (float) exp((double) (sv[i] - mx)); lsum += (double) e; }
-        es[j] = e;
-    }
-    lsum = wave_sum(lsum);
-    if (lane == 0) red_d[wave] = lsum;
-    __syncthreads();
-    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
-    const float inv = (float) (1.0 / sum);
-    const float acc = mix_chain<4>(vv, es, inv, chain, ctx);
-    TRACE_T2(acc);
-    part[chain][d] = acc;
-    __syncthreads();
-    if (tid < 16) {
-        float p[16];
-        #pragma unroll
-        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
-        #pragma unroll
-        for (int st = 1; st < 16; st <<= 1)
-            #pragma unroll
-            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        const int o = h * 64 + 16 * s + tid;
-        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
-    }
-    TRACE_END(a.tr);
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Wide decode attention: the value-sliced layout of attn_dslice_kernel (workgroup = head x 16 value dims, all 16 C5 chains local,
-// no cross-workgroup traffic) with 1024 threads, ONE key per thread.  The in-kernel time line of attn_dslice_kernel (tools/
-// trace_decode.py) showed 6.7 of its 8 us between "arguments ready" and "mix done": a wave alone on its SIMD runs dependent VALU
-// code at ~5 cycles per instruction, and every thread walked 3-4 score chains (64 fmaf each) and 3-4 double-precision exps
-// (~70 fp64 instructions each) one after the other.  Here a thread owns one key: one 64-fmaf chain, one exp; the 16 waves also
-// keep 16 x 16 K loads in flight instead of 4 x 64.  Threads 0..255 then mix as before (chain = tid / 16, dim = tid % 16); their V
-// loads are issued once the K registers are dead and land behind the softmax.
-//   FROM_SCORES = true : second half of the two-launch variant - scores come from attn_keyscores_kernel, which spreads the K
-//                        stream over ctx/64 x H waves (a head's K rows, 164-262 KB, are the per-CU bandwidth bound of the fused form)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attn_keyscores_kernel(const AttnDecodeArgs a) {
-    const int h = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
-    constexpr int P = 1024;
-    const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + j;
-    // the first 256 keys are scored without looking at the context length (one scalar round trip less before the loads go out)
-    if (blockIdx.x >= 4 && blockIdx.x * 64 > a.st->n_past) return;
-    float4 kv[16];
-    #pragma unroll
-    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
-    a.scores[(size_t) h * P + j] = score_chain(kv, a.q + h * 64);
-}
-
-template <bool FROM_SCORES>
-__global__ __launch_bounds__(1024) void attn_wide_kernel(const AttnDecodeArgs a) {
-    TRACE_T0();
-    TRACE_T1(a.H);
-    __shared__ float es[1024];
-    __shared__ float red_f[16];
-    __shared__ double red_d[16];
-    __shared__ float part[16][16];
-    const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // same XCD-affine id -> (head, slice) map as attn_dslice_kernel
-    const int h = x8 + 8 * (g8 / ATTN_SPLIT), s = g8 % ATTN_SPLIT;
-    if (h >= a.H) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int P = 1024;
-    const int chain = (tid >> 4) & 15, d = tid & 15;
-    const float * vp = a.vc + ((size_t) h * P + chain) * 64 + 16 * s + d;        // key `chain`, value dim 16 s + d
-    float sc = -INFINITY;
-    float vv[64];
-    int ctx;
-    if constexpr (FROM_SCORES) {
-        const float v = a.scores[(size_t) h * P + tid];
-        ctx = a.st->n_past + 1;
-        if (wave < 4) {
-            #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                if (g == 0 || ctx > 256 * g) {
-                    #pragma unroll
-                    for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];
-                }
-            }
-        }
-        if (tid < ctx) sc = v;
-    } else {
-        const float * __restrict__ qh = a.q + h * 64;
-        const float4 * kp = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * P + tid;
-        float4 kv[16];
-        if (wave < 4) {                                            // keys 0..255: always inside the cache, no need to know ctx yet
-            #pragma unroll
-            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
-        }
-        ctx = a.st->n_past + 1;
-        if (wave >= 4 && wave * 64 < ctx) {
-            #pragma unroll
-            for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
-        }
-        if (wave * 64 < ctx) {
-            const float v = score_chain(kv, qh);
-            if (tid < ctx) sc = v;
-        }
-        if (wave < 4) {                                            // K registers are dead: request the value slice
-            #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                if (g == 0 || ctx > 256 * g) {
-                    #pragma unroll
-                    for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 1024];
-                }
-            }
-        }
-    }
-    TRACE_TA(sc);
-    float mx = wave_max(sc);
-    if (lane == 0) red_f[wave] = mx;
-    __syncthreads();
-    mx = red_f[0];
-    #pragma unroll
-    for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
-    float e = 0.0f;
-    if (tid < ctx) e = (float) exp((double) (sc - mx));
-    es[tid] = e;
-    const double wsum = wave_sum((double) e);
-    if (lane == 0) red_d[wave] = wsum;
-    __syncthreads();
-    TRACE_TB(e);
-    if (wave >= 4) return;
-    // same association as the 4-wave kernels ((w0 + w1) + (w2 + w3) per 256 keys) is not required: a double sum of floats changes
-    // the rounded float only at ~2^-29; fixed order here: ascending waves
-    double sum = 0.0;
-    #pragma unroll
-    for (int i = 0; i < 16; i++) sum += red_d[i];
-    const float inv = (float) (1.0 / sum);
-    const float acc = mix_chain<4>(vv, es, inv, chain, ctx);
-    TRACE_T2(acc);
-    part[chain][d] = acc;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): the four mix waves meet through LDS without the exited waves
-    asm volatile("s_barrier" ::: "memory");
-    if (tid < 16) {
-        float p[16];
-        #pragma unroll
-        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
-        #pragma unroll
-        for (int st = 1; st < 16; st <<= 1)
-            #pragma unroll
-            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        const int o = h * 64 + 16 * s + tid;
-        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
-    }
-    TRACE_END_AB(a.tr);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Decode attention on partial scores.  The QKV kernel of the step (gemv_ln_wg_kernel<PS>) has already formed, for every cached key,
@@ -536,177 +236,15 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
 #endif
 }
 
-void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts) {
-    if (parts == 4) { hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a); return; }
-    if (parts == 5) {
-        if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: value-sliced decode attention needs one sequence and block_size 1024"); }
-        hipLaunchKernelGGL(attn_dslice_kernel, dim3(8 * ATTN_SPLIT * ((a.H + 7) / 8)), dim3(256), 0, s, a);
-        return;
-    }
-    if (parts == 8 || parts == 9) {
-        if (a.nbatch != 1 || a.P != 1024 || !a.ps) { kernel_fail("bark-hip: partial-score decode attention needs one sequence, block_size 1024 and the QKV kernel's partials"); }
+void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
+    if (a.ps) {
+        if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: partial-score decode attention needs one sequence and block_size 1024"); }
         if (!a.knew) kernel_fail("bark-hip: partial-score decode attention needs the fixed-address copy of the appended K row");
         if (!a.vt) kernel_fail("bark-hip: partial-score decode attention needs the K-layout copy of V");
         hipLaunchKernelGGL(attn_ps_kernel, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
         return;
     }
-    if (parts == 6 || parts == 7) {
-        if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: wide decode attention needs one sequence and block_size 1024"); }
-        const dim3 grid(8 * ATTN_SPLIT * ((a.H + 7) / 8));
-        if (parts == 6) { hipLaunchKernelGGL(attn_wide_kernel<false>, grid, dim3(1024), 0, s, a); return; }
-        hipLaunchKernelGGL(attn_keyscores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(attn_wide_kernel<true>, grid, dim3(1024), 0, s, a);
-        return;
-    }
-    if (parts & 1) hipLaunchKernelGGL(attn_scores_kernel, dim3(a.P / 64, a.H), dim3(64), 0, s, a);
-    if (parts & 2) hipLaunchKernelGGL(attn_mix_kernel, dim3(a.H), dim3(1024), 0, s, a);
-}
-void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
-    static const bool split = getenv("BARK_HIP_ATTN_SPLIT") != nullptr;      // two-launch variant kept for A/B timing
-    static const bool one_wg = getenv("BARK_HIP_ATTN_ONE_WG") != nullptr;    // one workgroup per head (A/B timing)
-    if (split) { launch_attn_decode_part(s, a, 3); return; }
-    // several sequences in lock step already give H * nbatch workgroups; a single one is spread over H * ATTN_SPLIT
-    const bool can_split = a.nbatch == 1 && a.P == 1024 && !one_wg;
-    // BARK_HIP_ATTN_MODE (A/B timing): 5 value-sliced 256-thread kernel, 6 wide fused kernel, 7 key scores + wide mix (two launches)
-    // 9: attention on the QKV kernel's partial scores, 8 value slices per head (needs a.ps)
-    static const int mode = getenv("BARK_HIP_ATTN_MODE") ? atoi(getenv("BARK_HIP_ATTN_MODE")) : 6;
-    static const int ps_mode = getenv("BARK_HIP_ATTN_PS") ? atoi(getenv("BARK_HIP_ATTN_PS")) : 9;
-    if (can_split && a.ps && ps_mode) { launch_attn_decode_part(s, a, ps_mode); return; }
-    launch_attn_decode_part(s, a, can_split ? mode : 4);
-}
-
-// ------------------------------------------------------------------------------------------------
-// prefill / fine attention (materialised scores): S = scale * Q K^T on the f32 matrix cores (C2 = one
-// MFMA accumulator chain over d), row softmax, O = P V on the f32 matrix cores (C5: 16 chains in
-// 8 waves x 2 accumulator sets, LDS tree).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_qk_kernel(const AttnPrefillArgs a) {
-    // workgroup tile 128 queries x 128 keys; wave (wi, wj) owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles, so every
-    // 16-byte operand load feeds four MFMAs
-    const int h = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const int ctx = a.n_past + a.N;
-    if (j0 >= ctx) return;
-    if (a.causal && j0 > a.n_past + i0 + 127) return;       // tile entirely masked
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wi = w >> 1, wj = w & 1;
-    const float4 * qp[2]; const float4 * kp[2];
-    #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int irow = min(i0 + wi * 64 + t * 32 + l31, a.N - 1);
-        const int jrow = min(j0 + wj * 64 + t * 32 + l31, ctx - 1);
-        qp[t] = reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + h * 64);
-        kp[t] = reinterpret_cast<const float4 *>(a.kc) + (size_t) h * 16 * a.P + jrow;
-    }
-    // C2: per 2 x 2 tile one running accumulator per block of 16 d; the block sums are combined as (c0 + c1) + (c2 + c3)
-    floatx16 acc[2][2], c01[2][2], c2[2][2];
-    #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        #pragma unroll
-        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-        #pragma unroll
-        for (int dq = 4 * b; dq < 4 * b + 4; dq++) {
-            float4 qv[2], kv[2];
-            #pragma unroll
-            for (int t = 0; t < 2; t++) { qv[t] = qp[t][dq]; kv[t] = kp[t][(size_t) dq * a.P]; }
-            // MFMA k pair (d = 4dq, 4dq+1) then (4dq+2, 4dq+3): lanes 0-31 feed the even d, 32-63 the odd d
-            #pragma unroll
-            for (int i = 0; i < 2; i++)
-                #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].y : qv[i].x, half ? kv[j].y : kv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? qv[i].w : qv[i].z, half ? kv[j].w : kv[j].z, acc[i][j], 0, 0, 0);
-                }
-        }
-        #pragma unroll
-        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) {
-            if (b == 0) c01[i][j][r] = acc[i][j][r];
-            else if (b == 1) c01[i][j][r] = c01[i][j][r] + acc[i][j][r];
-            else if (b == 2) c2[i][j][r] = acc[i][j][r];
-            else acc[i][j][r] = c01[i][j][r] + (c2[i][j][r] + acc[i][j][r]);
-        }
-    }
-    // A operand = Q (accumulator rows = queries i), B operand = K (accumulator cols = keys j: coalesced stores)
-    #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-        #pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-            #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i = i0 + wi * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int j = j0 + wj * 64 + tj * 32 + l31;
-                if (i < a.N && j < ctx) a.scores[((size_t) h * a.N + i) * a.P + j] = acc[ti][tj][r] * 0.125f;    // 1/sqrt(64), bark.cpp:1318
-            }
-}
-
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const AttnPrefillArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);     // row = h * N + i
-    if (row >= a.H * a.N) return;
-    const int i = row % a.N;
-    const int ctx = a.n_past + a.N;
-    const int valid = a.causal ? min(ctx, a.n_past + i + 1) : ctx;
-    float * s = a.scores + (size_t) row * a.P;
-    float mx = -INFINITY;
-    for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
-    mx = wave_max(mx);
-    double sum = 0.0;
-    for (int j = lane; j < valid; j += 64) { const float e = (float) exp((double) (s[j] - mx)); s[j] = e; sum += (double) e; }
-    sum = wave_sum(sum);
-    const float inv = (float) (1.0 / sum);
-    for (int j = lane; j < valid; j += 64) s[j] = s[j] * inv;
-    const int ctx32 = min((ctx + 31) & ~31, a.P);
-    for (int j = valid + lane; j < ctx32; j += 64) s[j] = 0.0f;          // masked keys: p == 0
-}
-
-__global__ __launch_bounds__(512) void attn_pv_kernel(const AttnPrefillArgs a) {
-    __shared__ float part[8][32][64];
-    const int h = blockIdx.y, i0 = blockIdx.x * 32;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int ctx = a.n_past + a.N;
-    const int irow = min(i0 + l31, a.N - 1);
-    // causal: rows of this tile see keys <= n_past + i0 + 31
-    const int jend = a.causal ? min(ctx, a.n_past + i0 + 32) : ctx;
-    const float * prow = a.scores + ((size_t) h * a.N + irow) * a.P;
-    const float * vbase = a.vc + (size_t) h * a.P * 64;
-    floatx16 acc[2][2];
-    #pragma unroll
-    for (int s = 0; s < 2; s++) for (int t = 0; t < 2; t++) for (int r = 0; r < 16; r++) acc[s][t][r] = 0.0f;
-    const int jlim = (jend + 1) & ~1;                            // P rows are zero-filled up to a multiple of 32 keys
-    #pragma unroll 2
-    for (int jb = 0; jb < jend; jb += 32) {
-        const int j = jb + 2 * w + 16 * half;                   // chains 2w, 2w+1: keys j, j+1 (this half-wave's k slot)
-        const bool ok = j < jlim;
-        const float2 p2 = ok ? *reinterpret_cast<const float2 *>(prow + j) : float2{0.0f, 0.0f};
-        #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const bool oks = j + s < jend;
-            const float pv = s ? p2.y : p2.x;
-            #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const float vv = oks ? vbase[(size_t) (j + s) * 64 + t * 32 + l31] : 0.0f;
-                acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(oks ? pv : 0.0f, vv, acc[s][t], 0, 0, 0);
-            }
-        }
-    }
-    #pragma unroll
-    for (int t = 0; t < 2; t++)
-        #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            part[w][row][t * 32 + l31] = acc[0][t][r] + acc[1][t][r];
-        }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * 64; idx += 512) {
-        const int row = idx >> 6, d = idx & 63;
-        float p[8];
-        #pragma unroll
-        for (int q = 0; q < 8; q++) p[q] = part[q][row][d];
-        const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        const int i = i0 + row;
-        if (i < a.N) { if (a.att32) a.att32[(size_t) i * a.ld_att + h * 64 + d] = v; else a.att[(size_t) i * a.ld_att + h * 64 + d] = to_half(v); }
-    }
+    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -763,7 +301,6 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
         // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs
         float4 ka[16], kb[16];
         int jt = w * 32;
-        if (a.dbg & 1) jt = jend;
         if (jt < jend) load_k(ka, jt);
         for (; jt < jend; jt += 512) {
             const bool more = jt + 256 < jend;
@@ -794,7 +331,7 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
         for (int j = lane; j < valid; j += 256) {
             float e[4];
             #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? ((a.dbg & 2) ? s[j + 64 * u] - mx : (float) exp((double) (s[j + 64 * u] - mx))) : 0.0f;
+            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? (float) exp((double) (s[j + 64 * u] - mx)) : 0.0f;
             #pragma unroll
             for (int u = 0; u < 4; u++) if (j + 64 * u < valid) { s[j + 64 * u] = e[u]; sum4[u] += (double) e[u]; }
         }
@@ -834,7 +371,7 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
                 acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, oks ? V[u][s][t] : 0.0f, acc[s][t], 0, 0, 0); \
         }                                                                                                \
     }
-    const int jstop = (a.dbg & 4) ? 0 : jend;
+    const int jstop = jend;
     if (jstop > 0) { ATT_LOAD_BATCH(va, ea, 0) }
     for (int jb = 0; jb < jstop; jb += 512) {
         const bool more = jb + 256 < jstop;
@@ -873,17 +410,8 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
 }
 
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
-    static const bool materialised = getenv("BARK_HIP_ATTN_MATERIALISED") != nullptr;   // three-kernel variant kept for A/B checks
-    if (!materialised) {
-        hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
-        return;
-    }
-    const int ctx = a.n_past + a.N;
-    hipLaunchKernelGGL(attn_qk_kernel, dim3((ctx + 127) / 128, (a.N + 127) / 128, a.H), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.H * a.N + 3) / 4), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_pv_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
 }
-
 
 void init_attention_attributes() {
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(attn_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -82,7 +82,7 @@ struct bark_context {
     size_t weight_bytes = 0;
     std::vector<void *> allocs;                         // everything else (freed in destroy)
     // GPT scratch
-    float * x = nullptr, * q = nullptr, * scores = nullptr, * logits = nullptr;
+    float * x = nullptr, * q = nullptr, * logits = nullptr;
     float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)
     float * ps = nullptr;                               // [H][4][P] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
@@ -93,7 +93,6 @@ struct bark_context {
     int32_t * d_tokens = nullptr, * d_out_tokens = nullptr;
     float * d_eos_trace = nullptr;
     barkhip::StepState * d_state = nullptr;
-    unsigned * d_hmax = nullptr;
     double * d_u = nullptr;                             // uniform draws for on-device multinomial sampling (8192)
     bool host_sampling = false;                         // BARK_HIP_HOST_SAMPLING=1: sample temp > 0 on the host (A/B path)
     uint16_t * d_gelu_lut = nullptr;

@@ -56,8 +56,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         launch_linear(s, a);
         AttnPrefillArgs at;
         at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
-        at.causal = causal ? 1 : 0; at.scores = c->scores; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
-        { static const int dbg = getenv("BARK_HIP_ATTN_DBG") ? atoi(getenv("BARK_HIP_ATTN_DBG")) : 0; at.dbg = dbg; }
+        at.causal = causal ? 1 : 0; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
         launch_attn_prefill(s, at);
         if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
@@ -90,13 +89,12 @@ void run_layers_decode(bark_context * c, GptModel & m) {
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.vt = layer_vt(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
-        static const bool use_ps = !getenv("BARK_HIP_ATTN_PS") || atoi(getenv("BARK_HIP_ATTN_PS")) != 0;
-        const bool ps = use_ps && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
+        const bool ps = !(crosscheck_mask() & 4) && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
         if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
         BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 4 * (E / 4));        // room for all four copies of the q workgroups
         launch_linear(s, a);
         AttnDecodeArgs at;
-        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att; at.scores = c->scores; at.hmax = c->d_hmax;
+        at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att;
         at.att32 = m.q4 ? c->att32 : nullptr;
         if (ps) { at.ps = c->ps; at.knew = c->knew; at.ng = c->decode_ng; at.vt = layer_vt(m, l); }
         BARK_TRACE_SET(c, at, 8 * 16 * ((H + 7) / 8) * 16);      // up to 16 slices per head, 16 waves per workgroup
@@ -130,7 +128,6 @@ void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, i
 }
 
 void set_state(bark_context * c, const StepState & st) {
-    HIP_OK(hipMemsetAsync(c->d_hmax, 0, 64 * sizeof(unsigned), c->stream));     // decode-attention row maxima (kernels.hip)
     HIP_OK(hipMemcpyAsync(c->d_state, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));       // `st` is a stack object
 }
@@ -138,6 +135,7 @@ StepState get_state(bark_context * c) {
     StepState st;
     HIP_OK(hipMemcpyAsync(&st, c->d_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (st.fault) throw std::runtime_error("decode step launched with a context bound below the cached keys (partial scores incomplete)");
     return st;
 }
 StepState fresh_state() {
@@ -236,17 +234,15 @@ hipGraphExec_t capture_decode(bark_context * c, const StageCfg & s, int n_past_a
 // and value rows at wave launch instead of waiting ~0.5 us for the context length to arrive from the device-resident state.
 void decode_steps_greedy(bark_context * c, const StageCfg & s, int n, int n_past) {
     GptModel & m = c->gpt[s.which];
-    static const bool multi = !getenv("BARK_HIP_GRAPH_STEPS") || atoi(getenv("BARK_HIP_GRAPH_STEPS")) > 1;
-    static const bool bucketed = !getenv("BARK_HIP_NG_BUCKETS") || atoi(getenv("BARK_HIP_NG_BUCKETS")) != 0;
     if (!c->use_graph) {
-        for (int k = 0; k < n; k++) { c->decode_ng = bucketed ? std::min(4, (n_past + k + 256) / 256) : 4; enqueue_decode_step(c, s, true, 1, false); }
-        c->decode_ng = 4;
+        struct Restore { bark_context * c; ~Restore() { c->decode_ng = 4; } } restore{c};      // also when a launch throws
+        for (int k = 0; k < n; k++) { c->decode_ng = std::min(4, (n_past + k + 256) / 256); enqueue_decode_step(c, s, true, 1, false); }
         return;
     }
     int k = 0;
     while (k < n) {
-        const int g = (multi && n - k >= 8) ? 8 : 1;
-        const int ng = bucketed ? std::min(4, (n_past + k + g + 255) / 256) : 4;      // ctx of the last step of this launch = n_past + k + g
+        const int g = n - k >= 8 ? 8 : 1;
+        const int ng = std::min(4, (n_past + k + g + 255) / 256);      // ctx of the last step of this launch = n_past + k + g
         hipGraphExec_t & e = g == 8 ? m.decode_graph8[ng] : m.decode_graph[ng];
         if (!e) e = capture_decode(c, s, 1, g, ng);
         HIP_OK(hipGraphLaunch(e, c->stream));
@@ -461,7 +457,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
     if (p.temp != 0.0f && greedy) upload_uniforms(c, n_steps);
     std::vector<int32_t> out;            // offset ids, as fed back into the model
     std::vector<int32_t> cached;         // token ids whose K/V rows are valid in the cache (prefix reuse)
-    static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
+    const bool reuse_prefix = !(crosscheck_mask() & 8);
     int step_idx = 0;
     for (int w = 0; w < n_windows; w++) {
         // window prompt (bark.cpp:1787-1807)

@@ -72,15 +72,10 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     const bool hoist = B >= 24 && !m.q4;
     // B >= 8, f16 weights: the products of the step run once for all slots on the f32 matrix cores (gemm_slots16_kernel, kernels.hip);
     // rows are normalised to f16 by ln_rows_kernel first.  Same C1 chains as the GEMV path: results do not depend on the route
-    // (tools/check_routes.py, test_lock_step_products_on_the_matrix_cores_give_the_same_bits).  BARK_HIP_BATCH_MFMA=0 forces the VALU
+    // (tools/check_routes.py, test_cross_check_routes_give_the_same_bits).  BARK_HIP_CROSSCHECK bit 1 forces the VALU
     // GEMV per pair of slots everywhere (the cross-check route, and the only one for fewer than 8 slots and for quantised files).
-    static const int mfma_kind = getenv("BARK_HIP_BATCH_MFMA") ? atoi(getenv("BARK_HIP_BATCH_MFMA")) : 4;
-    const bool mfma = mfma_kind != 0 && B >= 8 && !m.q4;
-    // timing experiments only (results are wrong): BARK_HIP_BATCH_DBG bit 0 skips the attention, 1 the products, 2 the LayerNorm rows
-    static const int dbg = getenv("BARK_HIP_BATCH_DBG") ? atoi(getenv("BARK_HIP_BATCH_DBG")) : 0;
+    const bool mfma = !(crosscheck_mask() & 2) && B >= 8 && !m.q4;
     auto product = [&](LinArgs & a, const float * ln_g, const float * ln_b) {
-        if (dbg & 2) return;
-        if (mfma && (dbg & 4)) { a.x_f16 = c->xn; a.x_f32 = nullptr; a.ln_stats = nullptr; launch_linear_slots(st, a, mfma_kind); return; }
         if (!mfma) { a.ln_g = ln_g; a.ln_b = ln_b; launch_linear(st, a); return; }
         // the two out-projections (input rows f16 already, 768 output rows): the VALU GEMV per pair of slots stays ahead for few slots
         // (tools/time_slots.py, us per launch VALU / matrix cores: proj 2.9 / 3.5 at 8 slots, 3.3 / 3.7 at 16, 4.4 / 3.7 at 32; MLP proj 5.1 / 8.0
@@ -88,7 +83,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         if (!ln_g && (a.K == a.M ? B < 24 : B < 16)) { launch_linear(st, a); return; }
         if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
-        launch_linear_slots(st, a, mfma_kind);
+        launch_linear_slots(st, a);
     };
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
@@ -100,9 +95,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
         product(a, L.ln1_g, L.ln1_b);
         AttnDecodeArgs at;
-        at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
+        at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
         at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
-        if (!(dbg & 1)) launch_attn_decode_part(st, at, 4);
+        launch_attn_decode(st, at);
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
@@ -248,9 +243,9 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
         if (op == 4) { launch_ln_rows(c->stream, bb.x, B, E, L.ln1_g, L.ln1_b, c->xn); return; }
         if (op == 5) {
             AttnDecodeArgs at;
-            at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att; at.scores = c->scores; at.hmax = c->d_hmax;
+            at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
             at.nbatch = B; at.kv_slot_stride = slot;
-            launch_attn_decode_part(c->stream, at, 4);
+            launch_attn_decode(c->stream, at);
             return;
         }
         LinArgs a;
@@ -265,7 +260,7 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
                     break;
             default: a.W = L.mproj_w; a.M = E; a.K = 4 * E; a.x_f16 = bb.h; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = bb.x; break;
         }
-        if (kind == 0) launch_linear(c->stream, a); else launch_linear_slots(c->stream, a, kind);
+        if (kind == 0) launch_linear(c->stream, a); else launch_linear_slots(c->stream, a);
     };
     const int per_graph = 48;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -320,7 +315,6 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
     bark_context::Batch & bb = c->batch;
     if (B > bb.cap) throw std::runtime_error("generate_batch: batch larger than the capacity fixed by the first call");
-    HIP_OK(hipMemsetAsync(c->d_hmax, 0, 64 * sizeof(unsigned), c->stream));
 
     // ---- semantic (bark.cpp:1645-1701), lock step -----------------------------------------------------
     int64_t t = now_us();
@@ -379,7 +373,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             if (sampled) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps[(size_t) b]);          // indexed by the slot's step_idx
         }
         std::vector<std::vector<int32_t>> cached((size_t) B);          // per slot: ids whose K/V rows are in its cache
-        static const bool reuse_prefix = !getenv("BARK_HIP_NO_PREFIX_REUSE");
+        const bool reuse_prefix = !(crosscheck_mask() & 8);
         for (int w = 0; w < max_windows; w++) {
             int max_here = 0;
             std::vector<int> here((size_t) B, 0), Ls((size_t) B, 0);

@@ -132,7 +132,6 @@ static void init_runtime(bark_context * ctxp) {
     ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
     ctx->att = dev_alloc<half_t>(ctx.get(), NE);
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
-    ctx->scores = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * P);
     ctx->ps = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * 4);
     ctx->knew = dev_alloc<float>(ctx.get(), (size_t) ctx->max_E);
     HIP_OK(hipMemset(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float)));
@@ -159,8 +158,6 @@ static void init_runtime(bark_context * ctxp) {
     ctx->d_lstm_t = dev_alloc<int>(ctx.get(), 2);
     ctx->d_u = dev_alloc<double>(ctx.get(), 8192);
     { const char * e = getenv("BARK_HIP_HOST_SAMPLING"); ctx->host_sampling = e && atoi(e) != 0; }
-    ctx->d_hmax = dev_alloc<unsigned>(ctx.get(), 64);
-    HIP_OK(hipMemset(ctx->d_hmax, 0, 64 * sizeof(unsigned)));
     {
         std::vector<uint16_t> lut(65536);
         for (uint32_t i = 0; i < 65536; i++) {

@@ -31,8 +31,8 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
     HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
     if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-    // the graph the stage loops replay: eight steps per launch (BARK_HIP_GRAPH_STEPS=1: one); n_past does not advance here
-    static const int per_graph = (getenv("BARK_HIP_GRAPH_STEPS") && atoi(getenv("BARK_HIP_GRAPH_STEPS")) <= 1) ? 1 : 8;
+    // the graph the stage loops replay: eight steps per launch; n_past does not advance here
+    const int per_graph = 8;
     if (m.bench_graph) { (void) hipGraphExecDestroy(m.bench_graph); m.bench_graph = nullptr; }     // the variant depends on the context length
     m.bench_graph = capture_decode(c, s, 0, per_graph, (ctxlen + 255) / 256);
     for (int i = 0; i < 3; i++) HIP_OK(hipGraphLaunch(m.bench_graph, c->stream));
@@ -63,36 +63,20 @@ double engine_time_decode_step(bark_context * c, int which, int ctxlen, int iter
 // stream comes from HBM / Infinity Cache like in a real step, not from a hot L2).  op: 0 LN+QKV, 1 proj,
 // 2 LN+FC+GELU, 3 mlp proj.  Returns the average device time per launch in microseconds.
 double engine_time_gemv(bark_context * c, int which, int op, int iters, double * bytes_per_launch) {
-    if (which < 0 || which > 1 || op < 0 || op > 12) throw std::runtime_error("time_gemv: bad arguments");
-    const bool attn = op >= 8;            // 8: attn_scores_kernel, 9: attn_mix_kernel, 10: both (context = n_past + 1 = 641)
-    const int attn_op = op;
-    const bool hot = op >= 4 && !attn;
+    if (which < 0 || which > 1 || op < 0 || op > 7) throw std::runtime_error("time_gemv: bad arguments");
+    const bool hot = op >= 4;
     op &= 3;
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[which];
     const int E = m.hp.n_embd, P = c->P;
-    StepState st = fresh_state(); st.n_past = attn ? 640 : 100; st.cur_token = 1;
+    StepState st = fresh_state(); st.n_past = 100; st.cur_token = 1;
     set_state(c, st);
-    if (attn) {
-        HIP_OK(hipMemsetAsync(m.kcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-        HIP_OK(hipMemsetAsync(m.vcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-        if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-    if (m.vtcache) HIP_OK(hipMemsetAsync(m.vtcache, 0, m.kv_layer_stride * m.hp.n_layer * 4, c->stream));
-        HIP_OK(hipMemsetAsync(c->q, 0, (size_t) E * 4, c->stream));
-    }
     HIP_OK(hipMemsetAsync(c->x, 0, (size_t) E * 4, c->stream));
     HIP_OK(hipMemsetAsync(c->att, 0, (size_t) E * 2, c->stream));
     HIP_OK(hipMemsetAsync(c->hbuf, 0, (size_t) 4 * E * 2, c->stream));
     if (m.q4) { HIP_OK(hipMemsetAsync(c->att32, 0, (size_t) E * 4, c->stream)); HIP_OK(hipMemsetAsync(c->h32, 0, (size_t) 4 * E * 4, c->stream)); }
     auto launch = [&](int l) {
         const GptModel::Layer & L = m.layers[(size_t) l];
-        if (attn) {
-            AttnDecodeArgs at;
-            at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = m.hp.n_head; at.P = P; at.st = c->d_state; at.att = c->att;
-            at.scores = c->scores; at.hmax = c->d_hmax;
-            launch_attn_decode_part(c->stream, at, attn_op == 8 ? 1 : attn_op == 9 ? 2 : attn_op == 10 ? 3 : attn_op == 11 ? 4 : 5);
-            return;
-        }
         LinArgs a;
         a.N = 1;
         switch (op) {

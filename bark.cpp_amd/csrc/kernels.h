@@ -28,7 +28,8 @@ struct StepState {
     int32_t near_tie;      // samples settled by the exact path (near tie of the two largest logits, or eos_p next to min_eos_p)
     int32_t n_out;         // sampled ids written to out_tokens so far
     float   last_eos_p;
-    float   pad1;
+    int32_t fault;         // set by a kernel whose launch-time assumption about the context does not hold (1: more cached keys than the
+                           // partial-score copies of the QKV kernel cover); the stage loops turn it into an error
 };
 
 // A ggml block-quantised matrix (quant_formats.h), re-laid out at load time into one array per field: scales d [M][K/32]
@@ -100,7 +101,7 @@ struct LinArgs {
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
-void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind);      // kind != 0: 4 x 4 x 1 blocks (gemm_slots4_kernel)
+void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
@@ -128,26 +129,21 @@ struct AttnDecodeArgs {
     const float * q = nullptr; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0; const StepState * st = nullptr; half_t * att = nullptr;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32
-    float * scores = nullptr;             // scratch [H][P]
     const float * vt = nullptr;           // V in the K layout [H][16][P][4] (attn_ps_kernel)
     int ng = 4;                           // the context holds at most 256 ng keys: those keys are requested at wave launch
     const float * knew = nullptr;         // [E] the K row this step appended (copy at a fixed address, see LinArgs::knew)
     const float * ps = nullptr;           // [H][4][P] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
-    unsigned * hmax = nullptr;            // [H] row maxima (order-preserving encoding), zero between launches
     BARK_TRACE_FIELD
 };
-void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);
-void launch_attn_decode_part(hipStream_t s, const AttnDecodeArgs & a, int parts);   // 1 scores, 2 mix, 3 both (timing hook)
+void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);      // a.ps set: attn_ps_kernel; otherwise attn_fused_kernel (one workgroup per head and slot)
 
 // Multi-query attention (prefill / fine): N queries at positions n_past.., keys 0..n_past+N-1.
 struct AttnPrefillArgs {
     const float * q = nullptr; int ldq = 0; const float * kc = nullptr; const float * vc = nullptr;
     int H = 0, P = 0, N = 0, n_past = 0; int causal = 1;
-    float * scores = nullptr;              // scratch [H][N][P]
     half_t * att = nullptr; int ld_att = 0;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32 (same leading dimension)
-    int dbg = 0;                          // timing experiments only (BARK_HIP_ATTN_DBG): 1 skip scores, 2 skip exp, 4 skip mix (results are wrong)
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 
@@ -178,6 +174,12 @@ void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld,
 void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
                         int out_stride, StepState * st);
 
+// BARK_HIP_CROSSCHECK (bit mask, read once per process): the slower routes kept to check the default ones against, bit for bit
+//   1  N > 1 products through the one-row-per-wave kernels instead of the matrix cores (gemv_rows_kernel / gemm_q_rows_kernel)
+//   2  lock-step decode products on the VALU GEMV per pair of slots instead of gemm_slots16_kernel
+//   4  decode attention without the QKV kernel's partial scores (attn_fused_kernel instead of attn_ps_kernel)
+//   8  every coarse window re-evaluated from its first row (no prefix reuse), as the reference does
+int crosscheck_mask();
 void init_kernel_attributes();
 // internal: per-file pieces of the above and the weight-type specific back ends of launch_linear
 void init_attention_attributes();

@@ -22,6 +22,11 @@
 
 namespace barkhip {
 
+int crosscheck_mask() {
+    static const int mask = getenv("BARK_HIP_CROSSCHECK") ? atoi(getenv("BARK_HIP_CROSSCHECK")) : 0;
+    return mask;
+}
+
 void kernel_fail(const char * fmt, ...) {
     char buf[256];
     va_list ap;
@@ -34,8 +39,7 @@ void kernel_fail(const char * fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // decode GEMV.  One wave = 4 output rows x 16 lanes; lane c of a row owns chain c of C1, i.e. the
 // 16-byte chunks c, c+16, c+32, ... of that weight row: the wave's loads are four fully used
-// 256-byte row segments per instruction.  x is either an f16 vector or (LN = true) an f32 row that
-// every 16-lane group normalises redundantly in registers (no LDS, no barrier).
+// 256-byte row segments per instruction.  x is an f16 vector (the LayerNorm-fused products use gemv_ln_wg_kernel below).
 // ------------------------------------------------------------------------------------------------
 // NBLK = K / 128 is a compile-time constant so that every load of a lane (weights, x, LayerNorm
 // parameters) is issued up front with no control flow in between: the kernel is one memory round
@@ -43,99 +47,31 @@ void kernel_fail(const char * fmt, ...) {
 // The operands the first loads need (weight / input pointers, row count, row window) are explicit leading kernel parameters: built
 // with -amdgpu-kernarg-preload-count the hardware delivers them in SGPRs at wave launch, so the weight stream is requested without
 // the ~0.2 us kernel-argument round trip the in-kernel time line shows in front of every kernel; the struct carries the rest.
-template <int NBLK, bool LN, bool LNB>
+template <int NBLK>
 __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W, const half_t * __restrict__ x_f16, const int M, const int parity_rows, const LinArgs a) {
     TRACE_T0();
     TRACE_T1(M);
     const int lane = threadIdx.x;
     const int c = lane & 15, rg = lane >> 4;
     const int m = blockIdx.x * 4 + rg;
-    constexpr int K = NBLK * 128;
     const int row_off = parity_rows ? parity_rows * (a.st->step & 1) : 0;
     const bool live = m < M;                                // whole 16-lane groups are live or dead together
+    constexpr int K = NBLK * 128;
     const half_t * wrow = W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
-    [[maybe_unused]] EpiPre pre{};
-    if constexpr (LN) pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    const half_t * xrow = x_f16 + (c << 3);
+    // every chunk of the row is requested before the first fmaf (up to 2 x 32 x 16 bytes per lane: a one-wave workgroup may
+    // use all 512 registers).  The chain of a lane is K / 16 dependent fmaf long whatever the load schedule; with batches of
+    // 8 chunks the K = 3072 product paid two more exposed memory round trips (1.8 us between "arguments ready" and "dot done").
+    half8 wv[NBLK], xv[NBLK];
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) { wv[i] = ld_half8_w(wrow + (i << 7)); xv[i] = ld_half8(xrow + (i << 7)); }
+    __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
+    const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     float acc = 0.0f;
-
-    if constexpr (LN) {
-        static_assert(NBLK <= 8, "LayerNorm-fused GEMV keeps the row in registers (n_embd <= 1024)");
-        half8 wv[NBLK];
-        float4 xa[NBLK][2], ga[NBLK][2], ba[NBLK][2];
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) {
         #pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            const int k0 = (b * 16 + c) << 3;
-            wv[b] = ld_half8(wrow + (b << 7));
-            xa[b][0] = *reinterpret_cast<const float4 *>(a.x_f32 + k0); xa[b][1] = *reinterpret_cast<const float4 *>(a.x_f32 + k0 + 4);
-            ga[b][0] = *reinterpret_cast<const float4 *>(a.ln_g + k0);  ga[b][1] = *reinterpret_cast<const float4 *>(a.ln_g + k0 + 4);
-            if constexpr (LNB) { ba[b][0] = *reinterpret_cast<const float4 *>(a.ln_b + k0); ba[b][1] = *reinterpret_cast<const float4 *>(a.ln_b + k0 + 4); }
-        }
-        // ggml_norm (+mul, +add): double sums, eps on the variance (bark.cpp:1265-1274)
-        // (four partial sums per lane keep the fp64 add chains short; the order of a double sum of floats
-        // changes the rounded float mean / variance with probability ~2^-29)
-        float xr[NBLK][8];
-        double p1[4] = {0.0, 0.0, 0.0, 0.0};
-        #pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            xr[b][0] = xa[b][0].x; xr[b][1] = xa[b][0].y; xr[b][2] = xa[b][0].z; xr[b][3] = xa[b][0].w;
-            xr[b][4] = xa[b][1].x; xr[b][5] = xa[b][1].y; xr[b][6] = xa[b][1].z; xr[b][7] = xa[b][1].w;
-            // the wave's four 16-lane groups hold identical rows: group rg sums only the blocks b = rg (mod 4)
-            if ((b & 3) == rg) {
-                #pragma unroll
-                for (int e = 0; e < 8; e++) p1[e & 3] += (double) xr[b][e];
-            }
-        }
-        const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
-        const float mean = (float) (s1 / (double) K);
-        double p2[4] = {0.0, 0.0, 0.0, 0.0};
-        #pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            #pragma unroll
-            for (int e = 0; e < 8; e++) { const float v = xr[b][e] - mean; xr[b][e] = v; if ((b & 3) == rg) p2[e & 3] += (double) (v * v); }
-        }
-        const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
-        const float var = (float) (s2 / (double) K);
-        const float scale = 1.0f / sqrtf(var + 1e-5f);
-        #pragma unroll
-        for (int b = 0; b < NBLK; b++) {
-            const float gg[8] = {ga[b][0].x, ga[b][0].y, ga[b][0].z, ga[b][0].w, ga[b][1].x, ga[b][1].y, ga[b][1].z, ga[b][1].w};
-            float bb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if constexpr (LNB) { bb[0] = ba[b][0].x; bb[1] = ba[b][0].y; bb[2] = ba[b][0].z; bb[3] = ba[b][0].w; bb[4] = ba[b][1].x; bb[5] = ba[b][1].y; bb[6] = ba[b][1].z; bb[7] = ba[b][1].w; }
-            #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float v = xr[b][e] * scale;
-                v = v * gg[e];
-                if constexpr (LNB) v = v + bb[e];
-                // mul_mat converts the activation to f16 first
-                acc = fmaf((float) wv[b][e], (float) to_half(v), acc);
-            }
-        }
-    } else {
-        const half_t * xrow = x_f16 + (c << 3);
-        // every chunk of the row is requested before the first fmaf (up to 2 x 32 x 16 bytes per lane: a one-wave workgroup may
-        // use all 512 registers).  The chain of a lane is K / 16 dependent fmaf long whatever the load schedule; with batches of
-        // 8 chunks the K = 3072 product paid two more exposed memory round trips (1.8 us between "arguments ready" and "dot done").
-        constexpr int G = NBLK;                               // loads in flight per lane and operand
-        half8 wv[2][G], xv[2][G];
-        #pragma unroll
-        for (int i = 0; i < G; i++) { wv[0][i] = ld_half8_w(wrow + (i << 7)); xv[0][i] = ld_half8(xrow + (i << 7)); }
-        __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
-        pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
-        #pragma unroll
-        for (int g = 0; g < NBLK / G; g++) {
-            if (g + 1 < NBLK / G) {
-                #pragma unroll
-                for (int i = 0; i < G; i++) {
-                    wv[(g + 1) & 1][i] = ld_half8(wrow + (((g + 1) * G + i) << 7));
-                    xv[(g + 1) & 1][i] = ld_half8(xrow + (((g + 1) * G + i) << 7));
-                }
-            }
-            #pragma unroll
-            for (int i = 0; i < G; i++) {
-                #pragma unroll
-                for (int e = 0; e < 8; e++) acc = fmaf((float) wv[g & 1][i][e], (float) xv[g & 1][i][e], acc);
-            }
-        }
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
     }
     TRACE_T2(acc);
     acc = wave_xor_add16(acc);
@@ -261,6 +197,8 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
     acc = wave_xor_add16(acc);
     if (live && c == 0 && !copy) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (PS) {
+        // the copies cover the keys below (copies per q block) x kpc; a launch whose bound on the context was too small must not pass silently
+        if (blockIdx.x == 0 && tid == 0 && pre.n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;
         __shared__ float qs[16];
         if (is_q) {                                              // uniform per workgroup
             if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
@@ -280,33 +218,27 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
 
 template <int NBLK>
 static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
-    dim3 grid((a.M + 3) / 4), block(64);
-    if (a.x_f32) {
-        if constexpr (NBLK <= 8) {
-            static const bool one_wave = getenv("BARK_HIP_LN_ONE_WAVE") != nullptr;       // A/B: every wave normalises the row itself
-            if (!one_wave) {
-                const dim3 g16((a.M + 15) / 16), b256(256);
-                const float * kc = a.kc;
-                if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
-                    // copies of the q workgroups: as many per q block as fit beside the main workgroups on 256 CUs (at most 2), each
-                    // scoring kpc = 256 or 512 of the up to 256 ng keys the context may hold
-                    const int n_main = (a.M + 15) / 16, n_q = a.E / 16, keys = 256 * std::max(1, std::min(a.ng, 4));
-                    const int fit = std::max(1, std::min(2, (256 - n_main) / n_q));
-                    const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));      // a copy scores at most 512 keys (two per thread)
-                    const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;                 // 256, 384 or 512
-                    const dim3 gps(n_main + n_copy * n_q);
-                    if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
-                    else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
-                }
-                else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
-                else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
-            }
-            else if (a.ln_b) hipLaunchKernelGGL((gemv_kernel<NBLK, true, true>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-            else             hipLaunchKernelGGL((gemv_kernel<NBLK, true, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
-        } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
-    } else {
-        hipLaunchKernelGGL((gemv_kernel<NBLK, false, false>), grid, block, 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    if (!a.x_f32) {
+        hipLaunchKernelGGL((gemv_kernel<NBLK>), dim3((a.M + 3) / 4), dim3(64), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+        return;
     }
+    if constexpr (NBLK <= 8) {
+        const dim3 g16((a.M + 15) / 16), b256(256);
+        const float * kc = a.kc;
+        if (a.ps && a.epi == EPI_QKV && a.P == 1024) {
+            // copies of the q workgroups: as many per q block as fit beside the main workgroups on 256 CUs (at most 2), each
+            // scoring kpc = 256 or 512 of the up to 256 ng keys the context may hold
+            const int n_main = (a.M + 15) / 16, n_q = a.E / 16, keys = 256 * std::max(1, std::min(a.ng, 4));
+            const int fit = std::max(1, std::min(2, (256 - n_main) / n_q));
+            const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));      // a copy scores at most 512 keys (two per thread)
+            const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;                 // 256, 384 or 512
+            const dim3 gps(n_main + n_copy * n_q);
+            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
+            else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
+        }
+        else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
+        else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
+    } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
 }
 
 // Batched decode GEMV (several utterances in lock step): grid.y walks the sequence slots, BPW slots per wave.
@@ -934,8 +866,7 @@ static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
     hipLaunchKernelGGL((gemm_slots16_kernel<NBLK>), dim3((a.M + 15) / 16, (a.nbatch + 15) / 16), dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
 }
 
-void launch_linear_slots(hipStream_t s, const LinArgs & a, int kind) {
-    (void) kind;                                                 // one matrix-core route (kind != 0); 0 = the VALU GEMV, chosen by the callers
+void launch_linear_slots(hipStream_t s, const LinArgs & a) {
     if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
     switch (a.K >> 7) {
         case 1:  launch_slots16_n<1>(s, a); break;
@@ -985,8 +916,7 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         return;
     }
     if (a.x_f32 || a.parity_rows) { kernel_fail("bark-hip: batched linear op needs f16 rows"); }
-    static const bool force_rows = getenv("BARK_HIP_GEMM_ROWS") != nullptr;      // cross-check path
-    if (force_rows) {
+    if (crosscheck_mask() & 1) {
         dim3 grid((a.M + 15) / 16, a.N), block(256);
         hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
         return;

@@ -172,13 +172,12 @@ __global__ __launch_bounds__(256) void ln_rows_vec_kernel(const float * __restri
     }
 }
 void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * g, const float * b, half_t * out) {
-    static const bool plain = getenv("BARK_HIP_LN_ROWS_PLAIN") != nullptr;       // A/B and cross-check
     const dim3 grid((N + 3) / 4), block(256);
-    if (!plain && E == 768)  { hipLaunchKernelGGL((ln_rows_vec_kernel<3>), grid, block, 0, s, x, N, g, b, out); return; }
-    if (!plain && E == 1024) { hipLaunchKernelGGL((ln_rows_vec_kernel<4>), grid, block, 0, s, x, N, g, b, out); return; }
-    if (!plain && E == 512)  { hipLaunchKernelGGL((ln_rows_vec_kernel<2>), grid, block, 0, s, x, N, g, b, out); return; }
-    if (!plain && E == 256)  { hipLaunchKernelGGL((ln_rows_vec_kernel<1>), grid, block, 0, s, x, N, g, b, out); return; }
-    hipLaunchKernelGGL(ln_rows_kernel, grid, block, 0, s, x, N, E, g, b, out);
+    if (E == 768)  { hipLaunchKernelGGL((ln_rows_vec_kernel<3>), grid, block, 0, s, x, N, g, b, out); return; }
+    if (E == 1024) { hipLaunchKernelGGL((ln_rows_vec_kernel<4>), grid, block, 0, s, x, N, g, b, out); return; }
+    if (E == 512)  { hipLaunchKernelGGL((ln_rows_vec_kernel<2>), grid, block, 0, s, x, N, g, b, out); return; }
+    if (E == 256)  { hipLaunchKernelGGL((ln_rows_vec_kernel<1>), grid, block, 0, s, x, N, g, b, out); return; }
+    hipLaunchKernelGGL(ln_rows_kernel, grid, block, 0, s, x, N, E, g, b, out);       // other widths (toy models): three trips over the row
 }
 
 
@@ -482,6 +481,7 @@ void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld,
 }
 
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
+    if (a.x && a.E > 1024) kernel_fail("bark-hip: the sampler writes the next token's embedding with one thread per element (n_embd <= 1024)");
     if (a.temp > 0.0f) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a.logits, a.st, a.n, a.ld_logits, a);
 }

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t * __restrict_
     acc = wave_xor_add16(acc);
     if (live && c == 0 && !copy) linear_epilogue_pre(a, slot, m, acc, pre);
     if constexpr (PS) {
+        if (blockIdx.x == 0 && tid == 0 && pre.n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;      // see gemv_ln_wg_kernel
         __shared__ float qsh[16];
         if (copy) {                                              // uniform per workgroup
             if (c == 0) qsh[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64) void q8_rows_kernel(const Q8RowsArgs a) {
 }
 
 // rows (N > 1), v_dot4 version: NB pre-quantised activation rows per wave share each unpacked weight block.  Kept as the
-// cross-check path of the MFMA kernel (BARK_HIP_Q4_ROWS); bound by L2 re-reads of the weights.
+// cross-check path of the MFMA kernel (BARK_HIP_CROSSCHECK bit 0); bound by L2 re-reads of the weights.
 struct QRowsArgs { LinArgs lin; const int8_t * q; const float * d, * dT, * s, * sT; };
 template <int QT, int NB>
 __global__ __launch_bounds__(64) void gemm_q_rows_kernel(const QRowsArgs qa) {
@@ -504,9 +505,8 @@ static void launch_linear_qt(hipStream_t s, const LinArgs & a) {
         }
         return;
     }
-    static const bool force_rows = getenv("BARK_HIP_Q4_ROWS") != nullptr;        // v_dot4 row kernel, the cross-check path
     const QRowsArgs qa{a, a.xq.q, a.xq.d, a.xq.dT, a.xq.s, a.xq.sT};
-    if (!force_rows) {
+    if (!(crosscheck_mask() & 1)) {                                              // bit 0: v_dot4 row kernel, the cross-check path
         dim3 grid((a.M + Q4G_TM - 1) / Q4G_TM, (a.N + Q4G_TN - 1) / Q4G_TN), block(512);
         hipLaunchKernelGGL((gemm_q_mfma_kernel<QT>), grid, block, 8 * Q4G_TN * Q4G_LD * sizeof(float), s, qa);
         return;

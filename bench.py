@@ -120,15 +120,21 @@ def cpu_baseline_leg(model_path: str, prompt: str, n_semantic: int) -> dict:
     the GPU box's host).  `value` is the RTF of that run - no extrapolation."""
     from oracle.pyoracle import Oracle
     cores = min(os.cpu_count() or 4, 4)
+    before = None
     try:
+        before = os.sched_getaffinity(0)
         os.sched_setaffinity(0, set(range(cores)))              # taskset -c 0-3
     except (AttributeError, OSError):
         pass
-    orc = Oracle(model_path, n_threads=cores)
-    t1 = time.perf_counter()
-    ref = orc.generate(prompt, orc.params(n_steps_text_encoder=n_semantic))
-    cdt = time.perf_counter() - t1
-    orc.close()
+    try:
+        orc = Oracle(model_path, n_threads=cores)
+        t1 = time.perf_counter()
+        ref = orc.generate(prompt, orc.params(n_steps_text_encoder=n_semantic))
+        cdt = time.perf_counter() - t1
+        orc.close()
+    finally:
+        if before is not None:
+            os.sched_setaffinity(0, before)                     # the caller's affinity comes back
     audio_s = ref["n_samples"] / 24000.0
     return {"value": audio_s / cdt, "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"the headline workload itself: same prompt, n_steps_text_encoder={n_semantic} ({audio_s:.2f} s audio, {cdt:.1f} s CPU wall, "
@@ -151,6 +157,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-q4", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the bark-large leg (BASELINE config 3)")
     ap.add_argument("--dump-pcm", default=None, help="rank 0 writes the gathered PCM of the last step here (.npz; tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N > 1 path on a single GPU (with --backend gloo)")
@@ -213,7 +220,7 @@ def main():
                 "metric": "audio-sec/sec (RTF), bark-small f16 greedy", "value": audio_total / dt, "unit": "audio-s/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1000.0 * dt / max(1, a.steps),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16 (f32 accumulate)", "data": "synthetic",
-                "config": {"workload": f"BASELINE config 5: bark-{a.preset} f16, {len(prompts)} synthetic prompts sorted by length, static split "
+                "config": {"workload": f"BASELINE config 5: bark-{a.preset} f16, {len(prompts)} synthetic prompts sorted by length and dealt snake-wise, "
                                        f"{len(idx)} per rank, bark_hip_generate_batch (lock-step) per rank, n_steps_text_encoder={a.n_semantic}; "
                                        "all_gather of sample counts + gather of PCM on rank 0 inside the timed region",
                            "prompts_per_step": len(prompts), "audio_s_per_step": audio_total / max(1, a.steps)},
@@ -273,8 +280,10 @@ def main():
         us, nbytes = ctx.time_gemv(0, 2, 2400)
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_ln_wg_kernel<6> (LayerNorm + FC 3072x768 f16 + GELU, decode)",
                            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12,
-                           "traffic": None, "traffic_note": "not measurable inside this run; PMC summary of this kernel on the final build: profiles/r02_pmc_gemv_fc.json (4.97 MB per launch = FETCH_SIZE x2 + WRITE_SIZE, against 4.72 MB algorithmic)",
-                           "us_per_launch": us, "bytes_per_launch": nbytes}
+                           "traffic": None, "traffic_note": "not measurable inside this run; PMC summary of this kernel on this build: profiles/r03_pmc_gemv_fc.json (FETCH_SIZE x2 + WRITE_SIZE per launch against 4.72 MB algorithmic)",
+                           "us_per_launch": us, "bytes_per_launch": nbytes,
+                           "evidence": "profiles/r03_trace_decode_step.txt (in-kernel time line of the step: span and gap of every kernel) reproduces this duration; "
+                                       "rocprofv3 --kernel-trace inflates 2-3 us kernels to ~5 us each (profiles/r03_kernel_stats_decode.csv is kept for the record)"}
         gem = {}
         for op, name in enumerate(("ln_qkv_partial_scores", "attn_proj", "ln_fc_gelu", "mlp_proj")):
             u, nb = ctx.time_gemv(0, op, 1200)
@@ -318,6 +327,33 @@ def main():
         ctx.set_params(params)
     except Exception as e:      # noqa: BLE001
         out["default_cap_768_steps"] = {"error": str(e)}
+    # BASELINE config 3: bark-large shapes (1024 wide, 24 layers, 16 heads; reference shapes convert.py:86-110), single prompt, greedy
+    if not a.no_large:
+        try:
+            lpath = ensure_model("large", 0)
+            lctx = pkg.BarkContext.load_model(lpath, params, seed=0)
+            lctx.generate_audio(prompts[0])
+            tl = time.perf_counter(); la = 0.0
+            lagg = {"t_semantic_us": 0, "t_coarse_us": 0, "t_fine_us": 0, "t_codec_us": 0, "n_sample_semantic": 0, "n_sample_coarse": 0, "n_sample_fine": 0}
+            for i in range(2):
+                assert lctx.generate_audio(prompts[1 + i])
+                ls = lctx.stats(); la += ls["n_samples"] / 24000.0
+                for k in lagg:
+                    lagg[k] += ls[k]
+            dtl = time.perf_counter() - tl
+            dus, dbytes = lctx.time_decode_step(0, 640, 160)
+            fus, flops = lctx.time_fine_pass(3)
+            out["bark_large"] = {"config": "BASELINE config 3: bark-large f16 on 1xMI355X, single prompt, greedy, n_steps_text_encoder=%d" % a.n_semantic,
+                                 "rtf": la / dtl, "ms_per_prompt": dtl * 500.0,
+                                 "stage_ms_per_token": {"semantic": lagg["t_semantic_us"] / 1000.0 / max(1, lagg["n_sample_semantic"]),
+                                                        "coarse": lagg["t_coarse_us"] / 1000.0 / max(1, lagg["n_sample_coarse"]),
+                                                        "fine": lagg["t_fine_us"] / 1000.0 / max(1, lagg["n_sample_fine"]), "codec_ms": lagg["t_codec_us"] / 2000.0},
+                                 "decode_step_us": dus, "decode_step_GB/s": dbytes / (dus * 1e-6) / 1e9, "decode_step_hbm_frac": dbytes / (dus * 1e-6) / 8e12,
+                                 "fine_pass_us": fus, "fine_pass_TFLOP/s": flops / (fus * 1e-6) / 1e12, "fine_pass_frac_of_f32_mfma_peak": flops / (fus * 1e-6) / 157.3e12,
+                                 "parity": "tests/test_gpu_parity.py::test_large_model_shapes (64- and 256-step oracle fixtures of this model file)"}
+            lctx.free()
+        except Exception as e:      # noqa: BLE001
+            out["bark_large"] = {"error": str(e)}
     # BASELINE config 4: the same model quantised to q4_0 by the native bark_model_quantize (reported beside the headline)
     if not a.no_q4:
         try:

@@ -168,3 +168,15 @@ def test_committed_batch_fixture_is_what_the_oracle_generates():
     assert np.array_equal(ref["semantic"], want[f"semantic{i}"]) and np.array_equal(ref["coarse"], want[f"coarse{i}"]) and np.array_equal(ref["fine"], want[f"fine{i}"])
     assert pcm.size == int(want[f"pcm_len{i}"])
     assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), want[f"pcm_sha256_{i}"])
+
+
+def test_large_256_step_fixture_extends_the_64_step_one():
+    """tests/golden/oracle_large_256.npz (BASELINE config 3's full workload) takes four minutes of oracle time and is therefore not
+    re-derived here; greedy decoding makes the 64-step run (re-derived above) a prefix of it, which ties the two files together."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    short = np.load(os.path.join(root, "tests", "golden", "oracle_large_64.npz"))
+    full = np.load(os.path.join(root, "tests", "golden", "oracle_large_256.npz"))
+    assert np.array_equal(short["model_sha256"], full["model_sha256"])
+    assert len(full["semantic"]) == 256 and full["coarse"].shape == (384, 2) and full["fine"].shape == (384, 8)
+    assert np.array_equal(full["semantic"][:64], short["semantic"])      # (the coarse windows see all semantic ids, so only this stage is a prefix)

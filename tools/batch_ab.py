@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the lock-step batch path (BARK_HIP_BATCH_MFMA=0 VALU, default matrix cores): prompts/s at B = 8 and 32, each arm in a fresh process."""
+"""A/B of the lock-step batch path (BARK_HIP_CROSSCHECK=2 VALU products, default matrix cores): prompts/s at B = 8 and 32, each arm in a fresh process."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -22,7 +22,7 @@ print("RESULT", json.dumps(out))
 ''' % ROOT
 # arms: NAME[:K=V,K=V...] on the command line; default: the VALU route against the two MFMA routes
 arms = []
-for a in sys.argv[1:] or ["valu:BARK_HIP_BATCH_MFMA=0", "mfma"]:
+for a in sys.argv[1:] or ["valu:BARK_HIP_CROSSCHECK=2", "mfma"]:
     name, _, kv = a.partition(":")
     arms.append((name, dict(x.split("=") for x in kv.split(",") if x)))
 for name, env in arms:
