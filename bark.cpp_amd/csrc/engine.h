@@ -86,6 +86,8 @@ struct bark_context {
     float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)
     float * ps = nullptr;                               // [H][4][P] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
+    barkhip::half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr;      // tolerance route (fast_gemm): f16 operands of the flash attention, [rows_cap][E] each
+    size_t rows_cap = 0;                                // rows the many-row scratch (x, q, xn, att, hbuf, q16 ...) holds: P, or P * fine batch
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;
     float * att32 = nullptr, * h32 = nullptr; barkhip::Q8Scratch xq;

@@ -39,6 +39,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
     const int fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
+    const bool flash = fast && !causal && pos0 == 0 && N % 1024 == 0 && !kbase && !vbase && c->q16 && E % 64 == 0;
     // kbase / vbase: another utterance slot's cache (batched decode); default: the context's own cache
     auto layer_k = [&](const GptModel & mm, int l) { return (kbase ? kbase : mm.kcache) + mm.kv_layer_stride * (size_t) l; };
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
@@ -53,11 +54,20 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         if (!kbase && !vbase) a.vt = detail::layer_vt(m, l);      // the context's own cache keeps the K-layout copy of V too
         a.fast = fast;
-        launch_linear(s, a);
-        AttnPrefillArgs at;
-        at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
-        at.causal = causal ? 1 : 0; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
-        launch_attn_prefill(s, at);
+        if (flash) {
+            // tolerance route of the fine model: q / k / v leave the product as the f16 operands of the flash attention (no KV cache)
+            a.epi = EPI_QKV16; a.q16 = c->q16; a.k16 = c->k16; a.vt16 = c->vt16; a.seq = 1024;
+            launch_linear(s, a);
+            AttnFlashArgs fa;
+            fa.q16 = c->q16; fa.k16 = c->k16; fa.vt16 = c->vt16; fa.H = H; fa.E = E; fa.S = 1024; fa.Z = N / 1024; fa.att = c->att; fa.ld_att = E;
+            launch_attn_flash(s, fa);
+        } else {
+            launch_linear(s, a);
+            AttnPrefillArgs at;
+            at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
+            at.causal = causal ? 1 : 0; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
+            launch_attn_prefill(s, at);
+        }
         if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; if (m.w32) p.x_f32 = c->att32; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;

@@ -132,6 +132,12 @@ static void init_runtime(bark_context * ctxp) {
     ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
     ctx->att = dev_alloc<half_t>(ctx.get(), NE);
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
+    ctx->rows_cap = (size_t) P;
+    if (ctx->fast_gemm) {
+        ctx->q16 = dev_alloc<half_t>(ctx.get(), NE);
+        ctx->k16 = dev_alloc<half_t>(ctx.get(), NE);
+        ctx->vt16 = dev_alloc<half_t>(ctx.get(), NE);
+    }
     ctx->ps = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * 4);
     ctx->knew = dev_alloc<float>(ctx.get(), (size_t) ctx->max_E);
     HIP_OK(hipMemset(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float)));

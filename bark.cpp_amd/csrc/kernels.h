@@ -52,7 +52,7 @@ struct TraceSink { unsigned long long * rec = nullptr; unsigned * pos = nullptr;
 #define BARK_TRACE_FIELD
 #endif
 
-enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
+enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_QKV16 = 4 };      // EPI_QKV16: tolerance route only (fast_kernels.hip)
 
 // One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
 struct LinArgs {
@@ -93,10 +93,13 @@ struct LinArgs {
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
-    // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order.  Same
-    // operands and roundings as the canonical product (R1), only the ORDER of the f32 additions differs from C1: results agree to f32
-    // rounding noise, not bit for bit, so this route is never the one the parity tests check.
+    // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order
+    // (gemm_f16_tile_kernel, fast_kernels.hip).  Same operands and roundings as the canonical product (R1), only the ORDER of the f32
+    // additions differs from C1: results agree to f32 rounding noise, not bit for bit, so this route is never the one the parity tests check.
     int fast = 0;
+    // EPI_QKV16 (fast route, fine model): q (x 0.125) and k as f16 rows [N][E], v transposed [N / seq][E][seq] with permuted keys - the
+    // operands of attn_flash_f16_kernel; N is a whole number of sequences of `seq` rows
+    half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr; int seq = 0;
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
@@ -146,6 +149,15 @@ struct AttnPrefillArgs {
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32 (same leading dimension)
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
+// Tolerance route of the fine model's attention (non-causal, whole sequences): flash-style on the f16 matrix cores, operands from EPI_QKV16
+struct AttnFlashArgs {
+    const half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr;
+    int H = 0, E = 0, S = 0, Z = 1;          // S keys / queries per sequence, Z sequences
+    half_t * att = nullptr; int ld_att = 0;   // [Z * S][ld_att]
+};
+void launch_attn_flash(hipStream_t s, const AttnFlashArgs & a);
+void launch_linear_fast(hipStream_t s, const LinArgs & a);           // gemm_f16_tile_kernel
+void init_fast_attributes();
 
 // Greedy pick (gpt_argmax_sample, bark.cpp:223-247) over logits[0..n); advances *st.
 struct SampleArgs {

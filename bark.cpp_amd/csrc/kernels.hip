@@ -544,245 +544,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// exact GEMM, second formulation: v_mfma_f32_16x16x4_f32 (an ascending-k fmaf chain over its four products, 32 cycles per issue, the
-// same 32 multiply-adds per clock and SIMD as 32x32x2 - tools/probes/mfma16x16x4_probe.hip, mfma_rate_probe.hip).  A 16 x 16 tile
-// costs 4 accumulator registers per chain, so ONE wave holds all 16 chains of a 32 x 16 sub-tile (128 registers) and the chains meet
-// in its registers in the C1 tree order: no 128 KB LDS tree, no serial epilogue phase behind the main loop (the 32x32x2 kernel above
-// parks 8 x 64 x 64 partial sums in LDS and idles its matrix cores while they are reduced - with one workgroup per CU nothing overlaps that).
-// LDS is spent on the operands instead: a K block (128 elements) of the workgroup's 64 x rows and 64 weight rows is converted to f32
-// ONCE by the thread that fetched it and stored as [chain][g][row]{element g, element 4 + g} - exactly the pair a lane of the MFMA
-// feeds to the two issues of a chain's 8-element chunk - so an operand fetch is one conflict-free ds_read_b64 and the matrix waves
-// run no conversions.  Two such blocks (2 x 65 KB) are resident: block b + 1 is written while block b is multiplied, one barrier per block.
-//   workgroup 64 (x rows n) x 64 (weight rows m), 8 waves as 2 (n) x 4 (m), wave sub-tile 32 x 16 = two MFMA tiles sharing the weight operand
-//   lane (g, r) of a wave: A = x row r of the tile, B = weight row r, k = g; D register v = (row 4 g + v, column r)
-// ------------------------------------------------------------------------------------------------
-constexpr int G16_ROWS = 65;                                   // row stride (float2) of the staged operands: 64 rows + 1 (spreads the stores over the banks)
-constexpr int G16_OPER = 16 * 4 * G16_ROWS;                    // float2 per operand and buffer
-__global__ __launch_bounds__(512) void gemm16_kernel(const LinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float2 * stage = reinterpret_cast<float2 *>(lds);          // [buffer][x | w][chain][g][row]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = lane >> 4, r = lane & 15;
-    const int wn = w >> 2, wm = w & 3;
-    const int n0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
-    const int K = a.K, nblk = K >> 7;
-    // staging: chunk id = tid + 512 i (i = 0, 1) of each operand: row id >> 4, chain id & 15 - a wave reads 4 rows x 256 contiguous bytes
-    const half_t * xsrc[2], * wsrc[2];
-    int sdst[2];
-    #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int id = tid + 512 * i, row = id >> 4, ch = id & 15;
-        xsrc[i] = a.x_f16 + (size_t) min(n0 + row, a.N - 1) * K + (ch << 3);
-        wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + (ch << 3);
-        sdst[i] = (ch * 4) * G16_ROWS + row;
-    }
-    uint4 xr[2], wr[2];
-    auto fetch = [&](int b) {
-        #pragma unroll
-        for (int i = 0; i < 2; i++) { xr[i] = ld_u4(xsrc[i] + (b << 7)); wr[i] = ld_u4(wsrc[i] + (b << 7)); }
-    };
-    auto store = [&](int buf) {
-        float2 * xs = stage + (size_t) buf * 2 * G16_OPER, * ws = xs + G16_OPER;
-        #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            #pragma unroll
-            for (int gg = 0; gg < 4; gg++) {
-                xs[sdst[i] + gg * G16_ROWS] = float2{half_of(xr[i], gg), half_of(xr[i], 4 + gg)};
-                ws[sdst[i] + gg * G16_ROWS] = float2{half_of(wr[i], gg), half_of(wr[i], 4 + gg)};
-            }
-        }
-    };
-    floatx4 acc[16][2];
-    #pragma unroll
-    for (int c = 0; c < 16; c++)
-        #pragma unroll
-        for (int t = 0; t < 2; t++) acc[c][t] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-    fetch(0);
-    store(0);
-    if (nblk > 1) fetch(1);
-    __syncthreads();
-    const int ra = g * G16_ROWS + wn * 32 + r, rb = g * G16_ROWS + wm * 16 + r;
-    for (int b = 0; b < nblk; b++) {
-        const float2 * xs = stage + (size_t) (b & 1) * 2 * G16_OPER, * ws = xs + G16_OPER;
-        #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const float2 a0 = xs[c * 4 * G16_ROWS + ra], a1 = xs[c * 4 * G16_ROWS + ra + 16], bw = ws[c * 4 * G16_ROWS + rb];
-            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bw.x, acc[c][0], 0, 0, 0);
-            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bw.x, acc[c][1], 0, 0, 0);
-            acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bw.y, acc[c][0], 0, 0, 0);
-            acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bw.y, acc[c][1], 0, 0, 0);
-            if (c == 7 && b + 1 < nblk) {                     // half way through the block: block b + 1 goes into the other buffer, block b + 2 is requested
-                store((b + 1) & 1);
-                if (b + 2 < nblk) fetch(b + 2);
-            }
-        }
-        __syncthreads();
-    }
-    // the 16 chains of every output meet in registers, C1 tree order (partner xor 1, 2, 4, 8)
-    floatx4 sum[2];
-    #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        floatx4 p[16];
-        #pragma unroll
-        for (int c = 0; c < 16; c++) p[c] = acc[c][t];
-        #pragma unroll
-        for (int st = 1; st < 16; st <<= 1)
-            #pragma unroll
-            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        sum[t] = p[0];
-    }
-    // lane (g, r): outputs (n = n0 + wn 32 + t 16 + 4 g + v, m = m0 + wm 16 + r); for fixed (t, v) the 16 lanes of a row group write 16 consecutive m
-    const int m = m0 + wm * 16 + r;
-    if (m >= a.M) return;
-    const float bias = a.bias ? a.bias[m] : 0.0f;
-    const int n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
-    #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int nb = n0 + wn * 32 + t * 16 + 4 * g;
-        float v[4];
-        #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = a.bias ? sum[t][e] + bias : sum[t][e];
-        switch (a.epi) {
-            case EPI_RESID: {
-                float old[4];
-                #pragma unroll
-                for (int e = 0; e < 4; e++) old[e] = nb + e < a.N ? a.res[(size_t) (nb + e) * a.M + m] : 0.0f;
-                #pragma unroll
-                for (int e = 0; e < 4; e++) if (nb + e < a.N) a.res[(size_t) (nb + e) * a.M + m] = v[e] + old[e];      // cur + inpL (bark.cpp:1352,1388)
-                break;
-            }
-            case EPI_GELU: {
-                #pragma unroll
-                for (int e = 0; e < 4; e++) if (nb + e < a.N) a.out_h[(size_t) (nb + e) * a.M + m] = gelu_lut_apply(v[e], a.lut);
-                break;
-            }
-            case EPI_QKV: {
-                const int E = a.E;
-                const int mm = m < E ? m : m < 2 * E ? m - E : m - 2 * E;
-                const int h = mm >> 6, d = mm & 63;
-                #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int n = nb + e;
-                    if (n >= a.N) continue;
-                    const int pos = a.pos0 + n_past + n;
-                    if (m < E) a.q[(size_t) n * E + m] = v[e];
-                    else if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v[e];
-                    else { a.vc[vc_index(h, d, pos, a.P)] = v[e]; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v[e]; }
-                }
-                break;
-            }
-            default: {
-                #pragma unroll
-                for (int e = 0; e < 4; e++) if (nb + e < a.N) a.out[(size_t) (nb + e) * a.ld_out + m] = v[e];
-                break;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fast (non-canonical) GEMM for N > 1: v_mfma_f32_32x32x16_f16.  One wave = one 64 x 64 output tile over the whole K; no LDS and no
-// barrier.  Lane (half, l31) feeds the 16-element k step with the 16-byte chunk at k + 8 half of its x row and of its weight row - the
-// instruction's k assignment inside a step does not matter because both operands use the same one.  Products of two f16 values are
-// exact in f32; the 16 products of a step and the running sum are added in the matrix core's order instead of C1's.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void gemm_f16_kernel(const LinArgs a) {
-    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.y * 64, m0 = blockIdx.x * 64;
-    const int K = a.K;
-    const half_t * xp[2], * wp[2];
-    #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        xp[t] = a.x_f16 + (size_t) min(n0 + t * 32 + l31, a.N - 1) * K + (half << 3);
-        wp[t] = a.W + (size_t) min(m0 + t * 32 + l31, a.M - 1) * K + (half << 3);
-    }
-    floatx16 acc[2][2];
-    #pragma unroll
-    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    // four k steps (64 elements) per buffer, two buffers: the loads of the next 64 elements are in flight while 16 MFMAs issue
-    half8 xa0[4][2], wb0[4][2], xa1[4][2], wb1[4][2];
-#define F16_LOAD(XA, WB, K0)                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                            \
-        _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                      \
-            XA[q][t] = ld_half8(xp[t] + (K0) + 16 * q);                                                      \
-            WB[q][t] = ld_half8(wp[t] + (K0) + 16 * q);                                                      \
-        }
-#define F16_MFMA(XA, WB)                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 4; q++)                                                            \
-        _Pragma("unroll") for (int i = 0; i < 2; i++)                                                        \
-            _Pragma("unroll") for (int j = 0; j < 2; j++)                                                    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(XA[q][i], WB[q][j], acc[i][j], 0, 0, 0);
-    F16_LOAD(xa0, wb0, 0)
-    for (int k = 0; k < K; k += 128) {                          // K is a multiple of 128
-        F16_LOAD(xa1, wb1, k + 64)
-        __builtin_amdgcn_sched_barrier(0);
-        F16_MFMA(xa0, wb0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 128 < K) { F16_LOAD(xa0, wb0, k + 128) }
-        __builtin_amdgcn_sched_barrier(0);
-        F16_MFMA(xa1, wb1)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef F16_LOAD
-#undef F16_MFMA
-    // accumulator register r of lane (half, l31): x row (r & 3) + 8 (r >> 2) + 4 half of the tile, weight row l31: for a fixed r the 32
-    // lanes of a half write 32 consecutive columns of one row.  The operator switch sits outside the element loops.
-    const int n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
-    #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int m = m0 + j * 32 + l31;
-        if (m >= a.M) continue;
-        const float bias = a.bias ? a.bias[m] : 0.0f;
-        #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int nb = n0 + i * 32 + 4 * half;
-            float v[16];
-            #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = a.bias ? acc[i][j][r] + bias : acc[i][j][r];
-            switch (a.epi) {
-                case EPI_RESID: {
-                    float old[16];
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); old[r] = n < a.N ? a.res[(size_t) n * a.M + m] : 0.0f; }
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); if (n < a.N) a.res[(size_t) n * a.M + m] = v[r] + old[r]; }
-                    break;
-                }
-                case EPI_GELU: {
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int n = nb + (r & 3) + 8 * (r >> 2);
-                        if (n < a.N) a.out_h[(size_t) n * a.M + m] = gelu_lut_apply(v[r], a.lut);
-                    }
-                    break;
-                }
-                case EPI_QKV: {
-                    const int E = a.E;
-                    const int mm = m < E ? m : m < 2 * E ? m - E : m - 2 * E;
-                    const int h = mm >> 6, d = mm & 63;
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int n = nb + (r & 3) + 8 * (r >> 2);
-                        if (n >= a.N) continue;
-                        const int pos = a.pos0 + n_past + n;
-                        if (m < E) a.q[(size_t) n * E + m] = v[r];
-                        else if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v[r];
-                        else { a.vc[vc_index(h, d, pos, a.P)] = v[r]; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v[r]; }
-                    }
-                    break;
-                }
-                default: {
-                    #pragma unroll
-                    for (int r = 0; r < 16; r++) { const int n = nb + (r & 3) + 8 * (r >> 2); if (n < a.N) a.out[(size_t) n * a.ld_out + m] = v[r]; }
-                    break;
-                }
-            }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Lock-step decode product: y[slot][m] for up to 32 utterance slots at once, every weight read ONCE per step for all slots.
 // v_mfma_f32_16x16x1_4b_f32 issues FOUR independent 16 x 16 x 1 blocks, each one fused multiply-add per element: block g of wave w is
 // chain 4 w + g of C1, so a wave walks four chains of a (16 weight rows x 16 slots) tile element by element and a 256-thread
@@ -921,22 +682,18 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
         return;
     }
-    if (a.fast == 1) {
-        hipLaunchKernelGGL(gemm_f16_kernel, dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(64), 0, s, a);
-        return;
-    }
+    if (a.fast == 1) { launch_linear_fast(s, a); return; }
+    if (a.epi == EPI_QKV16) kernel_fail("bark-hip: the f16 QKV epilogue exists on the tolerance route only");
     dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);
-    static const int which = getenv("BARK_HIP_GEMM16") ? atoi(getenv("BARK_HIP_GEMM16")) : 1;       // A/B: 0 = the 32x32x2 kernel with its LDS tree
-    if (which && !a.out_h32) hipLaunchKernelGGL(gemm16_kernel, grid, block, 4 * G16_OPER * sizeof(float2), s, a);
-    else hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+    hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
 }
 
 void init_kernel_attributes() {
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G16_OPER * (int) sizeof(float2));
     init_attention_attributes();
     init_quant_attributes();
+    init_fast_attributes();
 }
 
 }  // namespace barkhip

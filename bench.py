@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-q4", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the bark-large leg (BASELINE config 3)")
+    ap.add_argument("--no-roofline-legs", action="store_true", help="skip the kernel timing legs (rocprofv3 passes: the statistics then hold the prompts' kernels only)")
     ap.add_argument("--dump-pcm", default=None, help="rank 0 writes the gathered PCM of the last step here (.npz; tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N > 1 path on a single GPU (with --backend gloo)")
@@ -277,10 +278,15 @@ def main():
     # (they cannot be read inside this run): null here; profiles/r02_pmc_gemv_fc.json is the PMC summary of this kernel, regenerated
     # on the final build by the same gpurun call as the committed bench line (tools/collect_profiles.sh).
     try:
+        if a.no_roofline_legs:
+            raise RuntimeError("timing legs switched off (--no-roofline-legs)")
         us, nbytes = ctx.time_gemv(0, 2, 2400)
+        traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r03_pmc_gemv_fc.json")
+        if os.path.exists(traffic_src):
+            traffic = json.load(open(traffic_src)).get("traffic_bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_ln_wg_kernel<6> (LayerNorm + FC 3072x768 f16 + GELU, decode)",
                            "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12,
-                           "traffic": None, "traffic_note": "not measurable inside this run; PMC summary of this kernel on this build: profiles/r03_pmc_gemv_fc.json (FETCH_SIZE x2 + WRITE_SIZE per launch against 4.72 MB algorithmic)",
+                           "traffic": traffic, "traffic_note": "HBM-side bytes per launch; PMC counters cannot be read inside this run: the figure is the committed rocprofv3 PMC summary of this kernel, profiles/r03_pmc_gemv_fc.json (FETCH_SIZE x2 + WRITE_SIZE, separate passes), null when that file is absent",
                            "us_per_launch": us, "bytes_per_launch": nbytes,
                            "evidence": "profiles/r03_trace_decode_step.txt (in-kernel time line of the step: span and gap of every kernel) reproduces this duration; "
                                        "rocprofv3 --kernel-trace inflates 2-3 us kernels to ~5 us each (profiles/r03_kernel_stats_decode.csv is kept for the record)"}
