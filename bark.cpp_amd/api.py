@@ -67,7 +67,7 @@ EXPORTS = [
     "ggml_time_init", "ggml_time_us", "ggml_time_ms", "ggml_init", "ggml_free",
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
-    "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_codec_decode", "bark_hip_codec_tap",
+    "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_describe",
 ]
@@ -110,6 +110,7 @@ def load_library() -> C.CDLL:
     lib.bark_hip_semantic.argtypes = [vp, ip, ip, C.c_int, fp]
     lib.bark_hip_coarse.argtypes = [vp, ip, C.c_int, ip, C.c_int]
     lib.bark_hip_fine.argtypes = [vp, ip, C.c_int, ip, C.c_int]
+    lib.bark_hip_fine_many.argtypes = [vp, ip, ip, C.c_int, ip, C.c_int]
     lib.bark_hip_codec_decode.argtypes = [vp, ip, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_generate_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
@@ -274,6 +275,20 @@ class BarkContext:
         if T < 0:
             raise RuntimeError("bark_hip_fine failed")
         return out[:T].copy()
+
+    def fine_many(self, coarse_list) -> list:
+        """The fine stage of several utterances, their windows side by side in every forward pass (bark_hip_fine_many)."""
+        cos = [_i32(x).reshape(-1, 2) for x in coarse_list]
+        T = _i32([len(x) for x in cos])
+        cat = np.ascontiguousarray(np.concatenate(cos, axis=0))
+        out = np.zeros((len(cat), 8), np.int32)
+        n = self._lib.bark_hip_fine_many(self._h, cat.ctypes.data, T.ctypes.data, len(cos), out.ctypes.data, len(out))
+        if n < 0:
+            raise RuntimeError("bark_hip_fine_many failed")
+        res, off = [], 0
+        for t in T:
+            res.append(out[off:off + int(t)].copy()); off += int(t)
+        return res
 
     def codec_decode(self, codes_qxT) -> np.ndarray:
         codes = _i32(codes_qxT)

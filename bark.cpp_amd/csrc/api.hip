@@ -188,6 +188,28 @@ int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T,
     });
 }
 
+int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat, const int * T, int n, int32_t * out_concat, int capacity_rows) {
+    if (!bctx || !coarse_concat || !T || n <= 0 || !out_concat) return -1;
+    return guarded("bark_hip_fine_many", -1, [&] {
+        std::vector<std::vector<int32_t>> co((size_t) n);
+        std::vector<const std::vector<int32_t> *> ptr;
+        std::vector<std::mt19937> rngs;
+        size_t off = 0, total = 0;
+        for (int i = 0; i < n; i++) {
+            if (T[i] <= 0) throw std::runtime_error("fine_many: every utterance needs at least one frame");
+            co[(size_t) i].assign(coarse_concat + off * 2, coarse_concat + (off + (size_t) T[i]) * 2);
+            off += (size_t) T[i]; total += (size_t) T[i];
+            ptr.push_back(&co[(size_t) i]);
+            rngs.push_back(std::mt19937((uint32_t) bctx->rng()));
+        }
+        if ((long) total > (long) capacity_rows) throw std::runtime_error("output buffer too small");
+        std::vector<std::vector<int32_t>> r = engine_fine_many(bctx, ptr, &rngs);
+        off = 0;
+        for (int i = 0; i < n; i++) { memcpy(out_concat + off * 8, r[(size_t) i].data(), r[(size_t) i].size() * 4); off += r[(size_t) i].size() / 8; }
+        return (int) total;
+    });
+}
+
 int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm, int capacity) {
     if (!bctx || !codes || !pcm) return -1;
     return guarded("bark_hip_codec_decode", -1, [&] {

@@ -256,10 +256,19 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
 //   4. the 16 chains meet in LDS (aliasing the score tile) in tree order
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_LD = 1026;
-__global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a) {
+__global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [32][ATT_LD] scores, then [8][32][64] partial sums
     __shared__ float rowinv[32];
-    const int h = blockIdx.y, i0 = blockIdx.x * 32;
+    AttnPrefillArgs a = a0;
+    // XCD-aware: the query tiles of one (sequence, head) hold consecutive ranks, so its K and V (512 KB at 1024 keys) stay in one L2
+    const int QT = (a.N + 31) >> 5, rank = xcd_rank(blockIdx.x, QT * a.H * max(1, a.Z));
+    const int h = (rank / QT) % a.H, i0 = (rank % QT) * 32;
+    if (a.Z > 1) {                                                      // sequence z: its own rows of q / att and its own cache
+        const size_t z = rank / (QT * a.H);
+        a.q += z * (size_t) a.N * a.ldq; a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride;
+        if (a.att) a.att += z * (size_t) a.N * a.ld_att;
+        if (a.att32) a.att32 += z * (size_t) a.N * a.ld_att;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int ctx = a.n_past + a.N;
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a)
 }
 
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
-    hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32, a.H), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
+    hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32 * a.H * std::max(1, a.Z)), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
 }
 
 void init_attention_attributes() {

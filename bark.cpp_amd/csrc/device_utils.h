@@ -159,6 +159,22 @@ DEVINL float wte_elem(const half_t * wte, const QMat & q, int E, int tok, int e)
     return q.m ? v + (float) q.m[blk] : v;
 }
 
+// XCD-aware workgroup ids.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8; observed, used for
+// speed only) and every XCD has its own 4 MB L2: with the hardware order, the tiles that share an operand (a row panel of x, the K / V of
+// one head) are spread over all eight L2s and every one of them fetches everything through the fabric - measured on the many-row
+// products and the prefill attention as a common ceiling of ~3.8 TB/s of operand traffic.  xcd_rank() renumbers the workgroups so that
+// one XCD holds CONSECUTIVE ranks (bijective for any grid size); panel_tile() walks the output tiles in column panels of width pw, so
+// that a run of consecutive ranks covers a compact rows x pw rectangle (few distinct operand slices per XCD at any moment).
+DEVINL int xcd_rank(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+DEVINL void panel_tile(int l, int nrow, int ncol, int pw, int & row, int & col) {
+    const int per_panel = nrow * pw, p = l / per_panel, rem = l - p * per_panel;
+    const int c0 = p * pw, w = min(pw, ncol - c0);
+    row = rem / w; col = c0 + (rem - row * w);
+}
+
 // K cache element address: [H][16][P][4] floats; V cache: [H][P][64]
 DEVINL size_t kc_index(int h, int d, int pos, int P) { return (((size_t) h * 16 + (d >> 2)) * P + pos) * 4 + (d & 3); }
 DEVINL size_t vc_index(int h, int d, int pos, int P) { return ((size_t) h * P + pos) * 64 + d; }
@@ -243,10 +259,12 @@ DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_
         case EPI_QKV: {
             const int E = a.E;
             if (m < E) { a.q[(size_t) n * E + m] = v; break; }
-            const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
+            const int zq = a.seq ? n / a.seq : 0;
+            const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
+            const size_t zoff = (size_t) zq * a.kv_slot_stride;
             const int mm = m < 2 * E ? m - E : m - 2 * E;
             const int h = mm >> 6, d = mm & 63;
-            if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v; else { a.vc[vc_index(h, d, pos, a.P)] = v; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v; }
+            if (m < 2 * E) a.kc[zoff + kc_index(h, d, pos, a.P)] = v; else { a.vc[zoff + vc_index(h, d, pos, a.P)] = v; if (a.vt) a.vt[zoff + kc_index(h, d, pos, a.P)] = v; }
             break;
         }
         case EPI_RESID: { float * r = a.res + (size_t) n * a.M + m; *r = v + *r; break; }       // cur + inpL (bark.cpp:1352,1388)

@@ -122,6 +122,14 @@ struct bark_context {
         size_t ld_logits = 0;
         hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
     } batch;
+    // fine windows of several utterances in one forward pass (engine_fine_many): rows = cap * 1024
+    struct FineBatch {
+        int cap = 0;
+        float * x = nullptr, * q = nullptr, * logits = nullptr, * kc = nullptr, * vc = nullptr;
+        barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr, * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr;
+        int32_t * tokens = nullptr, * picks = nullptr;   // [8][cap * 1024] window ids (codebook-major planes), [cap * 1024] scratch picks
+        double * u = nullptr;                            // [6][cap * 1024] uniform draws (fine_temp > 0)
+    } fine_batch;
     struct BatchResult { std::vector<int32_t> semantic, coarse, fine; std::vector<float> audio; bool ok = false; };
     std::vector<BatchResult> batch_results;
 
@@ -151,6 +159,9 @@ void engine_fine_eval(bark_context * ctx, const int32_t * tokens_8x1024, int nn,
 std::vector<int32_t> engine_semantic(bark_context * ctx, const std::vector<int32_t> & prompt, std::vector<float> * eos_trace);
 std::vector<int32_t> engine_coarse(bark_context * ctx, const std::vector<int32_t> & semantic);          // [T][2]
 std::vector<int32_t> engine_fine(bark_context * ctx, const std::vector<int32_t> & coarse_Tx2);          // [T][8]
+// the fine stage of several utterances, their windows side by side in every forward pass (f16 model files; per-utterance results are those
+// of engine_fine); rngs: one generator per utterance (fine_temp > 0), advanced as engine_fine advances the context's
+std::vector<std::vector<int32_t>> engine_fine_many(bark_context * ctx, const std::vector<const std::vector<int32_t> *> & coarse, std::vector<std::mt19937> * rngs);
 // tap_stage >= 0: *tap receives the activation after that stage (0 first conv, 1 LSTM+skip, 2..5 up-blocks)
 std::vector<float>   engine_codec_decode(bark_context * ctx, const int32_t * codes, int n_q, int T, int tap_stage, std::vector<float> * tap);
 // all utterances of a batch in one pass (codes[b]: [n_q][T[b]]); the launches of one utterance serve all of them

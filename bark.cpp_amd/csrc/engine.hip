@@ -34,56 +34,68 @@ float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
 float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.kv_layer_stride * (size_t) l : nullptr; }
 
+RowBufs own_rows(bark_context * c) {
+    RowBufs r; r.x = c->x; r.q = c->q; r.xn = c->xn; r.att = c->att; r.hbuf = c->hbuf; r.q16 = c->q16; r.k16 = c->k16; r.vt16 = c->vt16;
+    r.logits = c->logits; r.tokens = c->d_tokens; r.plane = 1024;
+    return r;
+}
+
 // N > 1 rows through all layers (bark.cpp:1261-1389 causal, :1474-1562 fine); x holds the embeddings.
-void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0) {
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0, const RowBufs * rbp, int seq, size_t kv_seq_stride) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
+    const RowBufs own = own_rows(c);
+    const RowBufs & rb = rbp ? *rbp : own;
+    if (rbp && (m.q4 || m.w32)) throw std::runtime_error("row scratch other than the context's own: f16 model files only");
     const int fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
-    const bool flash = fast && !causal && pos0 == 0 && N % 1024 == 0 && !kbase && !vbase && c->q16 && E % 64 == 0;
-    // kbase / vbase: another utterance slot's cache (batched decode); default: the context's own cache
+    const int Z = seq > 0 ? N / seq : 1;
+    const bool flash = fast && !causal && pos0 == 0 && N % 1024 == 0 && (seq == 0 || seq == 1024) && (rbp || (!kbase && !vbase)) && rb.q16 && E % 64 == 0;
+    // kbase / vbase: another utterance slot's cache (batched decode) or the fine batch's; default: the context's own cache
     auto layer_k = [&](const GptModel & mm, int l) { return (kbase ? kbase : mm.kcache) + mm.kv_layer_stride * (size_t) l; };
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         // f16 weights: activations are rounded to f16 rows (xn / att / hbuf); q4_0 weights: f32 rows quantised to q8_0 (xq8 / xd8)
-        if (m.w32)     launch_ln_rows_f32(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn32);
-        else if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xq);
-        else           launch_ln_rows(s, c->x, N, E, L.ln1_g, L.ln1_b, c->xn);
+        if (m.w32)     launch_ln_rows_f32(s, rb.x, N, E, L.ln1_g, L.ln1_b, c->xn32);
+        else if (m.q4) launch_q8_rows(s, rb.x, N, E, L.ln1_g, L.ln1_b, c->xq);
+        else           launch_ln_rows(s, rb.x, N, E, L.ln1_g, L.ln1_b, rb.xn);
         LinArgs a;
-        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = c->xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
-        a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
+        a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = rb.xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
+        a.q = rb.q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         if (!kbase && !vbase) a.vt = detail::layer_vt(m, l);      // the context's own cache keeps the K-layout copy of V too
+        a.seq = seq; a.kv_slot_stride = kv_seq_stride;
         a.fast = fast;
         if (flash) {
             // tolerance route of the fine model: q / k / v leave the product as the f16 operands of the flash attention (no KV cache)
-            a.epi = EPI_QKV16; a.q16 = c->q16; a.k16 = c->k16; a.vt16 = c->vt16; a.seq = 1024;
+            a.epi = EPI_QKV16; a.q16 = rb.q16; a.k16 = rb.k16; a.vt16 = rb.vt16; a.seq = 1024;
             launch_linear(s, a);
             AttnFlashArgs fa;
-            fa.q16 = c->q16; fa.k16 = c->k16; fa.vt16 = c->vt16; fa.H = H; fa.E = E; fa.S = 1024; fa.Z = N / 1024; fa.att = c->att; fa.ld_att = E;
+            fa.q16 = rb.q16; fa.k16 = rb.k16; fa.vt16 = rb.vt16; fa.H = H; fa.E = E; fa.S = 1024; fa.Z = N / 1024; fa.att = rb.att; fa.ld_att = E;
             launch_attn_flash(s, fa);
         } else {
             launch_linear(s, a);
             AttnPrefillArgs at;
-            at.q = c->q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = N; at.n_past = pos0;
-            at.causal = causal ? 1 : 0; at.att = c->att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
+            at.q = rb.q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = seq > 0 ? seq : N; at.n_past = pos0;
+            at.causal = causal ? 1 : 0; at.att = rb.att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
+            at.Z = Z; at.kv_seq_stride = kv_seq_stride;
             launch_attn_prefill(s, at);
         }
         if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);
         LinArgs p;
-        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = c->att; p.xq = c->xq; if (m.w32) p.x_f32 = c->att32; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
+        p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = N; p.x_f16 = rb.att; p.xq = c->xq; if (m.w32) p.x_f32 = c->att32; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = rb.x;
         p.fast = fast;
         launch_linear(s, p);
-        if (m.w32)     launch_ln_rows_f32(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn32);
-        else if (m.q4) launch_q8_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xq);
-        else           launch_ln_rows(s, c->x, N, E, L.ln2_g, L.ln2_b, c->xn);
+        if (m.w32)     launch_ln_rows_f32(s, rb.x, N, E, L.ln2_g, L.ln2_b, c->xn32);
+        else if (m.q4) launch_q8_rows(s, rb.x, N, E, L.ln2_g, L.ln2_b, c->xq);
+        else           launch_ln_rows(s, rb.x, N, E, L.ln2_g, L.ln2_b, rb.xn);
         LinArgs f;
-        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = c->xn; f.xq = c->xq; if (m.w32) f.x_f32 = c->xn32; f.bias = L.fc_b; f.epi = EPI_GELU;
-        f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
+        f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = N; f.x_f16 = rb.xn; f.xq = c->xq; if (m.w32) f.x_f32 = c->xn32; f.bias = L.fc_b; f.epi = EPI_GELU;
+        f.out_h = rb.hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
         f.fast = fast;
         launch_linear(s, f);
         if (m.q4 && !m.w32) launch_q8_rows(s, c->h32, N, 4 * E, nullptr, nullptr, c->xq);
         LinArgs o;
-        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = c->hbuf; o.xq = c->xq; if (m.w32) o.x_f32 = c->h32; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
+        o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = N; o.x_f16 = rb.hbuf; o.xq = c->xq; if (m.w32) o.x_f32 = c->h32; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = rb.x;
         o.fast = fast;
         launch_linear(s, o);
     }
@@ -352,17 +364,21 @@ int engine_gpt_eval(bark_context * c, int which, const int32_t * tokens, int n_t
 }
 
 namespace detail {
-// one fine forward (bark_build_fine_gpt_graph, bark.cpp:1416-1584): d_tokens holds [8][1024]; logits -> c->logits [1024][n_rows]
-void run_fine_forward(bark_context * c, int nn, int n_rows) {
+// one fine forward (bark_build_fine_gpt_graph, bark.cpp:1416-1584): tokens [8][plane] hold Z windows of 1024 positions back to back;
+// logits -> rb.logits [Z * 1024][n_rows]
+void run_fine_forward(bark_context * c, int nn, int n_rows, const RowBufs * rbp, int Z) {
     GptModel & m = c->gpt[2];
-    const int E = m.hp.n_embd;
-    launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, c->d_tokens, nn, c->x);
-    run_layers_rows(c, m, 1024, false);
-    if (m.w32)     launch_ln_rows_f32(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn32);
-    else if (m.q4) launch_q8_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xq);
-    else           launch_ln_rows(c->stream, c->x, 1024, E, m.lnf_g, m.lnf_b, c->xn);
+    const int E = m.hp.n_embd, N = 1024 * Z;
+    const RowBufs own = own_rows(c);
+    const RowBufs & rb = rbp ? *rbp : own;
+    launch_embed_fine(c->stream, m.wte, m.wte_q, m.wpe, E, m.hp.n_in_vocab, rb.tokens, nn, rb.x, N, rb.plane);
+    if (rbp) run_layers_rows(c, m, N, false, c->fine_batch.kc, c->fine_batch.vc, 0, rbp, 1024, (size_t) E * c->P);
+    else     run_layers_rows(c, m, N, false);
+    if (m.w32)     launch_ln_rows_f32(c->stream, rb.x, N, E, m.lnf_g, m.lnf_b, c->xn32);
+    else if (m.q4) launch_q8_rows(c->stream, rb.x, N, E, m.lnf_g, m.lnf_b, c->xq);
+    else           launch_ln_rows(c->stream, rb.x, N, E, m.lnf_g, m.lnf_b, rb.xn);
     LinArgs a;
-    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = 1024; a.x_f16 = c->xn; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
+    a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = N; a.x_f16 = rb.xn; a.epi = EPI_LOGITS; a.out = rb.logits; a.ld_out = n_rows;
     a.fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
@@ -644,6 +660,113 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
     c->stats.n_near_tie += cur.near_tie;
     in_arr.resize((size_t) T * 8);                                                           // strip the time padding
     return in_arr;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The fine stage of several utterances at once (lock-step batches): window n of every utterance that has one goes through the six
+// forward passes side by side - rows z * 1024 .. z * 1024 + 1023 of every activation are utterance z's window, the attention runs per
+// window (grid.z), the products see 1024 Z rows.  Per utterance this is engine_fine's arithmetic, row for row.
+// ---------------------------------------------------------------------------------------------------
+static void ensure_fine_batch(bark_context * c, int Z) {
+    bark_context::FineBatch & fb = c->fine_batch;
+    if (fb.cap >= Z) return;
+    GptModel & m = c->gpt[2];
+    const size_t R = (size_t) Z * 1024, E = (size_t) m.hp.n_embd;
+    fb.x = dev_alloc<float>(c, R * E); fb.q = dev_alloc<float>(c, R * E);
+    fb.xn = dev_alloc<half_t>(c, R * E); fb.att = dev_alloc<half_t>(c, R * E); fb.hbuf = dev_alloc<half_t>(c, R * E * 4);
+    fb.kc = dev_alloc<float>(c, (size_t) Z * E * c->P); fb.vc = dev_alloc<float>(c, (size_t) Z * E * c->P);
+    if (c->fast_gemm) { fb.q16 = dev_alloc<half_t>(c, R * E); fb.k16 = dev_alloc<half_t>(c, R * E); fb.vt16 = dev_alloc<half_t>(c, R * E); }
+    fb.logits = dev_alloc<float>(c, R * 1024);
+    fb.tokens = dev_alloc<int32_t>(c, 8 * R); fb.picks = dev_alloc<int32_t>(c, R);
+    fb.u = dev_alloc<double>(c, 6 * R);
+    fb.cap = Z;                                             // (a smaller earlier allocation stays with the context until it is freed)
+}
+
+std::vector<std::vector<int32_t>> engine_fine_many(bark_context * c, const std::vector<const std::vector<int32_t> *> & coarse, std::vector<std::mt19937> * rngs) {
+    HIP_OK(hipSetDevice(c->device));
+    const bark_context_params & p = c->params;
+    GptModel & m = c->gpt[2];
+    const int nc = p.n_coarse_codebooks, nf = p.n_fine_codebooks, cs = p.codebook_size;
+    if (nc != 2 || nf != 8 || cs != 1024) throw std::runtime_error("fine: only 2 -> 8 codebooks of 1024 entries are supported");
+    if (m.q4 || m.w32 || c->host_sampling) throw std::runtime_error("fine_many: f16 model files, device sampling");
+    const int U = (int) coarse.size();
+    const bool greedy = p.fine_temp == 0.0f;
+    if (!greedy && (!rngs || (int) rngs->size() != U)) throw std::runtime_error("fine_many: one generator per utterance is needed for fine_temp > 0");
+    struct Utt { int T, L, n_loops; std::vector<int32_t> in_arr; };
+    std::vector<Utt> us((size_t) U);
+    int max_loops = 0;
+    for (int u = 0; u < U; u++) {
+        const std::vector<int32_t> & co = *coarse[(size_t) u];
+        Utt & t = us[(size_t) u];
+        t.T = (int) co.size() / nc;
+        if (t.T <= 0 || t.T > 8192) throw std::runtime_error("fine: number of frames must be in 1..8192");
+        for (int32_t v : co) if (v < 0 || v >= cs) throw std::runtime_error("fine: coarse code out of range");
+        t.L = std::max(t.T, 1024);
+        t.in_arr.assign((size_t) t.L * 8, cs);                                              // bark.cpp:1983-1996
+        for (int i = 0; i < t.T; i++) for (int ch = 0; ch < nc; ch++) t.in_arr[(size_t) i * 8 + ch] = co[(size_t) i * nc + ch];
+        t.n_loops = std::max(0, (int) ceilf((float) (t.L - 1024) / 512.f)) + 1;             // bark.cpp:1998
+        max_loops = std::max(max_loops, t.n_loops);
+    }
+    ensure_fine_batch(c, U);
+    bark_context::FineBatch & fb = c->fine_batch;
+    StepState st = fresh_state();
+    set_state(c, st);
+    std::vector<int32_t> buf;
+    std::vector<double> ubuf;
+    for (int n = 0; n < max_loops; n++) {
+        std::vector<int> act, rels, fills;
+        for (int u = 0; u < U; u++) if (n < us[(size_t) u].n_loops) act.push_back(u);
+        const int Z = (int) act.size(), R = Z * 1024;
+        buf.assign((size_t) 8 * R, cs);
+        bool any_rel = false;
+        for (int z = 0; z < Z; z++) {
+            const Utt & t = us[(size_t) act[(size_t) z]];
+            const int start_idx = std::min(n * 512, t.L - 1024), start_fill_idx = std::min(n * 512, t.L - 512);      // bark.cpp:2002-2013
+            rels.push_back(start_fill_idx - start_idx); fills.push_back(start_fill_idx);
+            any_rel = any_rel || rels.back() > 0;
+            for (int ch = 0; ch < 8; ch++) for (int j = 0; j < 1024; j++) buf[(size_t) ch * R + (size_t) z * 1024 + j] = t.in_arr[(size_t) (start_idx + j) * 8 + ch];
+        }
+        HIP_OK(hipMemcpyAsync(fb.tokens, buf.data(), buf.size() * 4, hipMemcpyHostToDevice, c->stream));
+        if (!greedy) {
+            // utterance z draws (nf - nc) * 1024 uniforms per window, codebook-major, from a COPY of its generator (upload_uniforms)
+            ubuf.assign((size_t) 6 * R, 0.0);
+            for (int z = 0; z < Z; z++) {
+                std::mt19937 tmp = (*rngs)[(size_t) act[(size_t) z]];
+                for (int k = 0; k < nf - nc; k++) for (int j = 0; j < 1024; j++) ubuf[(size_t) k * R + (size_t) z * 1024 + j] = std::generate_canonical<double, 53>(tmp);
+            }
+            HIP_OK(hipMemcpyAsync(fb.u, ubuf.data(), ubuf.size() * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_OK(hipStreamSynchronize(c->stream));
+        RowBufs rb; rb.x = fb.x; rb.q = fb.q; rb.xn = fb.xn; rb.att = fb.att; rb.hbuf = fb.hbuf; rb.q16 = fb.q16; rb.k16 = fb.k16; rb.vt16 = fb.vt16;
+        rb.logits = fb.logits; rb.tokens = fb.tokens; rb.plane = R;
+        for (int nn = nc; nn < nf; nn++) {
+            progress(c, FINE, 100 * (n * (nf - nc) + (nn - nc + 1)) / (max_loops * (nf - nc)));
+            // a window with rel > 0 (the last ones of a long utterance) keeps the positions below rel: picks go to a scratch row first
+            int32_t * pick_dst = any_rel ? fb.picks : fb.tokens + (size_t) nn * R;
+            run_fine_forward(c, nn, cs, &rb, Z);
+            if (greedy) launch_argmax_rows(c->stream, fb.logits, cs, R, cs, pick_dst, 1, c->d_state);
+            else launch_sample_rows_multinomial(c->stream, fb.logits, cs, R, cs, p.fine_temp, fb.u + (size_t) (nn - nc) * R, pick_dst, 1);
+            if (any_rel)
+                for (int z = 0; z < Z; z++)
+                    HIP_OK(hipMemcpyAsync(fb.tokens + (size_t) nn * R + (size_t) z * 1024 + rels[(size_t) z], fb.picks + (size_t) z * 1024 + rels[(size_t) z],
+                                          (size_t) (1024 - rels[(size_t) z]) * 4, hipMemcpyDeviceToDevice, c->stream));
+            c->stats.n_sample_fine += R;
+        }
+        HIP_OK(hipMemcpyAsync(buf.data(), fb.tokens, buf.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (int z = 0; z < Z; z++) {
+            Utt & t = us[(size_t) act[(size_t) z]];
+            const int rel = rels[(size_t) z];
+            if (!greedy) (*rngs)[(size_t) act[(size_t) z]].discard(2ull * (unsigned long long) ((nf - nc) * 1024));
+            for (int nn = nc; nn < nf; nn++)                                                 // bark.cpp:2041-2046
+                for (int j = 0; j < cs - rel; j++) t.in_arr[(size_t) (fills[(size_t) z] + j) * 8 + nn] = buf[(size_t) nn * R + (size_t) z * 1024 + rel + j];
+        }
+    }
+    const StepState cur = get_state(c);
+    c->stats.n_near_tie += cur.near_tie;
+    std::vector<std::vector<int32_t>> out((size_t) U);
+    for (int u = 0; u < U; u++) { us[(size_t) u].in_arr.resize((size_t) us[(size_t) u].T * 8); out[(size_t) u] = std::move(us[(size_t) u].in_arr); }
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------------

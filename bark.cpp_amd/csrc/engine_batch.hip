@@ -456,23 +456,45 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     }
     c->stats.t_coarse_us = now_us() - t;
 
-    // ---- fine: one utterance at a time (a pass is compute-bound on its own: 214 GFLOP of exact f32 products) --------------------
+    // ---- fine (bark.cpp:1961-2059): the windows of up to `chunk` utterances side by side in every forward pass (engine_fine_many): the
+    // products then see thousands of rows (whole waves of tiles on every CU instead of 0.75 - 2.25 rounds), the attention runs per window.
+    // Quantised / f32 model files keep the per-utterance loop.
     int good = 0;
     std::vector<int> live;                                           // utterances that reach the codec
     std::vector<std::vector<int32_t>> codes;
-    for (int b = 0; b < B; b++) {
-        bark_context::BatchResult & r = c->batch_results[(size_t) b];
-        if (r.coarse.empty()) continue;
+    {
+        static const int chunk_env = getenv("BARK_HIP_FINE_BATCH") ? atoi(getenv("BARK_HIP_FINE_BATCH")) : 8;
+        const bool many = chunk_env > 1 && !c->gpt[2].q4 && !c->gpt[2].w32 && !c->host_sampling;
+        std::vector<int> todo;
+        for (int b = 0; b < B; b++) if (!c->batch_results[(size_t) b].coarse.empty()) todo.push_back(b);
         t = now_us();
-        std::swap(c->rng, slot_rng[(size_t) b]);                        // the fine stage draws from the utterance's generator
-        try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, slot_rng[(size_t) b]); throw; }
-        std::swap(c->rng, slot_rng[(size_t) b]);
+        for (size_t k0 = 0; k0 < todo.size(); k0 += (size_t) std::max(1, chunk_env)) {
+            const size_t k1 = std::min(todo.size(), k0 + (size_t) std::max(1, chunk_env));
+            if (many) {
+                std::vector<const std::vector<int32_t> *> co;
+                std::vector<std::mt19937> rr;
+                for (size_t k = k0; k < k1; k++) { co.push_back(&c->batch_results[(size_t) todo[k]].coarse); rr.push_back(slot_rng[(size_t) todo[k]]); }
+                std::vector<std::vector<int32_t>> fine = engine_fine_many(c, co, &rr);
+                for (size_t k = k0; k < k1; k++) { c->batch_results[(size_t) todo[k]].fine = std::move(fine[k - k0]); slot_rng[(size_t) todo[k]] = rr[k - k0]; }
+            } else {
+                for (size_t k = k0; k < k1; k++) {
+                    const int b = todo[k];
+                    bark_context::BatchResult & r = c->batch_results[(size_t) b];
+                    std::swap(c->rng, slot_rng[(size_t) b]);                        // the fine stage draws from the utterance's generator
+                    try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, slot_rng[(size_t) b]); throw; }
+                    std::swap(c->rng, slot_rng[(size_t) b]);
+                }
+            }
+        }
         c->stats.t_fine_us += now_us() - t;
-        const int T = (int) r.fine.size() / 8;
-        std::vector<int32_t> cd((size_t) 8 * T);
-        for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) cd[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];      // bark.cpp:2153-2159
-        codes.push_back(std::move(cd)); live.push_back(b);
-        c->stats.n_frames += T; c->stats.n_semantic += (int32_t) r.semantic.size();
+        for (int b : todo) {
+            bark_context::BatchResult & r = c->batch_results[(size_t) b];
+            const int T = (int) r.fine.size() / 8;
+            std::vector<int32_t> cd((size_t) 8 * T);
+            for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) cd[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];      // bark.cpp:2153-2159
+            codes.push_back(std::move(cd)); live.push_back(b);
+            c->stats.n_frames += T; c->stats.n_semantic += (int32_t) r.semantic.size();
+        }
     }
     // ---- codec: every utterance of the batch in one pass (engine_codec.hip) ----------------------------------------------------
     if (!live.empty()) {

@@ -52,7 +52,12 @@ double weight_bytes_per_element(const GptModel & m);
 float * layer_k(const GptModel & m, int l);
 float * layer_v(const GptModel & m, int l);
 float * layer_vt(const GptModel & m, int l);
-void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0);
+// the many-row scratch a forward pass works in: the context's own (P rows), or the fine batch's (several windows back to back)
+struct RowBufs { float * x, * q; half_t * xn, * att, * hbuf, * q16, * k16, * vt16; float * logits; const int32_t * tokens; int plane; };
+RowBufs own_rows(bark_context * c);
+// seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
+                     const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0);
 void run_layers_decode(bark_context * c, GptModel & m);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);
@@ -74,6 +79,6 @@ std::vector<float> fetch_logits(bark_context * c, size_t n);
 void upload_uniforms(bark_context * c, int n);
 void consume_uniforms(bark_context * c, int n_used);
 void progress(bark_context * c, bark_encoding_step step, int pct);
-void run_fine_forward(bark_context * c, int nn, int n_rows);
+void run_fine_forward(bark_context * c, int nn, int n_rows, const RowBufs * rb = nullptr, int Z = 1);
 
 } }  // namespace barkhip::detail

@@ -62,10 +62,12 @@ DEVINL void fast_tile_epilogue(const LinArgs & a, const floatx16 & acc, int tile
             for (int r = 0; r < 16; r++) {
                 const int n = nb + (r & 3) + 8 * (r >> 2);
                 if (n >= a.N) continue;
-                const int pos = a.pos0 + n_past + n;
+                const int zq = a.seq ? n / a.seq : 0;
+                const int pos = a.pos0 + n_past + (n - zq * a.seq);
+                const size_t zoff = (size_t) zq * a.kv_slot_stride;
                 if (m < E) a.q[(size_t) n * E + m] = v[r];
-                else if (m < 2 * E) a.kc[kc_index(h, d, pos, a.P)] = v[r];
-                else { a.vc[vc_index(h, d, pos, a.P)] = v[r]; if (a.vt) a.vt[kc_index(h, d, pos, a.P)] = v[r]; }
+                else if (m < 2 * E) a.kc[zoff + kc_index(h, d, pos, a.P)] = v[r];
+                else { a.vc[zoff + vc_index(h, d, pos, a.P)] = v[r]; if (a.vt) a.vt[zoff + kc_index(h, d, pos, a.P)] = v[r]; }
             }
             break;
         }
@@ -101,8 +103,8 @@ DEVINL void fast_tile_epilogue(const LinArgs & a, const floatx16 & acc, int tile
     }
 }
 
-template <int TN, int TM>
-__global__ __launch_bounds__(256) void gemm_f16_tile_kernel(const LinArgs a) {
+template <int TN, int TM, int D>
+__global__ __launch_bounds__(256, 2) void gemm_f16_tile_kernel(const LinArgs a, const int ncol, const int nrow, const int pw) {
     extern __shared__ __attribute__((aligned(16))) half_t lds_h[];
     half_t * As = lds_h;                                    // [2][TN][FT_LDK]
     half_t * Bs = lds_h + 2 * TN * FT_LDK;                  // [2][TM][FT_LDK]
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(256) void gemm_f16_tile_kernel(const LinArgs a) {
     constexpr int CA = TN / 32, CB = TM / 32;               // 16-byte chunks per thread and K step
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int wn = w >> 1, wm = w & 1;
-    const int n0 = blockIdx.y * TN, m0 = blockIdx.x * TM;
+    int trow, tcol;
+    panel_tile(xcd_rank(blockIdx.x, ncol * nrow), nrow, ncol, pw, trow, tcol);      // XCD-aware: consecutive ranks = a compact block of tiles
+    const int n0 = trow * TN, m0 = tcol * TM;
     const int K = a.K, nkt = K >> 6;
     const half_t * xsrc[CA]; const half_t * wsrc[CB];
     int adst[CA], bdst[CB];
@@ -126,19 +130,9 @@ __global__ __launch_bounds__(256) void gemm_f16_tile_kernel(const LinArgs a) {
         wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + ch * 8;
         bdst[i] = row * FT_LDK + ch * 8;
     }
-    uint4 ra[CA], rb[CB];
-    auto fetch = [&](int kt) {
-        #pragma unroll
-        for (int i = 0; i < CA; i++) ra[i] = ld_u4g(xsrc[i] + (kt << 6));
-        #pragma unroll
-        for (int i = 0; i < CB; i++) rb[i] = ld_u4g(wsrc[i] + (kt << 6));
-    };
-    auto stage = [&](int buf) {
-        #pragma unroll
-        for (int i = 0; i < CA; i++) *reinterpret_cast<uint4 *>(As + buf * TN * FT_LDK + adst[i]) = ra[i];
-        #pragma unroll
-        for (int i = 0; i < CB; i++) *reinterpret_cast<uint4 *>(Bs + buf * TM * FT_LDK + bdst[i]) = rb[i];
-    };
+    // D register sets: tile t travels in set t % D, requested D - 1 K steps before it is written to LDS (a request to HBM takes ~2000
+    // cycles, one K step of MFMAs 130 - 520); the loop is unrolled D times so that every set index is a compile-time constant
+    uint4 ra[D][CA], rb[D][CB];
     floatx16 acc[IT][JT];
     #pragma unroll
     for (int i = 0; i < IT; i++)
@@ -146,29 +140,53 @@ __global__ __launch_bounds__(256) void gemm_f16_tile_kernel(const LinArgs a) {
         for (int j = 0; j < JT; j++)
             #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    fetch(0);
-    stage(0);
-    __syncthreads();
+#define FT_FETCH(SET, KT)                                                                                    \
+    { _Pragma("unroll") for (int i = 0; i < CA; i++) ra[SET][i] = ld_u4g(xsrc[i] + ((KT) << 6));             \
+      _Pragma("unroll") for (int i = 0; i < CB; i++) rb[SET][i] = ld_u4g(wsrc[i] + ((KT) << 6)); }
+#define FT_STAGE(SET, BUF)                                                                                   \
+    { _Pragma("unroll") for (int i = 0; i < CA; i++) *reinterpret_cast<uint4 *>(As + (BUF) * TN * FT_LDK + adst[i]) = ra[SET][i]; \
+      _Pragma("unroll") for (int i = 0; i < CB; i++) *reinterpret_cast<uint4 *>(Bs + (BUF) * TM * FT_LDK + bdst[i]) = rb[SET][i]; }
+#define FT_COMPUTE(KT)                                                                                       \
+    { const half_t * Ab = As + ((KT) & 1) * TN * FT_LDK + aoff;                                              \
+      const half_t * Bb = Bs + ((KT) & 1) * TM * FT_LDK + boff;                                              \
+      _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {                                                     \
+          half8 af[IT], bf[JT];                                                                              \
+          _Pragma("unroll") for (int i = 0; i < IT; i++) af[i] = *reinterpret_cast<const half8 *>(Ab + i * 32 * FT_LDK + kk * 16);      \
+          _Pragma("unroll") for (int jj = 0; jj < JT; jj++) bf[jj] = *reinterpret_cast<const half8 *>(Bb + jj * 32 * FT_LDK + kk * 16);  \
+          _Pragma("unroll") for (int i = 0; i < IT; i++)                                                     \
+              _Pragma("unroll") for (int jj = 0; jj < JT; jj++) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[jj], acc[i][jj], 0, 0, 0); \
+      } }
     const int aoff = (wn * (TN / 2) + l31) * FT_LDK + half * 8, boff = (wm * (TM / 2) + l31) * FT_LDK + half * 8;
-    for (int kt = 0; kt < nkt; kt++) {
-        if (kt + 1 < nkt) fetch(kt + 1);
-        const half_t * Ab = As + (kt & 1) * TN * FT_LDK + aoff;
-        const half_t * Bb = Bs + (kt & 1) * TM * FT_LDK + boff;
+    #pragma unroll
+    for (int j = 0; j < D - 1; j++) if (j < nkt) FT_FETCH(j, j)
+    FT_STAGE(0, 0)
+    __syncthreads();
+    // steady state: groups of D steps without a single branch between the requests and their use - hipcc places s_waitcnt per program
+    // point, not per path: one `if` around a request makes every consumer wait for ALL outstanding loads, i.e. for the request of its
+    // own step (measured: the pipeline depth then changes nothing).  The last 2 D - 2 steps run through a guarded tail.
+    int kt = 0;
+    for (; kt + 2 * D - 2 < nkt; kt += D) {
         #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            half8 af[IT], bf[JT];
-            #pragma unroll
-            for (int i = 0; i < IT; i++) af[i] = *reinterpret_cast<const half8 *>(Ab + i * 32 * FT_LDK + kk * 16);
-            #pragma unroll
-            for (int j = 0; j < JT; j++) bf[j] = *reinterpret_cast<const half8 *>(Bb + j * 32 * FT_LDK + kk * 16);
-            #pragma unroll
-            for (int i = 0; i < IT; i++)
-                #pragma unroll
-                for (int j = 0; j < JT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < D; j++) {
+            FT_FETCH((j + D - 1) % D, kt + j + D - 1)
+            FT_COMPUTE(kt + j)
+            FT_STAGE((j + 1) % D, (kt + j + 1) & 1)
+            __syncthreads();
         }
-        if (kt + 1 < nkt) stage((kt + 1) & 1);
-        __syncthreads();
     }
+    // kt is a multiple of D here: step kt + j travels in set j % D
+    #pragma unroll
+    for (int j = 0; j < 2 * D - 1; j++) {
+        if (kt + j < nkt) {                                     // uniform
+            if (kt + j + D - 1 < nkt) FT_FETCH((j + D - 1) % D, kt + j + D - 1)
+            FT_COMPUTE(kt + j)
+            if (kt + j + 1 < nkt) FT_STAGE((j + 1) % D, (kt + j + 1) & 1)
+            __syncthreads();
+        }
+    }
+#undef FT_COMPUTE
+#undef FT_FETCH
+#undef FT_STAGE
     const int n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
     #pragma unroll
     for (int j = 0; j < JT; j++) {
@@ -179,16 +197,22 @@ __global__ __launch_bounds__(256) void gemm_f16_tile_kernel(const LinArgs a) {
     }
 }
 
+template <int TN, int TM, int D>
+static void launch_tile(hipStream_t s, const LinArgs & a) {
+    const size_t lds = (size_t) 2 * (TN + TM) * FT_LDK * sizeof(half_t);
+    const int ncol = (a.M + TM - 1) / TM, nrow = (a.N + TN - 1) / TN;
+    hipLaunchKernelGGL((gemm_f16_tile_kernel<TN, TM, D>), dim3(ncol * nrow), dim3(256), lds, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+}
+
 void launch_linear_fast(hipStream_t s, const LinArgs & a) {
     if (!a.x_f16 || !a.W || (a.K & 63) != 0 || a.N < 1) kernel_fail("bark-hip: the f16 tile product takes f16 rows and f16 weights, K %% 64 == 0");
     if (a.epi == EPI_QKV16 && (!a.q16 || !a.k16 || !a.vt16 || a.seq <= 0 || (a.seq & 31) || a.N % a.seq)) kernel_fail("bark-hip: QKV16 epilogue needs whole sequences of a multiple of 32 rows");
+    static const int depth = getenv("BARK_HIP_FAST_DEPTH") ? atoi(getenv("BARK_HIP_FAST_DEPTH")) : 3;      // register stages of the operand pipeline: A/B on the device
     const long tiles128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (tiles128 >= 128) {
-        const size_t lds = (size_t) 2 * (128 + 128) * FT_LDK * sizeof(half_t);
-        hipLaunchKernelGGL((gemm_f16_tile_kernel<128, 128>), dim3((a.M + 127) / 128, (a.N + 127) / 128), dim3(256), lds, s, a);
+        if (depth <= 2) launch_tile<128, 128, 2>(s, a); else launch_tile<128, 128, 3>(s, a);
     } else {
-        const size_t lds = (size_t) 2 * (64 + 64) * FT_LDK * sizeof(half_t);
-        hipLaunchKernelGGL((gemm_f16_tile_kernel<64, 64>), dim3((a.M + 63) / 64, (a.N + 63) / 64), dim3(256), lds, s, a);
+        if (depth <= 2) launch_tile<64, 64, 2>(s, a); else if (depth == 3) launch_tile<64, 64, 3>(s, a); else launch_tile<64, 64, 4>(s, a);
     }
 }
 
@@ -199,11 +223,13 @@ void launch_linear_fast(hipStream_t s, const LinArgs & a) {
 //   second product  O^T[d][q] = sum_key V^T[d][key] P^T[key][q]:  B = the lane's own 8 exponentials of key step ks (registers 8 ks ..
 //                   8 ks + 7), A = V^T row d = 32 t + l31 at positions key0 + 16 ks + 8 half .. + 7 (the permuted order of the epilogue)
 // ------------------------------------------------------------------------------------------------
-template <int KS>
+template <int KS, int NB>
 __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlashArgs a) {
     __shared__ float comb[KS > 1 ? (KS - 1) * 34 * 64 : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-    const int q0 = blockIdx.x * 32, h = blockIdx.y, z = blockIdx.z;
+    // XCD-aware: the S / 32 query tiles of one (sequence, head) hold consecutive ranks, so its K and V^T (256 KB) stay in ONE L2
+    const int QT = a.S >> 5, rank = xcd_rank(blockIdx.x, QT * a.H * a.Z);
+    const int q0 = (rank % QT) * 32, h = (rank / QT) % a.H, z = rank / (QT * a.H);
     const int E = a.E, S = a.S;
     const half_t * Qp = a.q16 + ((size_t) z * S + q0 + l31) * E + h * 64 + half * 8;
     const half_t * Kp = a.k16 + ((size_t) z * S + l31) * E + h * 64 + half * 8;
@@ -217,39 +243,43 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
     for (int t = 0; t < 2; t++)
         #pragma unroll
         for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
+    // running maximum in log2 units; it is raised lazily: while the block maximum stays below mrun + 8 the exponentials are formed
+    // against the old maximum (at most 2^8: harmless in f32 and in the f16 operand) and the 32 accumulators are not rescaled
     float mrun = -INFINITY, lrun = 0.0f;
-    constexpr float L2E = 1.44269504088896340736f;
-    half8 kf[4], vf[2][2], kn[4], vn[2][2];
-    auto load_block = [&](half8 (&kk)[4], half8 (&vv)[2][2], int key0) {
-        #pragma unroll
-        for (int s = 0; s < 4; s++) kk[s] = ld_half8(Kp + (size_t) key0 * E + s * 16);
-        #pragma unroll
-        for (int t = 0; t < 2; t++)
-            #pragma unroll
-            for (int ks = 0; ks < 2; ks++) vv[t][ks] = ld_half8(Vp + (size_t) t * 32 * S + key0 + ks * 16);
-    };
-    auto block = [&](const half8 (&kk)[4], const half8 (&vv)[2][2]) {
+    constexpr float L2E = 1.44269504088896340736f, LAZY = 8.0f;
+    // NB register sets: key block b travels in set b % NB and is requested NB - 1 blocks ahead (the operands were written by the
+    // previous kernel on other XCDs: every request goes to the memory side)
+    half8 kr[NB][4], vr[NB][2][2];
+#define FA_LOAD(SET, KEY0)                                                                                   \
+    { _Pragma("unroll") for (int s = 0; s < 4; s++) kr[SET][s] = ld_half8(Kp + (size_t) (KEY0) * E + s * 16); \
+      _Pragma("unroll") for (int t = 0; t < 2; t++)                                                          \
+          _Pragma("unroll") for (int ks = 0; ks < 2; ks++) vr[SET][t][ks] = ld_half8(Vp + (size_t) t * 32 * S + (KEY0) + ks * 16); }
+    auto block = [&](const half8 (&kk_)[4], const half8 (&vv_)[2][2]) {
         floatx16 sc;
         #pragma unroll
         for (int r = 0; r < 16; r++) sc[r] = 0.0f;
         #pragma unroll
-        for (int s = 0; s < 4; s++) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk[s], qf[s], sc, 0, 0, 0);
-        float mx = sc[0];
+        for (int s = 0; s < 4; s++) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk_[s], qf[s], sc, 0, 0, 0);
+        float t2[16];
         #pragma unroll
-        for (int r = 1; r < 16; r++) mx = fmaxf(mx, sc[r]);
+        for (int r = 0; r < 16; r++) t2[r] = sc[r] * L2E;
+        float mx = fmaxf(fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3])), fmaxf(fmaxf(t2[4], t2[5]), fmaxf(t2[6], t2[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(t2[8], t2[9]), fmaxf(t2[10], t2[11])), fmaxf(fmaxf(t2[12], t2[13]), fmaxf(t2[14], t2[15]))));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * L2E);
-        const float moff = -mnew * L2E;
-        float p[16], ls = 0.0f;
-        #pragma unroll
-        for (int r = 0; r < 16; r++) { p[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], L2E, moff)); ls += p[r]; }
-        lrun = lrun * alpha + ls;
-        mrun = mnew;
-        #pragma unroll
-        for (int t = 0; t < 2; t++)
+        if (__builtin_amdgcn_ballot_w64(mx > mrun + LAZY) != 0) {       // some query of the wave needs a new maximum (rare after the first blocks)
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            lrun *= alpha;
             #pragma unroll
-            for (int r = 0; r < 16; r++) o[t][r] *= alpha;
+            for (int t = 0; t < 2; t++)
+                #pragma unroll
+                for (int r = 0; r < 16; r++) o[t][r] *= alpha;
+            mrun = mnew;
+        }
+        float p[16];
+        #pragma unroll
+        for (int r = 0; r < 16; r++) p[r] = __builtin_amdgcn_exp2f(t2[r] - mrun);
+        lrun += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) + (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
         half8 pf[2];
         #pragma unroll
         for (int ks = 0; ks < 2; ks++)
@@ -258,18 +288,27 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
         #pragma unroll
         for (int t = 0; t < 2; t++)
             #pragma unroll
-            for (int ks = 0; ks < 2; ks++) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv[t][ks], pf[ks], o[t], 0, 0, 0);
+            for (int ks = 0; ks < 2; ks++) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vv_[t][ks], pf[ks], o[t], 0, 0, 0);
     };
-    load_block(kf, vf, kbeg);
-    for (int key0 = kbeg; key0 < kend; key0 += 64) {
-        const bool more = key0 + 32 < kend;
-        if (more) load_block(kn, vn, key0 + 32);
-        block(kf, vf);
-        if (more) {
-            if (key0 + 64 < kend) load_block(kf, vf, key0 + 64);
-            block(kn, vn);
+    #pragma unroll
+    for (int j = 0; j < NB - 1; j++) if (kbeg + 32 * j < kend) FA_LOAD(j, kbeg + 32 * j)
+    // steady state without branches between the requests and their use (see gemm_f16_tile_kernel), guarded tail of 2 NB - 2 blocks
+    int key0 = kbeg;
+    for (; key0 + 32 * (2 * NB - 2) < kend; key0 += 32 * NB) {
+        #pragma unroll
+        for (int j = 0; j < NB; j++) {
+            FA_LOAD((j + NB - 1) % NB, key0 + 32 * (j + NB - 1))
+            block(kr[j], vr[j]);
         }
     }
+    #pragma unroll
+    for (int j = 0; j < 2 * NB - 1; j++) {
+        if (key0 + 32 * j < kend) {                             // uniform
+            if (key0 + 32 * (j + NB - 1) < kend) FA_LOAD((j + NB - 1) % NB, key0 + 32 * (j + NB - 1))
+            block(kr[j % NB], vr[j % NB]);
+        }
+    }
+#undef FA_LOAD
     lrun = lrun + __shfl_xor(lrun, 32, 64);                 // the two halves hold disjoint keys of the same query
     if constexpr (KS > 1) {
         // the waves' partial results meet in LDS: (m, l, O) of waves 1 .. KS-1, merged by wave 0
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
             const float * c = comb + (size_t) (ww - 1) * 34 * 64 + lane;
             const float m2 = c[0], l2 = c[64];
             const float mnew = fmaxf(mrun, m2);
-            const float a1 = __builtin_amdgcn_exp2f((mrun - mnew) * L2E), a2 = __builtin_amdgcn_exp2f((m2 - mnew) * L2E);
+            const float a1 = __builtin_amdgcn_exp2f(mrun - mnew), a2 = __builtin_amdgcn_exp2f(m2 - mnew);
             lrun = lrun * a1 + l2 * a2;
             #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -313,15 +352,17 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
 void launch_attn_flash(hipStream_t s, const AttnFlashArgs & a) {
     if (a.S <= 0 || (a.S & 127) || a.Z < 1 || (a.E & 7) || (a.ld_att & 3)) kernel_fail("bark-hip: flash attention takes whole sequences of a multiple of 128 keys");
     static const int ks = getenv("BARK_HIP_FLASH_KS") ? atoi(getenv("BARK_HIP_FLASH_KS")) : 2;      // waves per (head, 32-query) tile: A/B on the device
-    const dim3 grid(a.S / 32, a.H, a.Z);
-    if (ks >= 4)      hipLaunchKernelGGL((attn_flash_f16_kernel<4>), grid, dim3(256), 0, s, a);
-    else if (ks == 2) hipLaunchKernelGGL((attn_flash_f16_kernel<2>), grid, dim3(128), 0, s, a);
-    else              hipLaunchKernelGGL((attn_flash_f16_kernel<1>), grid, dim3(64), 0, s, a);
+    static const int nb = getenv("BARK_HIP_FLASH_NB") ? atoi(getenv("BARK_HIP_FLASH_NB")) : 3;      // register sets of the key-block ring
+    const dim3 grid(a.S / 32 * a.H * a.Z);
+    if (ks >= 4)      { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<4, 2>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<4, 3>), grid, dim3(256), 0, s, a); }
+    else if (ks == 2) { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<2, 2>), grid, dim3(128), 0, s, a); else if (nb == 3) hipLaunchKernelGGL((attn_flash_f16_kernel<2, 3>), grid, dim3(128), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<2, 4>), grid, dim3(128), 0, s, a); }
+    else              { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<1, 2>), grid, dim3(64), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<1, 4>), grid, dim3(64), 0, s, a); }
 }
 
 void init_fast_attributes() {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * (128 + 128) * FT_LDK * (int) sizeof(half_t));
+    const int lds = 2 * (128 + 128) * FT_LDK * (int) sizeof(half_t);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace barkhip

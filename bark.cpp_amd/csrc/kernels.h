@@ -100,6 +100,8 @@ struct LinArgs {
     // EPI_QKV16 (fast route, fine model): q (x 0.125) and k as f16 rows [N][E], v transposed [N / seq][E][seq] with permuted keys - the
     // operands of attn_flash_f16_kernel; N is a whole number of sequences of `seq` rows
     half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr; int seq = 0;
+    // EPI_QKV with seq > 0 (N > 1, not batched): the rows are N / seq independent sequences; row n is position pos0 + n % seq of sequence
+    // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
@@ -118,8 +120,9 @@ struct EmbedArgs {
 };
 void launch_embed_causal(hipStream_t s, const EmbedArgs & a);
 // fine: x[i] = sum_{c<=nn} wte_c[tok[c][i]] + wpe[i]                   (bark.cpp:1450-1472)
+// n_rows rows = n_rows / 1024 windows back to back (row i sits at position i % 1024); tokens [8][plane], plane >= n_rows
 void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const QMat * wte_q, const float * wpe, int E, int n_in,
-                       const int32_t * tokens_8x1024, int nn, float * x);
+                       const int32_t * tokens, int nn, float * x, int n_rows = 1024, int plane = 1024);
 
 void launch_ln_stats(hipStream_t s, const float * x, int N, int E, float * stats);
 // q8 quantisation of N <= 1024 f32 rows of length K (LayerNorm first when ln_g != nullptr)
@@ -147,6 +150,9 @@ struct AttnPrefillArgs {
     int H = 0, P = 0, N = 0, n_past = 0; int causal = 1;
     half_t * att = nullptr; int ld_att = 0;
     float * att32 = nullptr;              // q4_0 path: attention output kept in f32 (same leading dimension)
+    // Z > 1 (fine windows of several utterances in one launch, grid.z): sequence z owns rows [z N, (z + 1) N) of q / att and the cache at
+    // kc / vc + z kv_seq_stride
+    int Z = 1; size_t kv_seq_stride = 0;
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 // Tolerance route of the fine model's attention (non-causal, whole sequences): flash-style on the f16 matrix cores, operands from EPI_QKV16
@@ -192,6 +198,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 //   4  decode attention without the QKV kernel's partial scores (attn_fused_kernel instead of attn_ps_kernel)
 //   8  every coarse window re-evaluated from its first row (no prefix reuse), as the reference does
 int crosscheck_mask();
+int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();
 // internal: per-file pieces of the above and the weight-type specific back ends of launch_linear
 void init_attention_attributes();

@@ -27,6 +27,13 @@ int crosscheck_mask() {
     return mask;
 }
 
+int xcd_panel_width(int n_tiles, int ncol) {
+    // one XCD works on n_tiles / 8 consecutive tiles: a near-square block of them shares the fewest operand slices
+    int pw = 1;
+    while (pw * pw < (n_tiles + 7) / 8) pw++;
+    return std::max(1, std::min(pw, ncol));
+}
+
 void kernel_fail(const char * fmt, ...) {
     char buf[256];
     va_list ap;
@@ -408,16 +415,18 @@ DEVINL float half_of(const uint4 & u, int e) {                 // element e (com
     return (float) __builtin_bit_cast(half_t, (unsigned short) ((e & 1) ? (word >> 16) : word));
 }
 DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
-__global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
+__global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int ncol, const int nrow, const int pw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.y * GEMM_TN, m0 = blockIdx.x * GEMM_TM;
+    int trow, tcol;
+    panel_tile(xcd_rank(blockIdx.x, ncol * nrow), nrow, ncol, pw, trow, tcol);      // XCD-aware tile order (device_utils.h)
+    const int n0 = trow * GEMM_TN, m0 = tcol * GEMM_TM;
     const int K = a.K, nblk = K >> 7;
-    int nrow[2], mrow[2];
+    int nrw[2], mrow[2];
     #pragma unroll
     for (int t = 0; t < 2; t++) {
-        nrow[t] = min(n0 + t * 32 + l31, a.N - 1);
+        nrw[t] = min(n0 + t * 32 + l31, a.N - 1);
         mrow[t] = min(m0 + t * 32 + l31, a.M - 1);
     }
     floatx16 acc[2][2][2];
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
         const int koff = (((B) * 16 + 2 * w + s) << 3);                                                  \
         _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                  \
-            XA[s][t] = ld_half8(a.x_f16 + (size_t) nrow[t] * K + koff);                                  \
+            XA[s][t] = ld_half8(a.x_f16 + (size_t) nrw[t] * K + koff);                                  \
             WB[s][t] = ld_half8(a.W + (size_t) mrow[t] * K + koff);                                      \
         }                                                                                                \
     }
@@ -514,11 +523,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a) {
                 const int E = a.E;
                 float4 o = {v[0], v[1], v[2], v[3]};
                 if (m < E) { *reinterpret_cast<float4 *>(a.q + (size_t) n * E + m) = o; break; }
-                const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + n;
+                const int zq = a.seq ? n / a.seq : 0;                   // several sequences back to back (fine windows of a batch)
+                const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
+                const size_t zoff = (size_t) zq * a.kv_slot_stride;
                 const int m2 = m < 2 * E ? m - E : m - 2 * E;
                 const int h = m2 >> 6, d = m2 & 63;                     // d is a multiple of 4: one d-quad of the K layout
-                if (m < 2 * E) *reinterpret_cast<float4 *>(a.kc + kc_index(h, d, pos, a.P)) = o;
-                else         { *reinterpret_cast<float4 *>(a.vc + vc_index(h, d, pos, a.P)) = o; if (a.vt) *reinterpret_cast<float4 *>(a.vt + kc_index(h, d, pos, a.P)) = o; }
+                if (m < 2 * E) *reinterpret_cast<float4 *>(a.kc + zoff + kc_index(h, d, pos, a.P)) = o;
+                else         { *reinterpret_cast<float4 *>(a.vc + zoff + vc_index(h, d, pos, a.P)) = o; if (a.vt) *reinterpret_cast<float4 *>(a.vt + zoff + kc_index(h, d, pos, a.P)) = o; }
                 break;
             }
             case EPI_RESID: {                                           // cur + inpL (bark.cpp:1352,1388)
@@ -684,8 +695,8 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     }
     if (a.fast == 1) { launch_linear_fast(s, a); return; }
     if (a.epi == EPI_QKV16) kernel_fail("bark-hip: the f16 QKV epilogue exists on the tolerance route only");
-    dim3 grid((a.M + GEMM_TM - 1) / GEMM_TM, (a.N + GEMM_TN - 1) / GEMM_TN), block(512);
-    hipLaunchKernelGGL(gemm_kernel, grid, block, 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a);
+    const int ncol = (a.M + GEMM_TM - 1) / GEMM_TM, nrow = (a.N + GEMM_TN - 1) / GEMM_TN;
+    hipLaunchKernelGGL(gemm_kernel, dim3(ncol * nrow), dim3(512), 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
 }
 
 void init_kernel_attributes() {

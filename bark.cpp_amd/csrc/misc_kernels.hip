@@ -34,15 +34,15 @@ void launch_embed_causal(hipStream_t s, const EmbedArgs & a) {
     hipLaunchKernelGGL(embed_causal_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
 }
 
-struct FineEmbedArgs { const half_t * wte[8]; QMat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; };
+struct FineEmbedArgs { const half_t * wte[8]; QMat wte_q[8]; const float * wpe; int E, n_in; const int32_t * tok; int nn; float * x; int plane; };
 __global__ void embed_fine_kernel(const FineEmbedArgs a) {
     const int i = blockIdx.x;
     float * out = a.x + (size_t) i * a.E;
-    const float * pe = a.wpe + (size_t) i * a.E;
+    const float * pe = a.wpe + (size_t) (i & 1023) * a.E;
     for (int e = threadIdx.x; e < a.E; e += blockDim.x) {
         float v = 0.0f;                                     // ggml_set_zero(tok_emb), bark.cpp:1936-1937
         for (int cb = 0; cb <= a.nn; cb++) {
-            int id = a.tok[cb * 1024 + i];
+            int id = a.tok[(size_t) cb * a.plane + i];
             id = min(max(id, 0), a.n_in - 1);
             v = v + wte_elem(a.wte[cb], a.wte_q[cb], a.E, id, e);
         }
@@ -50,10 +50,10 @@ __global__ void embed_fine_kernel(const FineEmbedArgs a) {
     }
 }
 void launch_embed_fine(hipStream_t s, const half_t * const wte[8], const QMat * wte_q, const float * wpe, int E, int n_in,
-                       const int32_t * tokens_8x1024, int nn, float * x) {
+                       const int32_t * tokens, int nn, float * x, int n_rows, int plane) {
     FineEmbedArgs a; for (int i = 0; i < 8; i++) { a.wte[i] = wte[i]; a.wte_q[i] = wte_q[i]; }
-    a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens_8x1024; a.nn = nn; a.x = x;
-    hipLaunchKernelGGL(embed_fine_kernel, dim3(1024), dim3(256), 0, s, a);
+    a.wpe = wpe; a.E = E; a.n_in = n_in; a.tok = tokens; a.nn = nn; a.x = x; a.plane = plane;
+    hipLaunchKernelGGL(embed_fine_kernel, dim3(n_rows), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

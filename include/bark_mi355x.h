@@ -61,6 +61,10 @@ BARK_API int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * toke
 BARK_API int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, int capacity, float * eos_trace);
 BARK_API int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2, int capacity_rows);
 BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8, int capacity_rows);
+/* The fine stage of n utterances with their windows side by side in every forward pass (what bark_hip_generate_batch runs; greedy or
+ * device multinomial drawn from the context's generator utterance by utterance; f16 model files).  coarse: the utterances' [T_i][2]
+ * arrays back to back, out: their [T_i][8] results back to back (capacity_rows >= sum T_i).  Returns sum T_i or -1. */
+BARK_API int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat, const int * T, int n, int32_t * out_concat, int capacity_rows);
 
 /* EnCodec decode: codes [n_q][T] (time contiguous) -> pcm (capacity floats; 320 * T are produced). Returns samples or -1. */
 BARK_API int bark_hip_codec_decode(struct bark_context * bctx, const int32_t * codes, int n_q, int T, float * pcm, int capacity);
