@@ -263,11 +263,17 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
     // XCD-aware: the query tiles of one (sequence, head) hold consecutive ranks, so its K and V (512 KB at 1024 keys) stay in one L2
     const int QT = (a.N + 31) >> 5, rank = xcd_rank(blockIdx.x, QT * a.H * max(1, a.Z));
     const int h = (rank / QT) % a.H, i0 = (rank % QT) * 32;
-    if (a.Z > 1) {                                                      // sequence z: its own rows of q / att and its own cache
+    if (a.Z > 1 || a.seqtab) {                                          // sequence z: its own rows of q / att and its own cache
         const size_t z = rank / (QT * a.H);
-        a.q += z * (size_t) a.N * a.ldq; a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride;
+        a.q += z * (size_t) a.N * a.ldq;
         if (a.att) a.att += z * (size_t) a.N * a.ld_att;
         if (a.att32) a.att32 += z * (size_t) a.N * a.ld_att;
+        if (a.seqtab) {                                                 // ragged: its own length, its slot's cache, its own start position
+            const SeqTab t = a.seqtab[z];
+            a.kc += (size_t) t.slot * a.kv_seq_stride; a.vc += (size_t) t.slot * a.kv_seq_stride;
+            a.N = t.len; a.n_past = t.pos0;
+            if (i0 >= a.N) return;                                      // a tile of padding rows (the whole workgroup leaves)
+        } else { a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride; }
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;

@@ -260,8 +260,13 @@ DEVINL void linear_epilogue(const LinArgs & a, int n, int m, float dot, int row_
             const int E = a.E;
             if (m < E) { a.q[(size_t) n * E + m] = v; break; }
             const int zq = a.seq ? n / a.seq : 0;
-            const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
-            const size_t zoff = (size_t) zq * a.kv_slot_stride;
+            int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
+            size_t zoff = (size_t) zq * a.kv_slot_stride;
+            if (a.seqtab) {
+                const SeqTab t = a.seqtab[zq];
+                if (n - zq * a.seq >= t.len) break;
+                pos = t.pos0 + (n - zq * a.seq); zoff = (size_t) t.slot * a.kv_slot_stride;
+            }
             const int mm = m < 2 * E ? m - E : m - 2 * E;
             const int h = mm >> 6, d = mm & 63;
             if (m < 2 * E) a.kc[zoff + kc_index(h, d, pos, a.P)] = v; else { a.vc[zoff + vc_index(h, d, pos, a.P)] = v; if (a.vt) a.vt[zoff + kc_index(h, d, pos, a.P)] = v; }

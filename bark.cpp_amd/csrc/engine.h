@@ -121,6 +121,9 @@ struct bark_context {
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
         hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
+        // window prompts of all slots in ONE pass (batch_prefill_many): row scratch for cap * P rows, the prompts' ids, the sequence table
+        float * pf_x = nullptr, * pf_q = nullptr; barkhip::half_t * pf_xn = nullptr, * pf_att = nullptr, * pf_h = nullptr;
+        int32_t * pf_tokens = nullptr; barkhip::SeqTab * pf_tab = nullptr;
     } batch;
     // fine windows of several utterances in one forward pass (engine_fine_many): rows = cap * 1024
     struct FineBatch {

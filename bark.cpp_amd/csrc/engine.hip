@@ -41,7 +41,8 @@ RowBufs own_rows(bark_context * c) {
 }
 
 // N > 1 rows through all layers (bark.cpp:1261-1389 causal, :1474-1562 fine); x holds the embeddings.
-void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0, const RowBufs * rbp, int seq, size_t kv_seq_stride) {
+void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase, float * vbase, int pos0, const RowBufs * rbp, int seq, size_t kv_seq_stride,
+                     const SeqTab * seqtab) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
     const RowBufs own = own_rows(c);
@@ -63,7 +64,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = N; a.x_f16 = rb.xn; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.bias = L.attn_b; a.epi = EPI_QKV;
         a.q = rb.q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.E = E; a.P = P; a.pos0 = pos0;
         if (!kbase && !vbase) a.vt = detail::layer_vt(m, l);      // the context's own cache keeps the K-layout copy of V too
-        a.seq = seq; a.kv_slot_stride = kv_seq_stride;
+        a.seq = seq; a.kv_slot_stride = kv_seq_stride; a.seqtab = seqtab;
         a.fast = fast;
         if (flash) {
             // tolerance route of the fine model: q / k / v leave the product as the f16 operands of the flash attention (no KV cache)
@@ -77,7 +78,7 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
             AttnPrefillArgs at;
             at.q = rb.q; at.ldq = E; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.N = seq > 0 ? seq : N; at.n_past = pos0;
             at.causal = causal ? 1 : 0; at.att = rb.att; at.ld_att = E; at.att32 = m.q4 ? c->att32 : nullptr;
-            at.Z = Z; at.kv_seq_stride = kv_seq_stride;
+            at.Z = Z; at.kv_seq_stride = kv_seq_stride; at.seqtab = seqtab;
             launch_attn_prefill(s, at);
         }
         if (m.q4 && !m.w32) launch_q8_rows(s, c->att32, N, E, nullptr, nullptr, c->xq);

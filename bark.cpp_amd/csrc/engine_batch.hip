@@ -207,6 +207,73 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     launch_sample_greedy(c->stream, sa);
 }
 
+
+// The prompts of several slots through the model in ONE pass: sequence z = slot slots[z] evaluates ids[z][L[z] ..] behind the L[z] rows its
+// cache already holds.  Every activation holds the sequences back to back, `seq` rows each (the longest, rounded up; shorter ones are
+// padded - padding rows store nothing); the products see all rows at once (thousands instead of a few hundred: whole rounds of tiles),
+// the causal attention runs per sequence against the slot's own cache.  Row for row the arithmetic of batch_prefill_and_sample.
+void batch_prefill_many(bark_context * c, const StageCfg & s, const std::vector<int> & slots, const std::vector<const std::vector<int32_t> *> & ids,
+                        const std::vector<int> & Ls, bool merge, const std::vector<int> & step0) {
+    GptModel & m = c->gpt[s.which];
+    bark_context::Batch & bb = c->batch;
+    const int Z = (int) slots.size(), E = m.hp.n_embd, P = c->P;
+    if (Z == 0) return;
+    if (!bb.pf_x) {
+        const size_t R = (size_t) bb.cap * P, ME = (size_t) c->max_E;
+        bb.pf_x = dev_alloc<float>(c, R * ME); bb.pf_q = dev_alloc<float>(c, R * ME);
+        bb.pf_xn = dev_alloc<half_t>(c, R * ME); bb.pf_att = dev_alloc<half_t>(c, R * ME); bb.pf_h = dev_alloc<half_t>(c, R * ME * 4);
+        bb.pf_tokens = dev_alloc<int32_t>(c, R); bb.pf_tab = dev_alloc<SeqTab>(c, (size_t) bb.cap);
+    }
+    std::vector<SeqTab> tab((size_t) Z);
+    int max_rows = 0, tok_stride = 0;
+    for (int z = 0; z < Z; z++) {
+        check_ids(ids[(size_t) z]->data(), ids[(size_t) z]->size(), m.hp.n_in_vocab, "batch prefill");
+        const int n_tok = (int) ids[(size_t) z]->size() - Ls[(size_t) z], rows = merge ? n_tok - 256 : n_tok;
+        if (rows < 1 || Ls[(size_t) z] + rows > P || (merge && Ls[(size_t) z])) throw std::runtime_error("batch prefill: bad prompt length");
+        tab[(size_t) z] = SeqTab{slots[(size_t) z], Ls[(size_t) z], rows, 0};
+        max_rows = std::max(max_rows, rows); tok_stride = std::max(tok_stride, n_tok);
+    }
+    const int seq = std::min(P, (max_rows + 63) & ~63);
+    if ((size_t) Z * (size_t) std::max(seq, tok_stride) > (size_t) bb.cap * P) throw std::runtime_error("batch prefill: scratch too small");
+    std::vector<int32_t> tok((size_t) Z * tok_stride, 0);
+    std::vector<StepState> sts((size_t) Z, fresh_state());
+    for (int z = 0; z < Z; z++) {
+        std::copy(ids[(size_t) z]->begin() + Ls[(size_t) z], ids[(size_t) z]->end(), tok.begin() + (size_t) z * tok_stride);
+        sts[(size_t) z].step = step0[(size_t) z]; sts[(size_t) z].n_past = Ls[(size_t) z];
+    }
+    hipStream_t st = c->stream;
+    HIP_OK(hipMemcpyAsync(bb.pf_tokens, tok.data(), tok.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.pf_tab, tab.data(), tab.size() * sizeof(SeqTab), hipMemcpyHostToDevice, st));
+    for (int z = 0; z < Z; z++) HIP_OK(hipMemcpyAsync(bb.state + slots[(size_t) z], &sts[(size_t) z], sizeof(StepState), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(bb.pf_x, 0, (size_t) Z * seq * E * sizeof(float), st));          // padding rows: zeros (their results are never read)
+    for (int z = 0; z < Z; z++) {
+        EmbedArgs e;
+        e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = E; e.n_in = m.hp.n_in_vocab; e.P = P; e.tokens = bb.pf_tokens + (size_t) z * tok_stride;
+        e.n_rows = tab[(size_t) z].len; e.merge = merge ? 1 : 0; e.pos0 = Ls[(size_t) z]; e.x = bb.pf_x + (size_t) z * seq * E;
+        launch_embed_causal(st, e);
+    }
+    RowBufs rb; rb.x = bb.pf_x; rb.q = bb.pf_q; rb.xn = bb.pf_xn; rb.att = bb.pf_att; rb.hbuf = bb.pf_h; rb.q16 = rb.k16 = rb.vt16 = nullptr;
+    rb.logits = nullptr; rb.tokens = nullptr; rb.plane = 0;
+    run_layers_rows(c, m, Z * seq, true, bb.kc[s.which], bb.vc[s.which], 0, &rb, seq, bb.slot_stride[s.which], bb.pf_tab);
+    for (int z = 0; z < Z; z++) {
+        const int slot = slots[(size_t) z], N = tab[(size_t) z].len;
+        LinArgs h;
+        h.W = m.lm_head[0] + (size_t) s.lm_row0 * E; h.M = s.lm_rows; h.K = E; h.N = 1;
+        h.x_f32 = bb.pf_x + ((size_t) z * seq + (size_t) (N - 1)) * E; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
+        h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
+        launch_linear(st, h);
+        SampleArgs sa;
+        { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
+        sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
+        sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
+        sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
+        sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
+        sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x + (size_t) slot * E;
+        launch_sample_greedy(st, sa);
+    }
+    HIP_OK(hipStreamSynchronize(st));                           // tok / tab / sts are stack objects
+}
+
 }  // namespace
 
 // One lock-step decode kernel for B slots, launched back to back (hipGraph of 48 nodes) while rotating through the layers' weights.
@@ -312,6 +379,8 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     c->stats = bark_hip_stats{};
     c->stats.t_load_us = t_load;
     const int B = n;
+    // the prompts of all slots in one pass (batch_prefill_many) instead of slot by slot; BARK_HIP_CROSSCHECK bit 4 (16) keeps the slot-by-slot route
+    const bool prefill_many = !(crosscheck_mask() & 16);
     ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
     bark_context::Batch & bb = c->batch;
     if (B > bb.cap) throw std::runtime_error("generate_batch: batch larger than the capacity fixed by the first call");
@@ -327,7 +396,14 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         pp.semantic_pad_token = p.semantic_pad_token; pp.semantic_infer_token = p.semantic_infer_token;
         if (n_steps > 0) {
             if (sampled) for (int b = 0; b < B; b++) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps);
-            for (int b = 0; b < B; b++) batch_prefill_and_sample(c, s, b, build_semantic_prompt(c->vocab, pp, texts[b], true), true, 0);
+            if (prefill_many && !m.q4 && !m.w32) {
+                std::vector<std::vector<int32_t>> prompts((size_t) B);
+                std::vector<const std::vector<int32_t> *> pp_ids; std::vector<int> sl, l0((size_t) B, 0), s0((size_t) B, 0);
+                for (int b = 0; b < B; b++) { prompts[(size_t) b] = build_semantic_prompt(c->vocab, pp, texts[b], true); pp_ids.push_back(&prompts[(size_t) b]); sl.push_back(b); }
+                batch_prefill_many(c, s, sl, pp_ids, l0, true, s0);
+            } else {
+                for (int b = 0; b < B; b++) batch_prefill_and_sample(c, s, b, build_semantic_prompt(c->vocab, pp, texts[b], true), true, 0);
+            }
             int issued = 1;
             std::vector<StepState> st;
             while (true) {
@@ -406,6 +482,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 max_here = std::max(max_here, here[(size_t) b]);
             }
             int lock_steps = max_here - 1;                               // batched steps after every live slot has its first sample
+            std::vector<int> pf_slots, pf_L, pf_step; std::vector<const std::vector<int32_t> *> pf_ids;
             for (int b = 0; b < B; b++) {
                 if (!here[(size_t) b]) {                                 // finished (or empty) slot: park it at position 0
                     StepState idle = fresh_state(); idle.cur_token = 0;
@@ -422,10 +499,13 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                     set_slot_state(c, b, st1);
                     embed_slot(c, s, b);
                     if (!all_single) enqueue_batch_step(c, s, 1, slot_view(c, s, b));      // mixed window: this slot alone, eagerly
+                } else if (prefill_many && !m.q4 && !m.w32) {
+                    pf_slots.push_back(b); pf_ids.push_back(&ins[(size_t) b]); pf_L.push_back(L); pf_step.push_back(step_idx[(size_t) b]);
                 } else {
                     batch_prefill_and_sample(c, s, b, in, false, step_idx[(size_t) b], L);
                 }
             }
+            if (!pf_slots.empty()) batch_prefill_many(c, s, pf_slots, pf_ids, pf_L, false, pf_step);
             if (all_single && max_here > 0) lock_steps = max_here;       // the first sample of the window is a lock-step too
             for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
             const std::vector<StepState> st = get_slot_states(c, B);

@@ -57,7 +57,7 @@ struct RowBufs { float * x, * q; half_t * xn, * att, * hbuf, * q16, * k16, * vt1
 RowBufs own_rows(bark_context * c);
 // seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
-                     const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0);
+                     const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0, const SeqTab * seqtab = nullptr);
 void run_layers_decode(bark_context * c, GptModel & m);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);

@@ -63,8 +63,13 @@ DEVINL void fast_tile_epilogue(const LinArgs & a, const floatx16 & acc, int tile
                 const int n = nb + (r & 3) + 8 * (r >> 2);
                 if (n >= a.N) continue;
                 const int zq = a.seq ? n / a.seq : 0;
-                const int pos = a.pos0 + n_past + (n - zq * a.seq);
-                const size_t zoff = (size_t) zq * a.kv_slot_stride;
+                int pos = a.pos0 + n_past + (n - zq * a.seq);
+                size_t zoff = (size_t) zq * a.kv_slot_stride;
+                if (a.seqtab) {
+                    const SeqTab t = a.seqtab[zq];
+                    if (n - zq * a.seq >= t.len) continue;
+                    pos = t.pos0 + (n - zq * a.seq); zoff = (size_t) t.slot * a.kv_slot_stride;
+                }
                 if (m < E) a.q[(size_t) n * E + m] = v[r];
                 else if (m < 2 * E) a.kc[zoff + kc_index(h, d, pos, a.P)] = v[r];
                 else { a.vc[zoff + vc_index(h, d, pos, a.P)] = v[r]; if (a.vt) a.vt[zoff + kc_index(h, d, pos, a.P)] = v[r]; }

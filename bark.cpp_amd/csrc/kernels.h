@@ -52,6 +52,10 @@ struct TraceSink { unsigned long long * rec = nullptr; unsigned * pos = nullptr;
 #define BARK_TRACE_FIELD
 #endif
 
+// One sequence of a multi-sequence causal prefill (the window prompts of a lock-step batch in ONE pass): its rows sit at [z seq, z seq + len)
+// of every activation, continue its cache (utterance slot `slot`) at position pos0; rows len .. seq - 1 are padding
+struct SeqTab { int slot, pos0, len, pad; };
+
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_QKV16 = 4 };      // EPI_QKV16: tolerance route only (fast_kernels.hip)
 
 // One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
@@ -101,7 +105,9 @@ struct LinArgs {
     // operands of attn_flash_f16_kernel; N is a whole number of sequences of `seq` rows
     half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr; int seq = 0;
     // EPI_QKV with seq > 0 (N > 1, not batched): the rows are N / seq independent sequences; row n is position pos0 + n % seq of sequence
-    // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's
+    // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's - or, with seqtab, position seqtab[z].pos0 + n % seq of the
+    // cache of slot seqtab[z].slot (rows at or beyond seqtab[z].len are padding and store nothing)
+    const SeqTab * seqtab = nullptr;
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
@@ -153,6 +159,8 @@ struct AttnPrefillArgs {
     // Z > 1 (fine windows of several utterances in one launch, grid.z): sequence z owns rows [z N, (z + 1) N) of q / att and the cache at
     // kc / vc + z kv_seq_stride
     int Z = 1; size_t kv_seq_stride = 0;
+    const SeqTab * seqtab = nullptr;      // ragged causal sequences: N rows per sequence in q / att, sequence z has seqtab[z].len of them, continues
+                                          // the cache of slot seqtab[z].slot (kc / vc + slot * kv_seq_stride) at seqtab[z].pos0
 };
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a);
 // Tolerance route of the fine model's attention (non-causal, whole sequences): flash-style on the f16 matrix cores, operands from EPI_QKV16
@@ -197,6 +205,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 //   2  lock-step decode products on the VALU GEMV per pair of slots instead of gemm_slots16_kernel
 //   4  decode attention without the QKV kernel's partial scores (attn_fused_kernel instead of attn_ps_kernel)
 //   8  every coarse window re-evaluated from its first row (no prefix reuse), as the reference does
+//  16  lock-step batches: the prompts of the slots through the model slot by slot instead of all in one pass (batch_prefill_many)
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();

@@ -523,9 +523,14 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
                 const int E = a.E;
                 float4 o = {v[0], v[1], v[2], v[3]};
                 if (m < E) { *reinterpret_cast<float4 *>(a.q + (size_t) n * E + m) = o; break; }
-                const int zq = a.seq ? n / a.seq : 0;                   // several sequences back to back (fine windows of a batch)
-                const int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
-                const size_t zoff = (size_t) zq * a.kv_slot_stride;
+                const int zq = a.seq ? n / a.seq : 0;                   // several sequences back to back (fine windows / window prompts of a batch)
+                int pos = a.pos0 + (a.st ? a.st->n_past : 0) + (n - zq * a.seq);
+                size_t zoff = (size_t) zq * a.kv_slot_stride;
+                if (a.seqtab) {
+                    const SeqTab t = a.seqtab[zq];
+                    if (n - zq * a.seq >= t.len) break;                 // padding row
+                    pos = t.pos0 + (n - zq * a.seq); zoff = (size_t) t.slot * a.kv_slot_stride;
+                }
                 const int m2 = m < 2 * E ? m - E : m - 2 * E;
                 const int h = m2 >> 6, d = m2 & 63;                     // d is a multiple of 4: one d-quad of the K layout
                 if (m < 2 * E) *reinterpret_cast<float4 *>(a.kc + zoff + kc_index(h, d, pos, a.P)) = o;
