@@ -4,5 +4,5 @@ ctypes mirror of its C API.
 The directory name contains a dot, so import it through `load_package()` of the repo-root helper
 `bark_amd_loader.py`, or put the directory itself on sys.path and `import api`.
 """
-from .api import (BarkContext, BarkContextParams, BarkHipStats, build_library, default_params, library_path,  # noqa: F401
+from .api import (BarkContext, Batcher, BarkContextParams, BarkHipStats, build_library, default_params, library_path,  # noqa: F401
                   load_library)

@@ -69,7 +69,8 @@ EXPORTS = [
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
-    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_describe",
+    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe",
+    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_free",
 ]
 
 
@@ -132,6 +133,17 @@ def load_library() -> C.CDLL:
     lib.bark_hip_time_slots.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.bark_hip_time_fine_pass.restype = C.c_double
     lib.bark_hip_time_fine_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    lib.bark_hip_batcher_create.restype = vp
+    lib.bark_hip_batcher_create.argtypes = [vp, C.c_int, C.c_int]
+    lib.bark_hip_batcher_submit.restype = C.c_int64
+    lib.bark_hip_batcher_submit.argtypes = [vp, C.c_char_p, C.c_uint32]
+    lib.bark_hip_batcher_wait.argtypes = [vp, C.c_int64, fp, C.c_int]
+    lib.bark_hip_batcher_stats.restype = None
+    lib.bark_hip_batcher_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bark_hip_batcher_free.restype = None
+    lib.bark_hip_batcher_free.argtypes = [vp]
+    lib.bark_hip_time_fine_passes.restype = C.c_double
+    lib.bark_hip_time_fine_passes.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_describe.restype = C.c_char_p
     lib.bark_hip_describe.argtypes = [vp]
     _LIB = lib
@@ -389,9 +401,50 @@ class BarkContext:
             raise RuntimeError("bark_hip_time_slots failed")
         return us
 
-    def time_fine_pass(self, iters: int):
+    def time_fine_pass(self, iters: int, n_windows: int = 1):
+        """us per forward pass of the fine model over n_windows windows side by side, flops of that pass"""
         f = C.c_double(0)
-        us = self._lib.bark_hip_time_fine_pass(self._h, iters, C.byref(f))
+        if n_windows > 1:
+            us = self._lib.bark_hip_time_fine_passes(self._h, n_windows, iters, C.byref(f))
+        else:
+            us = self._lib.bark_hip_time_fine_pass(self._h, iters, C.byref(f))
         if us < 0:
             raise RuntimeError("bark_hip_time_fine_pass failed")
         return us, f.value
+
+
+class Batcher:
+    """bark_hip_batcher: thread-safe submit / wait in front of the context's lock-step batches (the context is owned by the batcher's
+    worker thread while it lives)."""
+
+    def __init__(self, ctx: "BarkContext", max_batch: int = 32, max_wait_ms: int = 2):
+        self._lib = ctx._lib
+        self._b = self._lib.bark_hip_batcher_create(ctx._h, max_batch, max_wait_ms)
+        if not self._b:
+            raise RuntimeError("bark_hip_batcher_create failed")
+
+    def submit(self, text: str, seed: int = 0) -> int:
+        t = self._lib.bark_hip_batcher_submit(self._b, text.encode("utf-8"), seed)
+        if t <= 0:
+            raise RuntimeError("bark_hip_batcher_submit failed")
+        return t
+
+    def wait(self, ticket: int) -> np.ndarray:
+        n = self._lib.bark_hip_batcher_wait(self._b, ticket, None, 0)          # probe: -(2 + samples)
+        if n > -2:
+            raise RuntimeError("generation failed")
+        pcm = np.zeros(-n - 2, np.float32)
+        n = self._lib.bark_hip_batcher_wait(self._b, ticket, pcm.ctypes.data, pcm.size)
+        if n < 0:
+            raise RuntimeError("bark_hip_batcher_wait failed")
+        return pcm[:n]
+
+    def stats(self) -> dict:
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._lib.bark_hip_batcher_stats(self._b, C.byref(a), C.byref(b), C.byref(c))
+        return {"n_batches": a.value, "n_requests": b.value, "largest_batch": c.value}
+
+    def free(self):
+        if self._b:
+            self._lib.bark_hip_batcher_free(self._b)
+            self._b = None

@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-c
 # explicit object list: stale objects of renamed / split sources are never linked
 OBJS=()
 pids=()
-for f in kernels.hip fast_kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_codec.hip engine_batch.hip engine_timing.hip api.hip; do
+for f in kernels.hip fast_kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_codec.hip engine_batch.hip engine_timing.hip api.hip batcher.hip; do
     o="$OUT/obj/${f%.*}.o"
     OBJS+=("$o")
     if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h' -newer "$o" 2>/dev/null | head -1)" ]; then

@@ -9,7 +9,7 @@ mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -Wno-pass-failed -I$HERE/../include -I$SRC $*"
 pids=()
-for f in kernels.hip fast_kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_codec.hip engine_batch.hip engine_timing.hip api.hip; do
+for f in kernels.hip fast_kernels.hip quant_kernels.hip attention_kernels.hip misc_kernels.hip codec_kernels.hip engine_load.hip engine.hip engine_codec.hip engine_batch.hip engine_timing.hip api.hip batcher.hip; do
     $HIPCC $FLAGS -c "$SRC/$f" -o "$OBJ/${f%.*}.o" & pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

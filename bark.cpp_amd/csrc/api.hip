@@ -292,6 +292,11 @@ double bark_hip_time_gemv(struct bark_context * bctx, int which, int op, int ite
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_gemv", -1.0, [&] { return engine_time_gemv(bctx, which, op, iters, bytes_per_launch); });
 }
+double bark_hip_time_fine_passes(struct bark_context * bctx, int n_windows, int iters, double * flops_per_pass) {
+    if (!bctx) return -1.0;
+    return guarded("bark_hip_time_fine_passes", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass, n_windows); });
+}
+
 double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass) {
     if (!bctx) return -1.0;
     return guarded("bark_hip_time_fine_pass", -1.0, [&] { return engine_time_fine_pass(bctx, iters, flops_per_pass); });

@@ -316,18 +316,28 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
         // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs
         float4 ka[16], kb[16];
         int jt = w * 32;
-        if (jt < jend) load_k(ka, jt);
-        for (; jt < jend; jt += 512) {
-            const bool more = jt + 256 < jend;
-            if (more) load_k(kb, jt + 256);
-            __builtin_amdgcn_sched_barrier(0);
-            score_tile(ka, jt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                if (jt + 512 < jend) load_k(ka, jt + 512);
+        if (jt < jend) {
+            load_k(ka, jt);
+            // steady state without a branch between a request and its use (hipcc's s_waitcnt is per program point: a conditional request
+            // makes the next consumer wait for every outstanding load), the last one or two tiles of the wave behind it
+            for (; jt + 512 < jend; jt += 512) {
+                load_k(kb, jt + 256);
+                __builtin_amdgcn_sched_barrier(0);
+                score_tile(ka, jt);
+                __builtin_amdgcn_sched_barrier(0);
+                load_k(ka, jt + 512);
                 __builtin_amdgcn_sched_barrier(0);
                 score_tile(kb, jt + 256);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (jt + 256 < jend) {
+                load_k(kb, jt + 256);
+                __builtin_amdgcn_sched_barrier(0);
+                score_tile(ka, jt);
+                __builtin_amdgcn_sched_barrier(0);
+                score_tile(kb, jt + 256);
+            } else {
+                score_tile(ka, jt);
             }
         }
     }
@@ -387,18 +397,27 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
         }                                                                                                \
     }
     const int jstop = jend;
-    if (jstop > 0) { ATT_LOAD_BATCH(va, ea, 0) }
-    for (int jb = 0; jb < jstop; jb += 512) {
-        const bool more = jb + 256 < jstop;
-        if (more) { ATT_LOAD_BATCH(vb, eb, jb + 256) }
-        __builtin_amdgcn_sched_barrier(0);
-        ATT_MFMA_BATCH(va, ea, jb)
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            if (jb + 512 < jstop) { ATT_LOAD_BATCH(va, ea, jb + 512) }
+    if (jstop > 0) {
+        ATT_LOAD_BATCH(va, ea, 0)
+        int jb = 0;
+        for (; jb + 512 < jstop; jb += 512) {                 // branch-free steady state, as in the score phase
+            ATT_LOAD_BATCH(vb, eb, jb + 256)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MFMA_BATCH(va, ea, jb)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_LOAD_BATCH(va, ea, jb + 512)
             __builtin_amdgcn_sched_barrier(0);
             ATT_MFMA_BATCH(vb, eb, jb + 256)
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (jb + 256 < jstop) {
+            ATT_LOAD_BATCH(vb, eb, jb + 256)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MFMA_BATCH(va, ea, jb)
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_MFMA_BATCH(vb, eb, jb + 256)
+        } else {
+            ATT_MFMA_BATCH(va, ea, jb)
         }
     }
 #undef ATT_LOAD_BATCH

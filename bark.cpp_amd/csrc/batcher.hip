@@ -1,0 +1,125 @@
+// batcher.hip - a native request collector in front of bark_hip_generate_batch.
+//
+// The reference's HTTP example serialises its requests on one mutex around bark_generate_audio (examples/server/server.cpp:76-94,
+// 128-163): one utterance in flight, every decode step streams the weights for a single sequence.  This component is what a server puts
+// in that place on this engine: any number of host threads submit texts; ONE worker thread owns the context, collects what is pending
+// (up to max_batch requests, waiting at most max_wait_ms for a batch to fill once the first request is there) and runs them as one
+// lock-step batch.  Per-request results are those of a fresh context seeded with the request's seed (engine_generate_batch's contract),
+// whatever batch a request happened to travel in.  Plain C++ threads; nothing here touches the device.
+#include "engine_internal.h"
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+using namespace barkhip;
+
+struct bark_hip_batcher {
+    struct Req { std::string text; uint32_t seed = 0; std::vector<float> pcm; bool done = false, ok = false; };
+    bark_context * ctx = nullptr;
+    int max_batch = 32;
+    std::chrono::microseconds max_wait{2000};
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::pair<int64_t, std::shared_ptr<Req>>> queue;
+    std::unordered_map<int64_t, std::shared_ptr<Req>> tickets;
+    int64_t next_ticket = 1;
+    bool stop = false;
+    int n_batches = 0, n_requests = 0, largest = 0;
+    std::thread worker;
+
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        while (true) {
+            cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+            if (stop && queue.empty()) return;
+            // the first request is there: give the batch max_wait to fill (a full batch leaves at once)
+            const auto deadline = std::chrono::steady_clock::now() + max_wait;
+            cv_work.wait_until(lk, deadline, [&] { return stop || (int) queue.size() >= max_batch; });
+            std::vector<std::shared_ptr<Req>> batch;
+            while (!queue.empty() && (int) batch.size() < max_batch) { batch.push_back(queue.front().second); queue.pop_front(); }
+            lk.unlock();
+            std::vector<const char *> texts; std::vector<uint32_t> seeds;
+            for (auto & r : batch) { texts.push_back(r->text.c_str()); seeds.push_back(r->seed); }
+            bool failed = false;
+            try { engine_generate_batch(ctx, texts.data(), (int) texts.size(), seeds.data()); }
+            catch (const std::exception & e) { fprintf(stderr, "bark_hip_batcher: batch failed: %s\n", e.what()); failed = true; }
+            lk.lock();
+            for (size_t i = 0; i < batch.size(); i++) {
+                Req & r = *batch[i];
+                if (!failed && i < ctx->batch_results.size() && ctx->batch_results[i].ok) { r.pcm = ctx->batch_results[i].audio; r.ok = true; }
+                r.done = true;
+            }
+            n_batches++; n_requests += (int) batch.size(); largest = std::max(largest, (int) batch.size());
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context * bctx, int max_batch, int max_wait_ms) {
+    if (!bctx || max_batch < 1 || max_batch > 32 || max_wait_ms < 0) return nullptr;
+    try {
+        engine_reserve_batch(bctx, max_batch);                 // the context's batch capacity is fixed by its first use
+        std::unique_ptr<bark_hip_batcher> b(new bark_hip_batcher());
+        b->ctx = bctx; b->max_batch = max_batch; b->max_wait = std::chrono::microseconds((int64_t) max_wait_ms * 1000);
+        bark_hip_batcher * raw = b.get();
+        b->worker = std::thread([raw] { raw->run(); });
+        return b.release();
+    } catch (const std::exception & e) {
+        fprintf(stderr, "bark_hip_batcher_create: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed) {
+    if (!b || !text) return -1;
+    auto r = std::make_shared<bark_hip_batcher::Req>();
+    r->text = text; r->seed = seed;
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (b->stop) return -1;
+    const int64_t t = b->next_ticket++;
+    b->tickets[t] = r;
+    b->queue.emplace_back(t, r);
+    b->cv_work.notify_all();
+    return t;
+}
+
+BARK_API int bark_hip_batcher_wait(struct bark_hip_batcher * b, int64_t ticket, float * pcm, int capacity) {
+    if (!b) return -1;
+    std::unique_lock<std::mutex> lk(b->mu);
+    auto it = b->tickets.find(ticket);
+    if (it == b->tickets.end()) return -1;
+    std::shared_ptr<bark_hip_batcher::Req> r = it->second;
+    b->cv_done.wait(lk, [&] { return r->done; });
+    if (!r->ok) { b->tickets.erase(ticket); return -1; }
+    if (!pcm || capacity < (int) r->pcm.size()) return -2 - (int) r->pcm.size();       // too small: -(2 + samples); the ticket stays valid
+    memcpy(pcm, r->pcm.data(), r->pcm.size() * sizeof(float));
+    const int n = (int) r->pcm.size();
+    b->tickets.erase(ticket);
+    return n;
+}
+
+BARK_API void bark_hip_batcher_stats(struct bark_hip_batcher * b, int * n_batches, int * n_requests, int * largest_batch) {
+    if (!b) return;
+    std::lock_guard<std::mutex> lk(b->mu);
+    if (n_batches) *n_batches = b->n_batches;
+    if (n_requests) *n_requests = b->n_requests;
+    if (largest_batch) *largest_batch = b->largest;
+}
+
+BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b) {
+    if (!b) return;
+    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }
+    if (b->worker.joinable()) b->worker.join();                // pending requests are still served
+    delete b;
+}
+
+}  // extern "C"

@@ -173,10 +173,11 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * ctx, con
 bool engine_generate(bark_context * ctx, const char * text);
 // seeds: one std::mt19937 seed per utterance (temp > 0); nullptr: drawn from the context's generator, in order.  Returns #ok
 int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n, const uint32_t * seeds);
+void engine_reserve_batch(bark_context * ctx, int slots);          // fixes the lock-step capacity (otherwise the first batch call does)
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);
-double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass);
+double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass, int Z = 1);     // Z windows side by side (engine_fine_many's pass)
 double engine_time_slots(bark_context * c, int which, int op, int B, int kind, int ctxlen, int iters);
 #ifdef BARK_TRACE
 int engine_trace_decode_step(bark_context * ctx, int which, int ctxlen, int replays, unsigned long long * out6, int cap_records);

@@ -668,7 +668,8 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
 // forward passes side by side - rows z * 1024 .. z * 1024 + 1023 of every activation are utterance z's window, the attention runs per
 // window (grid.z), the products see 1024 Z rows.  Per utterance this is engine_fine's arithmetic, row for row.
 // ---------------------------------------------------------------------------------------------------
-static void ensure_fine_batch(bark_context * c, int Z) {
+namespace detail {
+void ensure_fine_batch(bark_context * c, int Z) {
     bark_context::FineBatch & fb = c->fine_batch;
     if (fb.cap >= Z) return;
     GptModel & m = c->gpt[2];
@@ -682,6 +683,13 @@ static void ensure_fine_batch(bark_context * c, int Z) {
     fb.u = dev_alloc<double>(c, 6 * R);
     fb.cap = Z;                                             // (a smaller earlier allocation stays with the context until it is freed)
 }
+RowBufs fine_batch_rows(bark_context * c, int Z) {
+    const bark_context::FineBatch & fb = c->fine_batch;
+    RowBufs rb; rb.x = fb.x; rb.q = fb.q; rb.xn = fb.xn; rb.att = fb.att; rb.hbuf = fb.hbuf; rb.q16 = fb.q16; rb.k16 = fb.k16; rb.vt16 = fb.vt16;
+    rb.logits = fb.logits; rb.tokens = fb.tokens; rb.plane = Z * 1024;
+    return rb;
+}
+}  // namespace detail
 
 std::vector<std::vector<int32_t>> engine_fine_many(bark_context * c, const std::vector<const std::vector<int32_t> *> & coarse, std::vector<std::mt19937> * rngs) {
     HIP_OK(hipSetDevice(c->device));
@@ -738,8 +746,7 @@ std::vector<std::vector<int32_t>> engine_fine_many(bark_context * c, const std::
             HIP_OK(hipMemcpyAsync(fb.u, ubuf.data(), ubuf.size() * 8, hipMemcpyHostToDevice, c->stream));
         }
         HIP_OK(hipStreamSynchronize(c->stream));
-        RowBufs rb; rb.x = fb.x; rb.q = fb.q; rb.xn = fb.xn; rb.att = fb.att; rb.hbuf = fb.hbuf; rb.q16 = fb.q16; rb.k16 = fb.k16; rb.vt16 = fb.vt16;
-        rb.logits = fb.logits; rb.tokens = fb.tokens; rb.plane = R;
+        const RowBufs rb = fine_batch_rows(c, Z);
         for (int nn = nc; nn < nf; nn++) {
             progress(c, FINE, 100 * (n * (nf - nc) + (nn - nc + 1)) / (max_loops * (nf - nc)));
             // a window with rel > 0 (the last ones of a long utterance) keeps the positions below rel: picks go to a scratch row first

@@ -352,6 +352,13 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
     return (double) ms * 1000.0 / (reps * per_graph);
 }
 
+void engine_reserve_batch(bark_context * c, int slots) {
+    HIP_OK(hipSetDevice(c->device));
+    if (slots < 1 || slots > 32) throw std::runtime_error("reserve_batch: 1..32 slots");
+    if (c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) return;          // these contexts run batches sequentially
+    ensure_batch(c, std::max(slots, 8));
+}
+
 int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds) {
     HIP_OK(hipSetDevice(c->device));
     const bark_context_params & p = c->params;

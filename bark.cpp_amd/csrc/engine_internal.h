@@ -80,5 +80,7 @@ void upload_uniforms(bark_context * c, int n);
 void consume_uniforms(bark_context * c, int n_used);
 void progress(bark_context * c, bark_encoding_step step, int pct);
 void run_fine_forward(bark_context * c, int nn, int n_rows, const RowBufs * rb = nullptr, int Z = 1);
+void ensure_fine_batch(bark_context * c, int Z);            // scratch of engine_fine_many for Z windows side by side
+RowBufs fine_batch_rows(bark_context * c, int Z);
 
 } }  // namespace barkhip::detail

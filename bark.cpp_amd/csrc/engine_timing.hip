@@ -156,18 +156,27 @@ int engine_trace_decode_step(bark_context * c, int which, int ctxlen, int replay
 }
 #endif
 
-double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pass) {
+double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pass, int Z) {
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[2];
-    std::vector<int32_t> buf((size_t) 8 * 1024);
+    if (Z < 1 || Z > 32) throw std::runtime_error("time_fine_pass: 1..32 windows");
+    std::vector<int32_t> buf((size_t) 8 * 1024 * Z);
     for (size_t i = 0; i < buf.size(); i++) buf[i] = (int32_t) ((i * 2654435761u) >> 22) & 1023;
-    upload_tokens(c, buf.data(), buf.size());
-    run_fine_forward(c, 4, 1024);
+    RowBufs rb = own_rows(c);
+    if (Z > 1) {
+        if (m.q4 || m.w32) throw std::runtime_error("time_fine_pass: several windows side by side need an f16 model file");
+        ensure_fine_batch(c, Z);
+        rb = fine_batch_rows(c, Z);
+        HIP_OK(hipMemcpyAsync(c->fine_batch.tokens, buf.data(), buf.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    } else upload_tokens(c, buf.data(), buf.size());
+    auto pass = [&](int nn) { if (Z > 1) run_fine_forward(c, nn, 1024, &rb, Z); else run_fine_forward(c, nn, 1024); };
+    pass(4);
     HIP_OK(hipStreamSynchronize(c->stream));
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     HIP_OK(hipEventRecord(e0, c->stream));
-    for (int i = 0; i < iters; i++) run_fine_forward(c, 2 + i % 6, 1024);
+    for (int i = 0; i < iters; i++) pass(2 + i % 6);
     HIP_OK(hipEventRecord(e1, c->stream));
     HIP_OK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -175,7 +184,7 @@ double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pas
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (flops_per_pass) {
         const double E = m.hp.n_embd, L = m.hp.n_layer, N = 1024;
-        *flops_per_pass = 2.0 * N * (L * 12.0 * E * E + 1024.0 * E) + 4.0 * N * N * E * L;
+        *flops_per_pass = Z * (2.0 * N * (L * 12.0 * E * E + 1024.0 * E) + 4.0 * N * N * E * L);     // SURVEY.md 8(d), per window
     }
     return (double) ms * 1000.0 / std::max(1, iters);
 }

@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-q4", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the bark-large leg (BASELINE config 3)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the tolerance-route leg (BARK_HIP_FAST_GEMM=1)")
     ap.add_argument("--no-roofline-legs", action="store_true", help="skip the kernel timing legs (rocprofv3 passes: the statistics then hold the prompts' kernels only)")
     ap.add_argument("--dump-pcm", default=None, help="rank 0 writes the gathered PCM of the last step here (.npz; tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
@@ -304,6 +305,10 @@ def main():
                                      "frac": flops / (fus * 1e-6) / 157.3e12, "us_per_pass": fus,
                                      "frac_of_f16_mfma_peak_2500TF": flops / (fus * 1e-6) / 2.5e15,
                                      "hbm_frac_on_algorithmic_bytes": 171.5e6 / (fus * 1e-6) / 8e12}
+        # the pass a lock-step batch runs: the fine windows of 8 utterances side by side (engine_fine_many), canonical route
+        fus8, flops8 = ctx.time_fine_pass(3, 8)
+        out["roofline_fine_pass"]["eight_windows_side_by_side"] = {"us_per_window": fus8 / 8, "achieved": flops8 / (fus8 * 1e-6) / 1e12,
+                                                                   "frac": flops8 / (fus8 * 1e-6) / 157.3e12}
     except Exception as e:      # noqa: BLE001
         out["roofline"] = {"error": str(e)}
     # config 5 at N = 1: the 64-prompt job on this GPU, lock-step batches of 32 (the point the multi-GPU curve starts from)
@@ -318,10 +323,46 @@ def main():
             dtb = time.perf_counter() - tb
             out["config5_64_prompts"] = {"prompts_per_s": len(prompts) / dtb, "audio_s_per_s": float(counts.sum()) / 24000.0 / dtb,
                                          "wall_ms": dtb * 1e3, "batch": 32,
-                                         "note": "bark_hip_generate_batch: lock-step decode, per-utterance results bit-identical to the single path"}
+                                         "note": "bark_hip_generate_batch: lock-step decode, window prompts of all slots in one pass, fine windows of 8 utterances side by side, "
+                                                 "codec of all utterances in one pass; per-utterance results bit-identical to the single path"}
             bctx.free()
         except Exception as e:      # noqa: BLE001
             out["config5_64_prompts"] = {"error": str(e)}
+    # Tolerance route (BARK_HIP_FAST_GEMM=1, read when a context is loaded): the many-row products and the fine model's attention on the
+    # f16 matrix cores in hardware accumulation order (fast_kernels.hip).  Reported BESIDE the canonical numbers, never instead of them:
+    # its ids are not promised to be the oracle's (tests/test_gpu_parity.py bounds its logits against the canonical route).
+    if not a.no_fast:
+        try:
+            os.environ["BARK_HIP_FAST_GEMM"] = "1"
+            try:
+                fctx = pkg.BarkContext.load_model(path, params, seed=0)
+            finally:
+                del os.environ["BARK_HIP_FAST_GEMM"]
+            text = prompts[a.warmup % len(prompts)]
+            assert ctx.generate_audio(text)
+            ref_ids = (ctx.semantic_tokens().copy(), ctx.coarse_tokens().copy(), ctx.fine_tokens().copy())
+            fctx.generate_audio(text)
+            tf0 = time.perf_counter(); assert fctx.generate_audio(text); dtf = time.perf_counter() - tf0
+            got_ids = (fctx.semantic_tokens(), fctx.coarse_tokens(), fctx.fine_tokens())
+            agree = {k: (int(np.sum(x.ravel()[:min(x.size, y.size)] == y.ravel()[:min(x.size, y.size)])), int(x.size))
+                     for k, x, y in zip(("semantic", "coarse", "fine"), ref_ids, got_ids)}
+            f1, fl1 = fctx.time_fine_pass(6)
+            f8, fl8 = fctx.time_fine_pass(3, 8)
+            leg = {"switch": "BARK_HIP_FAST_GEMM=1", "rtf": fctx.stats()["n_samples"] / 24000.0 / dtf, "ms_per_prompt": dtf * 1e3,
+                   "ids_equal_to_the_canonical_run_of_the_same_prompt": {k: "%d / %d" % v for k, v in agree.items()},
+                   "fine_pass": {"bound": "mfma-f16", "us_per_pass": f1, "achieved": fl1 / (f1 * 1e-6) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": fl1 / (f1 * 1e-6) / 2.5e15,
+                                 "eight_windows_side_by_side": {"us_per_window": f8 / 8, "achieved": fl8 / (f8 * 1e-6) / 1e12, "frac": fl8 / (f8 * 1e-6) / 2.5e15}},
+                   "tolerance": "logits within 5e-3 of the canonical route (fine model 1e-2), checked by test_tolerance_route_stays_within_its_stated_tolerance"}
+            if not a.no_batched:
+                idx = shard_prompts(prompts, 0, 1)
+                run_shard(fctx, prompts, idx[:32])
+                tb = time.perf_counter(); pcms = run_shard(fctx, prompts, idx); dtb = time.perf_counter() - tb
+                leg["config5_64_prompts"] = {"prompts_per_s": len(prompts) / dtb, "audio_s_per_s": sum(len(p) for p in pcms) / 24000.0 / dtb, "wall_ms": dtb * 1e3, "batch": 32}
+            out["tolerance_route"] = leg
+            fctx.free()
+        except Exception as e:      # noqa: BLE001
+            out["tolerance_route"] = {"error": str(e)}
     # the reference's default step cap (n_steps_text_encoder = 768, bark.cpp:2212): 1154 frames = 15.4 s per prompt, two fine windows
     try:
         ctx.set_params(pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=768))

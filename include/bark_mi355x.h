@@ -83,8 +83,8 @@ BARK_API struct bark_context * bark_hip_clone_context(struct bark_context * src,
 BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * const * texts, int n);
 
 /* In-engine batching: n utterances (n <= 32) advance in lock step through the semantic and coarse decode loops of ONE
- * context, so every decode kernel reads the weights once per step for all of them; prefill, fine passes and the codec
- * run per utterance.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context.  With temp > 0 every
+ * context, so every decode kernel reads the weights once per step for all of them; the prompts of all slots go through the model
+ * in one pass, the fine windows of 8 utterances side by side, the codec of all utterances in one pass.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context.  With temp > 0 every
  * utterance has its own std::mt19937 (the reference seeds one per context, bark.cpp:1179): utterance i is what a context
  * loaded with seed seeds[i] would generate; the unseeded call draws those seeds from the context's generator, in order.
  * BARK_HIP_HOST_SAMPLING degrades the call to a sequential loop.  The first call fixes the batch capacity.
@@ -95,6 +95,22 @@ BARK_API int bark_hip_generate_batch_seeded(struct bark_context * bctx, const ch
 BARK_API int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data);
 /* token stream of utterance i: stage 0 semantic, 1 coarse [T][2], 2 fine [T][8]; returns the id count or -1 */
 BARK_API int bark_hip_batch_tokens(struct bark_context * bctx, int i, int stage, int32_t * out, int capacity);
+
+/* Request collector in front of bark_hip_generate_batch - what a server puts where the reference's example holds one mutex around
+ * bark_generate_audio (examples/server/server.cpp:76-94,128-163).  Any number of host threads submit; one worker thread owns `bctx`
+ * (nobody else may use it while the batcher lives), collects pending requests - up to max_batch (<= 32), waiting at most max_wait_ms
+ * for a batch to fill once one request is pending - and runs them as ONE lock-step batch.  A request's result is what a fresh context
+ * seeded with its `seed` generates, whatever batch it travelled in (seed is irrelevant for temp == 0).
+ *   submit: thread-safe, returns a ticket > 0 (or -1).
+ *   wait  : blocks until the request is done; copies the PCM (24 kHz mono) and returns the sample count, -1 if the generation failed,
+ *           -(2 + samples) if `capacity` is too small (the ticket stays valid).  A ticket is consumed by a successful or failed wait.
+ *   free  : serves what is pending, then stops the worker. */
+struct bark_hip_batcher;
+BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context * bctx, int max_batch, int max_wait_ms);
+BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed);
+BARK_API int bark_hip_batcher_wait(struct bark_hip_batcher * b, int64_t ticket, float * pcm, int capacity);
+BARK_API void bark_hip_batcher_stats(struct bark_hip_batcher * b, int * n_batches, int * n_requests, int * largest_batch);
+BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b);
 
 /* Token streams of the last bark_generate_audio call (copied out; returns counts). */
 BARK_API int bark_hip_get_semantic_tokens(struct bark_context * bctx, int32_t * out, int capacity);
@@ -133,6 +149,8 @@ BARK_API double bark_hip_time_slots(struct bark_context * bctx, int which, int o
 
 /* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
 BARK_API double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass);
+/* the same for n_windows fine windows side by side (the forward pass of bark_hip_fine_many / of a lock-step batch); flops for all windows */
+BARK_API double bark_hip_time_fine_passes(struct bark_context * bctx, int n_windows, int iters, double * flops_per_pass);
 
 /* Library / device description (static string). */
 BARK_API const char * bark_hip_describe(struct bark_context * bctx);

@@ -69,7 +69,9 @@ def test_committed_bench_line_follows_the_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r02_bench_small_n1.json")))
+    import glob
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench_small_n1.json")))[-1]      # the latest round's line
+    d = json.load(open(newest))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

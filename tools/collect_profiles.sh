@@ -12,7 +12,7 @@ if [ -f bark.cpp_amd/lib/libbark_trace.so ]; then
     timeout 300 python tools/trace_decode.py small 640 gpurun_out/${N}_trace_decode_step.json > gpurun_out/${N}_trace_decode_step.txt 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batched --no-q4 --no-large --no-roofline-legs > $R/gpurun_out/prof_bench.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batched --no-q4 --no-large --no-fast --no-roofline-legs > $R/gpurun_out/prof_bench.log 2>&1
 DB=$(find $R/gpurun_out/prof_bench -name "*.db" | head -1); python $R/tools/rocpd_stats.py $DB $R/gpurun_out/${N}_kernel_stats_bench.csv > /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_decode -- python $R/tools/profile_decode.py > $R/gpurun_out/prof_decode.log 2>&1
 DB=$(find $R/gpurun_out/prof_decode -name "*.db" | head -1); python $R/tools/rocpd_stats.py $DB $R/gpurun_out/${N}_kernel_stats_decode.csv > /dev/null

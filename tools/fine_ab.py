@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fine forward pass (N = 1024) under environment variants, each in a fresh process: fine_ab.py NAME[:K=V,...] ...  -> us per pass.
+"""Fine forward pass (N = 1024) under environment variants, each in a fresh process: fine_ab.py NAME[:K=V,...] ...  -> us per pass (FINE_WINDOWS=Z: Z windows side by side, us per window).
 BARK_HIP_ATTN_DBG bits skip phases of attn_rows_kernel (1 scores, 2 exp, 4 mix; results are wrong, timing only)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,10 @@ from bark_amd_loader import load_package
 from tools.make_synth_model import ensure_model
 pkg = load_package()
 ctx = pkg.BarkContext.load_model(ensure_model("small", 0), pkg.default_params(temp=0.0, fine_temp=0.0), 0)
-us, flops = ctx.time_fine_pass(12)
+import os
+Z = int(os.environ.get("FINE_WINDOWS", "1"))
+us, flops = ctx.time_fine_pass(12 if Z == 1 else 6, Z)
+us /= Z
 print("RESULT", round(us, 1))
 ctx.free()
 ''' % ROOT

@@ -12,5 +12,6 @@ if len(sys.argv) > 1 and sys.argv[1] != "f16":
         assert pkg.load_library().bark_model_quantize(path.encode(), q.encode(), ftype)
     path = q
 ctx = pkg.BarkContext.load_model(path, pkg.default_params(temp=0.0, fine_temp=0.0), 0)
-print("fine pass", ctx.time_fine_pass(3))
+Z = int(os.environ.get("FINE_WINDOWS", "1"))
+print("fine pass", ctx.time_fine_pass(3, Z))
 ctx.free()
