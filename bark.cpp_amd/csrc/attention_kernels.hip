@@ -236,12 +236,133 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lock-step batches: the decode attention of all slots as TWO launches.  attn_fused_kernel is one workgroup per (head, slot) that pulls the
+// head's whole K and V (328 KB at 640 keys) through ONE CU - and a CU pulls ~24 bytes/ns: 13.4 us per launch at 8 slots with 96 of 256 CUs
+// busy, and at 32 slots 384 such workgroups (400+ registers: one per CU) are two rounds, the second half empty.  Split at the only place
+// the orders C2 / C4 / C5 allow: the scores of different keys are independent (C2), the mix of different value dims is independent (C5).
+//   attn_slots_scores_kernel   workgroup = (256-key group, head, slot), thread = key: 16 coalesced float4 of K, one C2 score -> sc [slot][head][P]
+//   attn_slots_mix_kernel<DS>  workgroup = (value slice of 64 / DS dims, head, slot): every thread takes its share of the scores (max, e =
+//                              (float) exp((double)(s - max)), double sum: C4, formed redundantly by the DS slices of a head), then lane
+//                              (chain c, 4 dims) walks keys c, c + 16, ... with fmaf (C5) and the 16 chains meet in LDS in tree order.
+// One more kernel boundary (~1.5 us) and 1.5 MB of scores, for 5 x as many workgroups of a quarter of the bytes each.  Used when there are
+// more (head, slot) pairs than CUs (launch_attn_decode); with fewer pairs the single launch is faster: its time is the latency chain
+// K -> scores -> exp -> mix of ONE workgroup, not the CU's bandwidth (13.5 against 15.9 us at 8 slots).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_slots_scores_kernel(const AttnDecodeArgs a, float * __restrict__ sc) {
+    const int g = blockIdx.x, h = blockIdx.y, slot = blockIdx.z, tid = threadIdx.x;
+    const int ctx = a.st[slot].n_past + 1;
+    if (g * 256 >= ctx) return;
+    const int P = a.P, E = a.H * 64;
+    const float * __restrict__ qh = a.q + (size_t) slot * E + h * 64;            // wave-uniform: scalar loads
+    const int j = min(g * 256 + tid, ctx - 1);
+    const float4 * kp = reinterpret_cast<const float4 *>(a.kc + (size_t) slot * a.kv_slot_stride) + (size_t) h * 16 * P + j;
+    float4 kv[16];
+    #pragma unroll
+    for (int dq = 0; dq < 16; dq++) kv[dq] = kp[(size_t) dq * P];
+    const float v = score_chain(kv, qh);
+    if (g * 256 + tid < ctx) sc[((size_t) slot * a.H + h) * P + g * 256 + tid] = v;
+}
+
+template <int DS>
+__global__ __launch_bounds__(256) void attn_slots_mix_kernel(const AttnDecodeArgs a, const float * __restrict__ sc) {
+    constexpr int NT = 256, NW = NT / 64, DW = 64 / DS;             // DW value dims per workgroup; the first 16 x DW / 4 threads mix (chain, float4 lane)
+    __shared__ float es[1024];
+    __shared__ float red_f[NW];
+    __shared__ double red_d[NW];
+    __shared__ float part[16][DW];
+    const int ds = blockIdx.x, h = blockIdx.y, slot = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, E = a.H * 64;
+    const int ctx = a.st[slot].n_past + 1;
+    const float * __restrict__ srow = sc + ((size_t) slot * a.H + h) * P;
+    constexpr int L4 = DW / 4;                                      // float4 lanes per chain
+    const bool mixer = tid < 16 * L4;
+    const int chain = mixer ? tid / L4 : 0, d4 = tid % L4;
+    const float4 * vp = reinterpret_cast<const float4 *>(a.vc + (size_t) slot * a.kv_slot_stride + (size_t) h * P * 64) + (size_t) chain * 16 + ds * L4 + d4;
+    // the value rows of the first 256 keys are requested before the softmax (every context holds them or the loads hit allocated cache rows)
+    float4 v0[16];
+    if (mixer) {
+        #pragma unroll
+        for (int i = 0; i < 16; i++) v0[i] = vp[(size_t) i * 256];
+    }
+    constexpr int KPT = 1024 / NT;                                  // keys per thread in the softmax phase
+    float s[KPT];
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int i = 0; i < KPT; i++) { const int j = tid + NT * i; s[i] = j < ctx ? srow[j] : -INFINITY; mx = fmaxf(mx, s[i]); }
+    mx = wave_max(mx);
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    #pragma unroll
+    for (int w = 1; w < NW; w++) mx = fmaxf(mx, red_f[w]);
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < KPT; i++) {
+        const int j = tid + NT * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    double sum = red_d[0];
+    #pragma unroll
+    for (int w = 1; w < NW; w++) sum += red_d[w];
+    const float inv = (float) (1.0 / sum);
+    float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto mix16 = [&](const float4 (&vv)[16], int g) {               // keys chain + 16 (16 g + i), i < 16
+        float pj[16];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;          // p = e * (float)(1/sum)
+        #pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool ok = chain + 16 * (16 * g + i) < ctx;
+            const float4 v = vv[i];
+            const float tx = fmaf(v.x, pj[i], acc.x), ty = fmaf(v.y, pj[i], acc.y), tz = fmaf(v.z, pj[i], acc.z), tw = fmaf(v.w, pj[i], acc.w);
+            acc.x = ok ? tx : acc.x; acc.y = ok ? ty : acc.y; acc.z = ok ? tz : acc.z; acc.w = ok ? tw : acc.w;
+        }
+    };
+    if (mixer) {
+        mix16(v0, 0);
+        for (int g = 1; g * 256 < ctx; g++) {
+            float4 vv[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[i] = vp[(size_t) (16 * g + i) * 256];
+            mix16(vv, g);
+        }
+        *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
+    }
+    __syncthreads();
+    if (tid < DW) {
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        const size_t o = (size_t) slot * E + h * 64 + ds * DW + tid;
+        if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
+    }
+}
+
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     if (a.ps) {
         if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: partial-score decode attention needs one sequence and block_size 1024"); }
         if (!a.knew) kernel_fail("bark-hip: partial-score decode attention needs the fixed-address copy of the appended K row");
         if (!a.vt) kernel_fail("bark-hip: partial-score decode attention needs the K-layout copy of V");
         hipLaunchKernelGGL(attn_ps_kernel, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
+        return;
+    }
+    // lock-step batches with more (head, slot) pairs than CUs: scores and softmax + mix as two launches.  Measured per call at 8 / 16 / 32
+    // slots (context 640; profiles/r03_attn_slots_split.txt): one workgroup per pair 13.5 / 17.5 / 33.1 us, the pair of launches 15.9 / 18.6 /
+    // 29.9 us (44.3 -> 37.6 at context 900) - it pays only where attn_fused_kernel needs a second, half-empty round of workgroups
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+    if (a.sc && a.P == 1024 && (a.H * a.nbatch > n_cu || (crosscheck_mask() & 64)) && !(crosscheck_mask() & 32)) {
+        hipLaunchKernelGGL(attn_slots_scores_kernel, dim3(4, a.H, a.nbatch), dim3(256), 0, s, a, a.sc);
+        hipLaunchKernelGGL((attn_slots_mix_kernel<2>), dim3(2, a.H, a.nbatch), dim3(256), 0, s, a, a.sc);
         return;
     }
     hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a);
@@ -316,28 +437,18 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
         // key tiles w, w+8, w+16, w+24 (32 keys each); the next tile's K rows are in flight during the MFMAs
         float4 ka[16], kb[16];
         int jt = w * 32;
-        if (jt < jend) {
-            load_k(ka, jt);
-            // steady state without a branch between a request and its use (hipcc's s_waitcnt is per program point: a conditional request
-            // makes the next consumer wait for every outstanding load), the last one or two tiles of the wave behind it
-            for (; jt + 512 < jend; jt += 512) {
-                load_k(kb, jt + 256);
-                __builtin_amdgcn_sched_barrier(0);
-                score_tile(ka, jt);
-                __builtin_amdgcn_sched_barrier(0);
-                load_k(ka, jt + 512);
-                __builtin_amdgcn_sched_barrier(0);
-                score_tile(kb, jt + 256);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (jt + 256 < jend) {
-                load_k(kb, jt + 256);
-                __builtin_amdgcn_sched_barrier(0);
-                score_tile(ka, jt);
+        if (jt < jend) load_k(ka, jt);
+        for (; jt < jend; jt += 512) {
+            const bool more = jt + 256 < jend;
+            if (more) load_k(kb, jt + 256);
+            __builtin_amdgcn_sched_barrier(0);
+            score_tile(ka, jt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (jt + 512 < jend) load_k(ka, jt + 512);
                 __builtin_amdgcn_sched_barrier(0);
                 score_tile(kb, jt + 256);
-            } else {
-                score_tile(ka, jt);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -397,27 +508,18 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
         }                                                                                                \
     }
     const int jstop = jend;
-    if (jstop > 0) {
-        ATT_LOAD_BATCH(va, ea, 0)
-        int jb = 0;
-        for (; jb + 512 < jstop; jb += 512) {                 // branch-free steady state, as in the score phase
-            ATT_LOAD_BATCH(vb, eb, jb + 256)
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_MFMA_BATCH(va, ea, jb)
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_LOAD_BATCH(va, ea, jb + 512)
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_MFMA_BATCH(vb, eb, jb + 256)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (jb + 256 < jstop) {
-            ATT_LOAD_BATCH(vb, eb, jb + 256)
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_MFMA_BATCH(va, ea, jb)
+    if (jstop > 0) { ATT_LOAD_BATCH(va, ea, 0) }
+    for (int jb = 0; jb < jstop; jb += 512) {
+        const bool more = jb + 256 < jstop;
+        if (more) { ATT_LOAD_BATCH(vb, eb, jb + 256) }
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_MFMA_BATCH(va, ea, jb)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            if (jb + 512 < jstop) { ATT_LOAD_BATCH(va, ea, jb + 512) }
             __builtin_amdgcn_sched_barrier(0);
             ATT_MFMA_BATCH(vb, eb, jb + 256)
-        } else {
-            ATT_MFMA_BATCH(va, ea, jb)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #undef ATT_LOAD_BATCH

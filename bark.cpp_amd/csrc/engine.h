@@ -118,6 +118,7 @@ struct bark_context {
         float * x = nullptr, * q = nullptr, * logits = nullptr; barkhip::half_t * att = nullptr, * h = nullptr;
         barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr; float * ln_stats = nullptr;
         float * att32 = nullptr, * h32 = nullptr;        // quantised models: f32 activations per slot
+        float * sc = nullptr;                            // [cap][max_H][P] attention scores of a lock step (scores kernel -> mix kernel)
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
         hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};

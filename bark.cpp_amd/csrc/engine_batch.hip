@@ -45,6 +45,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.out_tokens = dev_alloc<int32_t>(c, (size_t) B * 2048);
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
     bb.u = dev_alloc<double>(c, (size_t) B * 8192);
+    bb.sc = dev_alloc<float>(c, (size_t) B * c->max_H * c->P);
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.cap = B;
 }
@@ -97,6 +98,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         AttnDecodeArgs at;
         at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
         at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
+        at.sc = bb.sc;
         launch_attn_decode(st, at);
         LinArgs p;
         p.batched = 1; p.nbatch = B;
@@ -312,6 +314,7 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
             AttnDecodeArgs at;
             at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
             at.nbatch = B; at.kv_slot_stride = slot;
+            if (kind != 0) at.sc = bb.sc;                        // kind 0: the one-workgroup-per-(head, slot) kernel, for the A/B
             launch_attn_decode(c->stream, at);
             return;
         }

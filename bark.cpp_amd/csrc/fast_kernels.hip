@@ -212,13 +212,9 @@ static void launch_tile(hipStream_t s, const LinArgs & a) {
 void launch_linear_fast(hipStream_t s, const LinArgs & a) {
     if (!a.x_f16 || !a.W || (a.K & 63) != 0 || a.N < 1) kernel_fail("bark-hip: the f16 tile product takes f16 rows and f16 weights, K %% 64 == 0");
     if (a.epi == EPI_QKV16 && (!a.q16 || !a.k16 || !a.vt16 || a.seq <= 0 || (a.seq & 31) || a.N % a.seq)) kernel_fail("bark-hip: QKV16 epilogue needs whole sequences of a multiple of 32 rows");
-    static const int depth = getenv("BARK_HIP_FAST_DEPTH") ? atoi(getenv("BARK_HIP_FAST_DEPTH")) : 3;      // register stages of the operand pipeline: A/B on the device
+    // three register sets (a tile is requested two K steps ahead): 1.34 / 1.12 / 1.12 ms per fine pass at D = 2 / 3 / 4 (profiles/r03_fine_ab_fast.txt)
     const long tiles128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 128) {
-        if (depth <= 2) launch_tile<128, 128, 2>(s, a); else launch_tile<128, 128, 3>(s, a);
-    } else {
-        if (depth <= 2) launch_tile<64, 64, 2>(s, a); else if (depth == 3) launch_tile<64, 64, 3>(s, a); else launch_tile<64, 64, 4>(s, a);
-    }
+    if (tiles128 >= 128) launch_tile<128, 128, 3>(s, a); else launch_tile<64, 64, 3>(s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,17 +352,13 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
 
 void launch_attn_flash(hipStream_t s, const AttnFlashArgs & a) {
     if (a.S <= 0 || (a.S & 127) || a.Z < 1 || (a.E & 7) || (a.ld_att & 3)) kernel_fail("bark-hip: flash attention takes whole sequences of a multiple of 128 keys");
-    static const int ks = getenv("BARK_HIP_FLASH_KS") ? atoi(getenv("BARK_HIP_FLASH_KS")) : 2;      // waves per (head, 32-query) tile: A/B on the device
-    static const int nb = getenv("BARK_HIP_FLASH_NB") ? atoi(getenv("BARK_HIP_FLASH_NB")) : 3;      // register sets of the key-block ring
-    const dim3 grid(a.S / 32 * a.H * a.Z);
-    if (ks >= 4)      { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<4, 2>), grid, dim3(256), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<4, 3>), grid, dim3(256), 0, s, a); }
-    else if (ks == 2) { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<2, 2>), grid, dim3(128), 0, s, a); else if (nb == 3) hipLaunchKernelGGL((attn_flash_f16_kernel<2, 3>), grid, dim3(128), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<2, 4>), grid, dim3(128), 0, s, a); }
-    else              { if (nb <= 2) hipLaunchKernelGGL((attn_flash_f16_kernel<1, 2>), grid, dim3(64), 0, s, a); else hipLaunchKernelGGL((attn_flash_f16_kernel<1, 4>), grid, dim3(64), 0, s, a); }
+    // two waves per (window, head, 32 queries) split the keys, three register sets per wave: KS = 1 / 2 / 4 and NB = 2 / 3 / 4 measured within
+    // 2 % of each other once the pipeline's steady state is branch-free (profiles/r03_fine_ab_fast.txt)
+    hipLaunchKernelGGL((attn_flash_f16_kernel<2, 3>), dim3(a.S / 32 * a.H * a.Z), dim3(128), 0, s, a);
 }
 
 void init_fast_attributes() {
     const int lds = 2 * (128 + 128) * FT_LDK * (int) sizeof(half_t);
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 

@@ -146,6 +146,7 @@ struct AttnDecodeArgs {
     const float * knew = nullptr;         // [E] the K row this step appended (copy at a fixed address, see LinArgs::knew)
     const float * ps = nullptr;           // [H][4][P] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
+    float * sc = nullptr;                  // lock-step batches: [nbatch][H][P] scores between attn_slots_scores_kernel and attn_slots_mix_kernel (nullptr: attn_fused_kernel)
     BARK_TRACE_FIELD
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);      // a.ps set: attn_ps_kernel; otherwise attn_fused_kernel (one workgroup per head and slot)
@@ -206,6 +207,8 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 //   4  decode attention without the QKV kernel's partial scores (attn_fused_kernel instead of attn_ps_kernel)
 //   8  every coarse window re-evaluated from its first row (no prefix reuse), as the reference does
 //  16  lock-step batches: the prompts of the slots through the model slot by slot instead of all in one pass (batch_prefill_many)
+//  32  lock-step batches: the decode attention always as one workgroup per (head, slot) (attn_fused_kernel), also above 256 pairs
+//  64  lock-step batches: the decode attention always as the scores / mix pair of launches, also below 256 (head, slot) pairs
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();

@@ -467,28 +467,23 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     const unsigned sh16 = half ? 16u : 0u;
     GEMM_LOAD_BLOCK(xa0, wb0, 0)
     int b = 0;
-    // steady state WITHOUT a branch between a request and its use: hipcc places s_waitcnt per program point, so the former
-    // `if (b + 2 < nblk) load` made the second half of every trip wait for vmcnt(0) - for the loads it had just issued (round 3: seen in
-    // the ISA; the prefetch then covered only every other block).  The last one or two blocks run through the tail below.
-    for (; b + 2 < nblk; b += 2) {
+    // NOTE (round 3, profiles/r03_exact_loops_branch_free.txt): hipcc places s_waitcnt per program point, so the conditional request of block
+    // b + 2 below makes the second half of a trip wait for vmcnt(0), i.e. for the loads it has just issued.  The branch-free form of this
+    // loop (steady state + guarded tail, waits of vmcnt(8) in both halves) measured SLOWER on the device - QKV 56 -> 66 us, FC 61 -> 72 us
+    // per launch, pass 3.50 -> 3.96 ms: the eight waves of a workgroup read the same 256-byte span of every operand row (16 bytes per
+    // chain), and only while they advance together does the second wave find the line in L1; with 16 loads in flight per wave they
+    // drift apart and every line travels from L2 up to eight times.  The loop stays as it is.
+    for (; b + 1 < nblk; b += 2) {
         GEMM_LOAD_BLOCK(xa1, wb1, b + 1)
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
         GEMM_MFMA_BLOCK(xa0, wb0)
         __builtin_amdgcn_sched_barrier(0);
-        GEMM_LOAD_BLOCK(xa0, wb0, b + 2)
+        if (b + 2 < nblk) { GEMM_LOAD_BLOCK(xa0, wb0, b + 2) }
         __builtin_amdgcn_sched_barrier(0);
         GEMM_MFMA_BLOCK(xa1, wb1)
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (b + 1 < nblk) {
-        GEMM_LOAD_BLOCK(xa1, wb1, b + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_MFMA_BLOCK(xa0, wb0)
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_MFMA_BLOCK(xa1, wb1)
-    } else {
-        GEMM_MFMA_BLOCK(xa0, wb0)
-    }
+    if (b < nblk) { GEMM_MFMA_BLOCK(xa0, wb0) }
 #undef GEMM_LOAD_BLOCK
 #undef GEMM_MFMA_BLOCK
     // chain pair (2w, 2w+1) -> LDS; accumulator register r of lane l holds row (r&3)+8(r>>2)+4*half, col l31

@@ -17,7 +17,8 @@ out = {"preset": preset, "B": B, "ctx": ctxlen, "us_per_launch": {}}
 for kind in kinds:
     out["us_per_launch"]["kind%d" % kind] = {n: round(ctx.time_slots(0, op, B, kind, ctxlen, 960), 2) for op, n in enumerate(names)}
 out["us_per_launch"]["ln_rows"] = round(ctx.time_slots(0, 4, B, 0, ctxlen, 960), 2)
-out["us_per_launch"]["attention_all_slots"] = round(ctx.time_slots(0, 5, B, 0, ctxlen, 480), 2)
+out["us_per_launch"]["attention_all_slots_one_workgroup_per_head_and_slot"] = round(ctx.time_slots(0, 5, B, 0, ctxlen, 480), 2)
+out["us_per_launch"]["attention_all_slots"] = round(ctx.time_slots(0, 5, B, 1, ctxlen, 480), 2)       # scores + mix launches (two kernels per call)
 ctx.free()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "time_slots.json"), "w"), indent=1)
