@@ -82,7 +82,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         // (tools/time_slots.py, us per launch VALU / matrix cores: proj 2.9 / 3.5 at 8 slots, 3.3 / 3.7 at 16, 4.4 / 3.7 at 32; MLP proj 5.1 / 8.0
         // at 8, 9.0 / 8.8 at 16, 12.7 / 8.9 at 32)
         if (!ln_g && (a.K == a.M ? B < 24 : B < 16)) { launch_linear(st, a); return; }
-        if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
+        // LayerNorm of the slot rows: inside the product kernel (BARK_HIP_CROSSCHECK bit 7 keeps the launch of its own, the cross-check route)
+        if (ln_g && linear_slots_fuses_ln(a.K) && !(crosscheck_mask() & 128)) { a.ln_g = ln_g; a.ln_b = ln_b; }
+        else if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
         launch_linear_slots(st, a);
     };
@@ -322,11 +324,15 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.N = 1;
         switch (op) {
             case 0: a.W = L.attn_w; a.M = 3 * E; a.K = E; a.bias = L.attn_b; a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.st = bb.state;
-                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; } else a.x_f16 = c->xn;
+                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; }
+                    else if (kind == 6) { a.x_f32 = bb.x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; }          // LayerNorm fused into the matrix-core product
+                    else a.x_f16 = c->xn;
                     break;
             case 1: a.W = L.proj_w; a.M = E; a.K = E; a.x_f16 = bb.att; a.bias = L.proj_b; a.epi = EPI_RESID; a.res = bb.x; break;
             case 2: a.W = L.fc_w; a.M = 4 * E; a.K = E; a.bias = L.fc_b; a.epi = EPI_GELU; a.out_h = bb.h; a.lut = c->d_gelu_lut;
-                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; } else a.x_f16 = c->xn;
+                    if (kind == 0) { a.x_f32 = bb.x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.ln_stats = B >= 24 ? bb.ln_stats : nullptr; }
+                    else if (kind == 6) { a.x_f32 = bb.x; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; }
+                    else a.x_f16 = c->xn;
                     break;
             default: a.W = L.mproj_w; a.M = E; a.K = 4 * E; a.x_f16 = bb.h; a.bias = L.mproj_b; a.epi = EPI_RESID; a.res = bb.x; break;
         }

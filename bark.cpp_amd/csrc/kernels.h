@@ -112,7 +112,8 @@ struct LinArgs {
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
-void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel
+void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel; x_f32 + ln_g: the LayerNorm of the rows fused (when linear_slots_fuses_ln(K))
+bool linear_slots_fuses_ln(int K);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
@@ -209,6 +210,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 //  16  lock-step batches: the prompts of the slots through the model slot by slot instead of all in one pass (batch_prefill_many)
 //  32  lock-step batches: the decode attention always as one workgroup per (head, slot) (attn_fused_kernel), also above 256 pairs
 //  64  lock-step batches: the decode attention always as the scores / mix pair of launches, also below 256 (head, slot) pairs
+// 128  lock-step batches: the LayerNorm of the slot rows as a launch of its own in front of the QKV / FC / LM-head products instead of inside them
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();

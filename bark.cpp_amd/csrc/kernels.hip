@@ -585,13 +585,20 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
 // Per launch at 32 slots, bark-small (tools/time_slots.py, QKV / proj / FC / MLP proj): 5.7 / 3.7 / 5.5 / 8.9 us against 9.2 / 4.9 / 9.1 /
 // 11.2 for the 4 x 4 x 1 kernel and 17.1 / 4.4 / 22.7 / 12.7 for the VALU GEMV per pair of slots (profiles/r03_slots16_times.txt).
 // ------------------------------------------------------------------------------------------------
-template <int NBLK>
+// LNF: the LayerNorm of the slot rows happens HERE instead of in a launch of its own (ln_rows_vec_kernel, 2.0 us + a kernel boundary, twice per
+// layer): wave w normalises slots s0 + 4 w .. + 3 with ln_rows_vec_kernel's arithmetic (the row in registers, lane l holds elements 4 l + 256 i:
+// the same partition of the double sums, the same operations per element - bit-equal), the f16 rows go to LDS (row stride K + 8 halfs: the 16
+// rows a load instruction touches cover all 64 banks), and the weight rows are requested BEFORE that, so their way from HBM overlaps it.
+template <int NBLK, bool LNF>
 __global__ __launch_bounds__(256) void gemm_slots16_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const int parity_rows,
                                                            const LinArgs a) {
     constexpr int K = NBLK * 128;
     constexpr int G = NBLK <= 8 ? NBLK : 8, NG = NBLK / G;       // blocks per load group
     static_assert(NBLK % G == 0, "K/128 must be <= 8 or a multiple of 8");
+    static_assert(!LNF || (NG == 1 && NBLK % 2 == 0), "the fused LayerNorm needs the whole row in one load group and K % 256 == 0");
     __shared__ float red[4][16][17];
+    constexpr int XS_LD = K + 8;
+    __shared__ __attribute__((aligned(16))) half_t xs[LNF ? 16 * XS_LD : 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int m0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(256) void gemm_slots16_kernel(const half_t * __rest
 #define SLOTS16_LOAD(WV, XV, GI)                                                                            \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
         WV[i] = ld_u4(wrow + (((GI) * G + i) << 7));                                                         \
-        XV[i] = ld_u4(xrow + (((GI) * G + i) << 7));                                                         \
+        if constexpr (!LNF) XV[i] = ld_u4(xrow + (((GI) * G + i) << 7));                                     \
     }
 #define SLOTS16_MFMA(WV, XV)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < G; i++) {                                                          \
@@ -621,6 +628,54 @@ __global__ __launch_bounds__(256) void gemm_slots16_kernel(const half_t * __rest
     const int em = m0 + (threadIdx.x & 15), en = s0 + (threadIdx.x >> 4);
     const bool live = em < M && en < a.nbatch;
     const EpiPre pre = epilogue_prefetch(a, live ? en : 0, live ? em : 0, row_off);
+    if constexpr (LNF) {
+        constexpr int NV = K / 256;
+        float4 gg[NV], bb[NV];
+        #pragma unroll
+        for (int i = 0; i < NV; i++) {
+            gg[i] = *reinterpret_cast<const float4 *>(a.ln_g + 4 * lane + 256 * i);
+            bb[i] = a.ln_b ? *reinterpret_cast<const float4 *>(a.ln_b + 4 * lane + 256 * i) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        float4 v[4][NV];
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float * xr = a.x_f32 + (size_t) min(s0 + 4 * w + q, a.nbatch - 1) * K + 4 * lane;
+            #pragma unroll
+            for (int i = 0; i < NV; i++) v[q][i] = *reinterpret_cast<const float4 *>(xr + 256 * i);
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double s1 = 0.0;
+            #pragma unroll
+            for (int i = 0; i < NV; i++) { s1 += (double) v[q][i].x; s1 += (double) v[q][i].y; s1 += (double) v[q][i].z; s1 += (double) v[q][i].w; }
+            s1 = wave_sum(s1);
+            const float mean = (float) (s1 / (double) K);
+            double s2 = 0.0;
+            #pragma unroll
+            for (int i = 0; i < NV; i++) {
+                float4 & u = v[q][i];
+                u.x = u.x - mean; u.y = u.y - mean; u.z = u.z - mean; u.w = u.w - mean;
+                s2 += (double) (u.x * u.x); s2 += (double) (u.y * u.y); s2 += (double) (u.z * u.z); s2 += (double) (u.w * u.w);
+            }
+            s2 = wave_sum(s2);
+            const float var = (float) (s2 / (double) K);
+            const float scale = 1.0f / sqrtf(var + 1e-5f);
+            half_t * o = xs + (4 * w + q) * XS_LD + 4 * lane;
+            #pragma unroll
+            for (int i = 0; i < NV; i++) {
+                float t[4] = {v[q][i].x * scale, v[q][i].y * scale, v[q][i].z * scale, v[q][i].w * scale};
+                t[0] = t[0] * gg[i].x; t[1] = t[1] * gg[i].y; t[2] = t[2] * gg[i].z; t[3] = t[3] * gg[i].w;
+                if (a.ln_b) { t[0] = t[0] + bb[i].x; t[1] = t[1] + bb[i].y; t[2] = t[2] + bb[i].z; t[3] = t[3] + bb[i].w; }
+                half_t h[4];
+                #pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = to_half(t[e]);
+                *reinterpret_cast<uint2 *>(o + 256 * i) = __builtin_bit_cast(uint2, h);
+            }
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int i = 0; i < G; i++) xa[i] = *reinterpret_cast<const uint4 *>(xs + r * XS_LD + coff + (i << 7));
+    }
     #pragma unroll
     for (int gi = 0; gi < NG; gi += 2) {
         if constexpr (NG > 1) { if (gi + 1 < NG) { SLOTS16_LOAD(wb, xb, gi + 1) } }
@@ -646,11 +701,17 @@ __global__ __launch_bounds__(256) void gemm_slots16_kernel(const half_t * __rest
 }
 template <int NBLK>
 static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
-    hipLaunchKernelGGL((gemm_slots16_kernel<NBLK>), dim3((a.M + 15) / 16, (a.nbatch + 15) / 16), dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+    const dim3 grid((a.M + 15) / 16, (a.nbatch + 15) / 16);
+    if constexpr (NBLK <= 8 && NBLK % 2 == 0) {
+        if (a.ln_g) { hipLaunchKernelGGL((gemm_slots16_kernel<NBLK, true>), grid, dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a); return; }
+    }
+    if (a.ln_g || !a.x_f16) kernel_fail("bark-hip: the lock-step MFMA product fuses the LayerNorm only for n_embd %% 256 == 0, n_embd <= 1024");
+    hipLaunchKernelGGL((gemm_slots16_kernel<NBLK, false>), grid, dim3(256), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
 }
+bool linear_slots_fuses_ln(int K) { return K % 256 == 0 && K <= 1024; }
 
 void launch_linear_slots(hipStream_t s, const LinArgs & a) {
-    if (!a.batched || !a.x_f16 || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows of up to 32 slots and f16 weights");
+    if (!a.batched || (!a.x_f16 && !(a.x_f32 && a.ln_g)) || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows (or f32 rows + LayerNorm) of up to 32 slots and f16 weights");
     switch (a.K >> 7) {
         case 1:  launch_slots16_n<1>(s, a); break;
         case 2:  launch_slots16_n<2>(s, a); break;

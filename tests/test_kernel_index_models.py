@@ -96,3 +96,67 @@ def test_slots4_decomposition_is_c1():
                         if n < B and m < M:
                             want = c1_dot(W[m].astype(np.float32), X[n].astype(np.float32))
                             assert t[0] == want and all(x == t[0] for x in t), (bx, w, gidx, v, j)
+
+
+def _xcd_rank(b, n):
+    """device_utils.h: xcd_rank - workgroup b (XCD b % 8) -> a rank such that one XCD holds consecutive ranks"""
+    q, r, x, i = n >> 3, n & 7, b & 7, b >> 3
+    return (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + i
+
+
+def _panel_tile(l, nrow, ncol, pw):
+    """device_utils.h: panel_tile - rank -> (row tile, column tile), column panels of width pw"""
+    per_panel = nrow * pw
+    p, rem = divmod(l, per_panel)
+    c0 = p * pw
+    w = min(pw, ncol - c0)
+    row = rem // w
+    return row, c0 + (rem - row * w)
+
+
+def _xcd_panel_width(n_tiles, ncol):
+    """kernels.hip: xcd_panel_width"""
+    pw = 1
+    while pw * pw < (n_tiles + 7) // 8:
+        pw += 1
+    return max(1, min(pw, ncol))
+
+
+def test_xcd_aware_tile_order_visits_every_tile_once():
+    """The renumbering the many-row products and the prefill / fine attentions apply to blockIdx.x (any grid size, also when it is not a
+    multiple of 8, ragged last column panel): every output tile exactly once, and the workgroups of one XCD (b % 8) cover a compact
+    block (a run of consecutive ranks: at most two column panels, share / pw rows of each) instead of tiles from all over the output."""
+    for nrow, ncol in [(1, 1), (1, 7), (3, 5), (16, 36), (8, 18), (8, 24), (16, 12), (16, 17), (5, 36), (64, 18), (11, 9), (2, 48)]:
+        n = nrow * ncol
+        pw = _xcd_panel_width(n, ncol)
+        ranks = sorted(_xcd_rank(b, n) for b in range(n))
+        assert ranks == list(range(n)), (nrow, ncol)
+        seen = set()
+        per_xcd = {}
+        for b in range(n):
+            t = _panel_tile(_xcd_rank(b, n), nrow, ncol, pw)
+            assert 0 <= t[0] < nrow and 0 <= t[1] < ncol and t not in seen, (nrow, ncol, b, t)
+            seen.add(t)
+            per_xcd.setdefault(b % 8, []).append(t)
+        assert len(seen) == n
+        if n >= 64:
+            for tiles in per_xcd.values():
+                rows, cols = {t[0] for t in tiles}, {t[1] for t in tiles}
+                assert len(cols) <= 2 * pw, (nrow, ncol, pw, len(rows), len(cols))
+                if (nrow, ncol) in ((16, 36), (8, 18), (8, 24), (16, 12), (64, 18)):          # the fine model's products
+                    assert len(rows) + len(cols) <= (nrow + ncol) * 2 // 3, (nrow, ncol, pw, len(rows), len(cols))
+
+
+def test_attention_rank_order_keeps_a_head_on_one_xcd():
+    """attn_rows_kernel / attn_flash_f16_kernel: rank -> (sequence, head, query tile); the 32 query tiles of one (sequence, head) are
+    consecutive ranks, i.e. they run on at most QT / (ranks per XCD) + 2 XCDs - two for the fine model's 32 tiles x 12 heads."""
+    for QT, H, Z in [(32, 12, 1), (32, 12, 8), (9, 2, 3), (32, 16, 5)]:
+        n = QT * H * Z
+        owner = {}
+        for b in range(n):
+            r = _xcd_rank(b, n)
+            key = (r // (QT * H), (r // QT) % H)
+            owner.setdefault(key, set()).add(b % 8)
+            assert 0 <= r % QT < QT
+        share = max(1, n // 8)                                             # consecutive ranks one XCD holds
+        assert len(owner) == H * Z and all(len(v) <= QT // share + 2 for v in owner.values())

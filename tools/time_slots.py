@@ -16,6 +16,7 @@ names = ["qkv", "proj", "fc_gelu", "mproj"]
 out = {"preset": preset, "B": B, "ctx": ctxlen, "us_per_launch": {}}
 for kind in kinds:
     out["us_per_launch"]["kind%d" % kind] = {n: round(ctx.time_slots(0, op, B, kind, ctxlen, 960), 2) for op, n in enumerate(names)}
+out["us_per_launch"]["ln_fused_products"] = {n: round(ctx.time_slots(0, op, B, 6, ctxlen, 960), 2) for op, n in ((0, "qkv"), (2, "fc_gelu"))}
 out["us_per_launch"]["ln_rows"] = round(ctx.time_slots(0, 4, B, 0, ctxlen, 960), 2)
 out["us_per_launch"]["attention_all_slots_one_workgroup_per_head_and_slot"] = round(ctx.time_slots(0, 5, B, 0, ctxlen, 480), 2)
 out["us_per_launch"]["attention_all_slots"] = round(ctx.time_slots(0, 5, B, 1, ctxlen, 480), 2)       # scores + mix launches (two kernels per call)
