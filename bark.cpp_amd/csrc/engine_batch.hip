@@ -83,7 +83,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         // at 8, 9.0 / 8.8 at 16, 12.7 / 8.9 at 32)
         if (!ln_g && (a.K == a.M ? B < 24 : B < 16)) { launch_linear(st, a); return; }
         // LayerNorm of the slot rows: inside the product kernel (BARK_HIP_CROSSCHECK bit 7 keeps the launch of its own, the cross-check route)
-        if (ln_g && linear_slots_fuses_ln(a.K) && !(crosscheck_mask() & 128)) { a.ln_g = ln_g; a.ln_b = ln_b; }
+        // - measured per launch (QKV, small): 8 slots 5.7 us fused against 4.0 + 1.9 separate, 32 slots 8.7 against 5.7 + 2.0 (two slot tiles: twice
+        // the workgroups repeat the LayerNorm), whole batches +2 % at 8 slots, -1 % at 32 (profiles/r03_ln_fused_slots.txt): fused for one slot tile
+        if (ln_g && linear_slots_fuses_ln(a.K) && B <= 16 && !(crosscheck_mask() & 128)) { a.ln_g = ln_g; a.ln_b = ln_b; }
         else if (ln_g) { launch_ln_rows(st, a.x_f32, B, a.K, ln_g, ln_b, c->xn); a.x_f16 = c->xn; a.x_f32 = nullptr; }
         a.ln_stats = nullptr;
         launch_linear_slots(st, a);

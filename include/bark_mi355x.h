@@ -143,8 +143,9 @@ BARK_API double bark_hip_time_gemv(struct bark_context * bctx, int which, int op
 
 /* Device time (us) of ONE lock-step decode kernel over n_slots utterance slots (the kernels of bark_hip_generate_batch), averaged over
  * `iters` back-to-back launches that rotate through the layers' weights.  op: 0 QKV, 1 attention out-proj, 2 FC + GELU, 3 MLP out-proj,
- * 4 LayerNorm of the slot rows, 5 attention of every slot at context `ctx`.  kind: route of the products (0 VALU GEMV with the LayerNorm
- * fused, 1 = 32 x 32 MFMA tiles, 2 = 4 x 4 MFMA blocks, 3 = the same with conversions hoisted out of the MFMA runs, 5 = 16 x 16 x 4 MFMA tiles).  f16 model files only. */
+ * 4 LayerNorm of the slot rows, 5 attention of every slot at context `ctx`.  kind: 0 = the VALU GEMV per pair of slots with the LayerNorm fused
+ * (ops 0 / 2) and, for op 5, one workgroup per (head, slot); 6 = the matrix-core product with the LayerNorm fused (ops 0 / 2); any other value =
+ * the matrix-core product on normalised f16 rows and, for op 5, the scores + mix pair of launches where the engine would use it.  f16 model files only. */
 BARK_API double bark_hip_time_slots(struct bark_context * bctx, int which, int op, int n_slots, int kind, int ctx, int iters);
 
 /* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
