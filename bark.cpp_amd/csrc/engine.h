@@ -86,8 +86,7 @@ struct bark_context {
     float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)
     float * ps = nullptr;                               // [H][4][P] partial attention scores of a decode step (QKV kernel -> attn_ps_kernel)
     barkhip::half_t * xn = nullptr, * att = nullptr, * hbuf = nullptr;
-    barkhip::half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr;      // tolerance route (fast_gemm): f16 operands of the flash attention, [rows_cap][E] each
-    size_t rows_cap = 0;                                // rows the many-row scratch (x, q, xn, att, hbuf, q16 ...) holds: P, or P * fine batch
+    barkhip::half_t * q16 = nullptr, * k16 = nullptr, * vt16 = nullptr;      // tolerance route (fast_gemm): f16 operands of the flash attention, [P][E] each
     // quantised models: activations stay f32 between the products and are quantised to q8 rows (xq) in front of each
     bool any_q4 = false;
     float * att32 = nullptr, * h32 = nullptr; barkhip::Q8Scratch xq;
@@ -110,8 +109,8 @@ struct bark_context {
     struct LstmGraph { hipGraphExec_t exec = nullptr; int B = 0; const float * out = nullptr; const float * gi = nullptr; } lstm_graph;    // 64 wave-front steps
     struct CodecGraph { hipGraphExec_t exec = nullptr; std::vector<int> T; const float * buf = nullptr; float * out = nullptr; int tmul = 0; } codec_graph;   // conv stack behind the LSTM
 
-    // batched decode (several utterances in lock step on this context, bark_hip_generate_batch): per-slot KV caches
-    // and decode rows; prefill / fine / codec still run one utterance at a time on the buffers above
+    // batched decode (several utterances in lock step on this context, bark_hip_generate_batch): per-slot KV caches and decode rows,
+    // the row scratch of the all-slots prefill; FineBatch below holds the scratch of the side-by-side fine passes
     struct Batch {
         int cap = 0;
         float * kc[2] = {nullptr, nullptr}, * vc[2] = {nullptr, nullptr}; size_t slot_stride[2] = {0, 0};

@@ -17,8 +17,10 @@ namespace barkhip {
 
 // ---------------------------------------------------------------------------------------------------
 // batched decode: B utterances advance in lock step through the semantic and coarse decode loops; every decode
-// kernel processes all slots (weights are read from HBM once per step instead of once per utterance), prefill,
-// fine passes and the codec still run per utterance.  Per-slot arithmetic is exactly the single-utterance one.
+// kernel processes all slots (weights are read from HBM once per step instead of once per utterance); the prompts of all
+// slots go through the model in one pass (batch_prefill_many), the fine windows of several utterances side by side
+// (engine_fine_many, engine.hip), the codec of all utterances in one pass (engine_codec.hip).  Per-slot arithmetic is
+// exactly the single-utterance one.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 

@@ -132,7 +132,6 @@ static void init_runtime(bark_context * ctxp) {
     ctx->xn = dev_alloc<half_t>(ctx.get(), NE);
     ctx->att = dev_alloc<half_t>(ctx.get(), NE);
     ctx->hbuf = dev_alloc<half_t>(ctx.get(), NE * 4);
-    ctx->rows_cap = (size_t) P;
     if (ctx->fast_gemm) {
         ctx->q16 = dev_alloc<half_t>(ctx.get(), NE);
         ctx->k16 = dev_alloc<half_t>(ctx.get(), NE);
