@@ -404,11 +404,12 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const LinArgs a) {
 // exact GEMM on the f32 matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain
 // (cdna_hip_programming.md section 3), so one accumulator register == one chain of C1.
 // Workgroup: 8 waves, output tile 64 (rows n) x 64 (cols m).  Wave w owns chains 2w and 2w+1 for the
-// whole tile (2 x 2 MFMA tiles x 2 chains = 8 accumulators); per 128-element K block it loads one
-// 16-byte chunk per operand row and chain and issues 4 MFMAs (k pairs) per tile.  The 16 chains meet
-// in LDS and are added in the C1 tree order.
+// whole tile (2 x 2 MFMA tiles x 2 chains = 8 accumulators) and issues 4 MFMAs (k pairs) per tile, chain and 128-element K block.
+// Operands are staged through LDS as f16 whole rows, fetched once per workgroup (round 3; before, every wave fetched 16-byte pieces of
+// the same rows itself: 3.6 % slower, profiles/r03_gemm_lds.txt).  The 16 chains meet in LDS and are added in the C1 tree order.
 // ------------------------------------------------------------------------------------------------
 constexpr int GEMM_TM = 64, GEMM_TN = 64;
+constexpr int GEMM_LDS_BYTES = 8 * 64 * 64 * 4;                  // the reduction tree of the epilogue (8 x 64 x 64 f32); the two staging buffers (2 x 2 x 64 rows x 272 bytes = 68 KB) re-use it
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 DEVINL float half_of(const uint4 & u, int e) {                 // element e (compile-time) of eight packed f16 values, widened
     const unsigned word = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
@@ -419,31 +420,50 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    int trow, tcol;
-    panel_tile(xcd_rank(blockIdx.x, ncol * nrow), nrow, ncol, pw, trow, tcol);      // XCD-aware tile order (device_utils.h)
-    const int n0 = trow * GEMM_TN, m0 = tcol * GEMM_TM;
+    // Persistent: the grid is one workgroup per CU (128 KB of LDS each); workgroup b walks the virtual ids b, b + grid, ... (same XCD: the grid is
+    // a multiple of 8) through the XCD-aware tile order, and requests the first K block of its NEXT tile before the epilogue of the current one,
+    // so that the ~2 us a first request takes overlap the reduction tree and the stores instead of standing in front of every tile's MFMAs.
+    const int ntiles = ncol * nrow;
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    int n0, m0;
     const int K = a.K, nblk = K >> 7;
-    int nrw[2], mrow[2];
-    #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        nrw[t] = min(n0 + t * 32 + l31, a.N - 1);
-        mrow[t] = min(m0 + t * 32 + l31, a.M - 1);
-    }
     floatx16 acc[2][2][2];
-    #pragma unroll
-    for (int s = 0; s < 2; s++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++)
-        for (int r = 0; r < 16; r++) acc[s][i][j][r] = 0.0f;
 
-    // operands of one K block (both chains of this wave): [chain][row tile]; double buffered so that the
-    // loads of block b+1 are in flight while the 32 MFMAs of block b issue
-    // (buffer indices are compile-time constants: runtime-indexed register arrays would go to scratch)
-    half8 xa0[2][2], wb0[2][2], xa1[2][2], wb1[2][2];
-#define GEMM_LOAD_BLOCK(XA, WB, B)                                                                       \
+    // Operand staging: the workgroup fetches the K block (128 elements = 256 bytes per row) of its 64 x rows and 64 weight rows ONCE, as
+    // whole rows (a wave covers 4 rows x 256 contiguous bytes; gemm_kernel's waves fetch 16-byte pieces of those rows separately and depend
+    // on finding each other's lines in L1), keeps them f16 in LDS (row stride 272 bytes: the 16-byte chunks a ds_read_b128 takes from 16
+    // consecutive rows cover all 64 banks) and every wave reads the chunks of ITS two chains from there; conversions stay in the matrix waves.
+    // Two LDS buffers, one barrier per K block: block b + 1 travels through registers (requested one block = ~4096 matrix-core cycles ahead)
+    // and is written behind the MFMAs of block b.  The staging buffers (68 KB) are re-used by the reduction tree of the epilogue (128 KB).
+    constexpr int GL_LD = 136;                                   // halfs per staged row
+    half_t * stg = reinterpret_cast<half_t *>(lds);              // [buffer][x | w][64][GL_LD]
+    const half_t * xsrc[2]; const half_t * wsrc[2]; int sdst[2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++) { const int c = threadIdx.x + 512 * i; sdst[i] = (c >> 4) * GL_LD + (c & 15) * 8; }
+    auto setup_tile = [&](int id) {
+        int trow, tcol;
+        panel_tile(xcd_rank(id, ntiles), nrow, ncol, pw, trow, tcol);      // XCD-aware tile order (device_utils.h)
+        n0 = trow * GEMM_TN; m0 = tcol * GEMM_TM;
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int c = threadIdx.x + 512 * i, row = c >> 4, ch = c & 15;
+            xsrc[i] = a.x_f16 + (size_t) min(n0 + row, a.N - 1) * K + ch * 8;
+            wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + ch * 8;
+        }
+    };
+    uint4 rx[2], rw[2];
+#define GL_FETCH(B) { _Pragma("unroll") for (int i = 0; i < 2; i++) { rx[i] = ld_u4(xsrc[i] + ((B) << 7)); rw[i] = ld_u4(wsrc[i] + ((B) << 7)); } }
+#define GL_STAGE(BUF) { half_t * d_ = stg + (BUF) * 2 * 64 * GL_LD;                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; i++) { *reinterpret_cast<uint4 *>(d_ + sdst[i]) = rx[i];                   \
+                                                        *reinterpret_cast<uint4 *>(d_ + 64 * GL_LD + sdst[i]) = rw[i]; } }
+    half8 xa0[2][2], wb0[2][2];
+#define GEMM_LOAD_BLOCK(XA, WB, BUF)                                                                     \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
-        const int koff = (((B) * 16 + 2 * w + s) << 3);                                                  \
+        const half_t * src_ = stg + (BUF) * 2 * 64 * GL_LD + ((2 * w + s) << 3);                          \
         _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                  \
-            XA[s][t] = ld_half8(a.x_f16 + (size_t) nrw[t] * K + koff);                                  \
-            WB[s][t] = ld_half8(a.W + (size_t) mrow[t] * K + koff);                                      \
+            XA[s][t] = *reinterpret_cast<const half8 *>(src_ + (t * 32 + l31) * GL_LD);                   \
+            WB[s][t] = *reinterpret_cast<const half8 *>(src_ + 64 * GL_LD + (t * 32 + l31) * GL_LD);      \
         }                                                                                                \
     }
 #define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
@@ -465,27 +485,34 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     }
     // lanes 32-63 feed the odd element of each f16 pair (the MFMA's second k slot): one per-lane shift selects it
     const unsigned sh16 = half ? 16u : 0u;
-    GEMM_LOAD_BLOCK(xa0, wb0, 0)
+    setup_tile(vb);
+    GL_FETCH(0)
+    while (true) {
+    #pragma unroll
+    for (int s = 0; s < 2; s++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++)
+        for (int r = 0; r < 16; r++) acc[s][i][j][r] = 0.0f;
+    GL_STAGE(0)
+    if (nblk > 1) GL_FETCH(1)
+    __syncthreads();
     int b = 0;
-    // NOTE (round 3, profiles/r03_exact_loops_branch_free.txt): hipcc places s_waitcnt per program point, so the conditional request of block
-    // b + 2 below makes the second half of a trip wait for vmcnt(0), i.e. for the loads it has just issued.  The branch-free form of this
-    // loop (steady state + guarded tail, waits of vmcnt(8) in both halves) measured SLOWER on the device - QKV 56 -> 66 us, FC 61 -> 72 us
-    // per launch, pass 3.50 -> 3.96 ms: the eight waves of a workgroup read the same 256-byte span of every operand row (16 bytes per
-    // chain), and only while they advance together does the second wave find the line in L1; with 16 loads in flight per wave they
-    // drift apart and every line travels from L2 up to eight times.  The loop stays as it is.
-    for (; b + 1 < nblk; b += 2) {
-        GEMM_LOAD_BLOCK(xa1, wb1, b + 1)
-        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+    // branch-free steady state (a conditional request would make hipcc wait for vmcnt(0) at the staging stores), guarded last blocks behind it
+    for (; b + 2 < nblk; b++) {
+        GEMM_LOAD_BLOCK(xa0, wb0, b & 1)
         GEMM_MFMA_BLOCK(xa0, wb0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (b + 2 < nblk) { GEMM_LOAD_BLOCK(xa0, wb0, b + 2) }
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_MFMA_BLOCK(xa1, wb1)
-        __builtin_amdgcn_sched_barrier(0);
+        GL_STAGE((b + 1) & 1)
+        GL_FETCH(b + 2)
+        __syncthreads();
     }
-    if (b < nblk) { GEMM_MFMA_BLOCK(xa0, wb0) }
-#undef GEMM_LOAD_BLOCK
-#undef GEMM_MFMA_BLOCK
+    for (; b < nblk; b++) {
+        GEMM_LOAD_BLOCK(xa0, wb0, b & 1)
+        GEMM_MFMA_BLOCK(xa0, wb0)
+        if (b + 1 < nblk) GL_STAGE((b + 1) & 1)
+        __syncthreads();
+    }
+    const int cn0 = n0, cm0 = m0;                               // the tile being finished
+    const int nvb = vb + (int) gridDim.x;
+    const bool more = nvb < ntiles;
+    if (more) { setup_tile(nvb); GL_FETCH(0) }                  // in flight during the epilogue
     // chain pair (2w, 2w+1) -> LDS; accumulator register r of lane l holds row (r&3)+8(r>>2)+4*half, col l31
     float * mine = lds + (size_t) w * (GEMM_TN * GEMM_TM);
     #pragma unroll
@@ -505,7 +532,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int idx4 = threadIdx.x + 512 * r;
-        nn[r] = n0 + (idx4 >> 4); mm[r] = m0 + ((idx4 & 15) << 2);
+        nn[r] = cn0 + (idx4 >> 4); mm[r] = cm0 + ((idx4 & 15) << 2);
         const bool ok = nn[r] < a.N && mm[r] < a.M;
         bias4[r] = (a.bias && ok) ? *reinterpret_cast<const float4 *>(a.bias + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
         res4[r] = (a.epi == EPI_RESID && ok) ? *reinterpret_cast<const float4 *>(a.res + (size_t) nn[r] * a.M + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
@@ -562,8 +589,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
             }
         }
     }
+    if (!more) break;
+    vb = nvb;
+    __syncthreads();                                            // every partial sum has been read: the staging buffers may be written again
+    }
+#undef GL_FETCH
+#undef GL_STAGE
+#undef GEMM_LOAD_BLOCK
+#undef GEMM_MFMA_BLOCK
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Lock-step decode product: y[slot][m] for up to 32 utterance slots at once, every weight read ONCE per step for all slots.
@@ -768,12 +802,13 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     if (a.fast == 1) { launch_linear_fast(s, a); return; }
     if (a.epi == EPI_QKV16) kernel_fail("bark-hip: the f16 QKV epilogue exists on the tolerance route only");
     const int ncol = (a.M + GEMM_TM - 1) / GEMM_TM, nrow = (a.N + GEMM_TN - 1) / GEMM_TN;
-    hipLaunchKernelGGL(gemm_kernel, dim3(ncol * nrow), dim3(512), 8 * GEMM_TN * GEMM_TM * sizeof(float), s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+    const int grid = std::min(ncol * nrow, std::max(8, n_cu / 8 * 8));                  // persistent: one workgroup per CU
+    hipLaunchKernelGGL(gemm_kernel, dim3(grid), dim3(512), GEMM_LDS_BYTES, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
 }
 
 void init_kernel_attributes() {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               8 * GEMM_TN * GEMM_TM * (int) sizeof(float));
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     init_attention_attributes();
     init_quant_attributes();
     init_fast_attributes();
