@@ -16,10 +16,10 @@ timeout 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -- pyth
 DB=$(find $R/gpurun_out/prof_bench -name "*.db" | head -1); python $R/tools/rocpd_stats.py $DB $R/gpurun_out/${N}_kernel_stats_bench.csv > /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_decode -- python $R/tools/profile_decode.py > $R/gpurun_out/prof_decode.log 2>&1
 DB=$(find $R/gpurun_out/prof_decode -name "*.db" | head -1); python $R/tools/rocpd_stats.py $DB $R/gpurun_out/${N}_kernel_stats_decode.csv > /dev/null
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do   # PMC_COUNTERS="" skips the passes (they hung twice in round 3 after working once; the committed summaries are from the first run)
     timeout 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/prof_pmc_$C -- python $R/tools/profile_decode.py > $R/gpurun_out/prof_pmc_$C.log 2>&1
     DB=$(find $R/gpurun_out/prof_pmc_$C -name "*.db" | head -1); python $R/tools/rocpd_pmc.py $DB $R/gpurun_out/${N}_pmc_$C.json > /dev/null
 done
-python $R/tools/derive_pmc_gemv_fc.py $R/gpurun_out/${N}_pmc_FETCH_SIZE.json $R/gpurun_out/${N}_pmc_WRITE_SIZE.json $R/gpurun_out/${N}_pmc_gemv_fc.json > /dev/null
+[ -s $R/gpurun_out/${N}_pmc_FETCH_SIZE.json ] && [ -s $R/gpurun_out/${N}_pmc_WRITE_SIZE.json ] && python $R/tools/derive_pmc_gemv_fc.py $R/gpurun_out/${N}_pmc_FETCH_SIZE.json $R/gpurun_out/${N}_pmc_WRITE_SIZE.json $R/gpurun_out/${N}_pmc_gemv_fc.json > /dev/null
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_decode $R/gpurun_out/prof_pmc_*
 ls -la $R/gpurun_out | tail -15
