@@ -506,7 +506,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             for (int b = 0; b < B; b++) {
                 if (!here[(size_t) b]) {                                 // finished (or empty) slot: park it at position 0
                     StepState idle = fresh_state(); idle.cur_token = 0;
-                    idle.step = w * p.sliding_window_size;          // same codebook parity as the live slots (slot 0's step selects the LM-head rows)
+                    // same codebook parity as the live slots DURING THE LOCK STEPS (slot 0's step selects the LM-head rows of every slot): in a
+                    // window whose first samples come from prompts (not from a lock step) the live slots have already taken one step by then
+                    idle.step = w * p.sliding_window_size + (all_single ? 0 : 1);
                     set_slot_state(c, b, idle);
                     continue;
                 }
