@@ -108,15 +108,20 @@ DEVINL void fast_tile_epilogue(const LinArgs & a, const floatx16 & acc, int tile
     }
 }
 
-template <int TN, int TM, int D>
-__global__ __launch_bounds__(256, 2) void gemm_f16_tile_kernel(const LinArgs a, const int ncol, const int nrow, const int pw) {
+// WM: waves along m (the waves form a 2 x WM grid: 4 or 8 per workgroup).  Eight waves (two workgroups per CU = four waves per SIMD) keep a SIMD's
+// matrix core fed while some of them sit at the per-step barrier or wait for LDS - the PMC pass of the four-wave kernel showed 46 - 57 % of
+// the wave cycles parked there.
+template <int TN, int TM, int D, int WM>
+__global__ __launch_bounds__(128 * WM, WM) void gemm_f16_tile_kernel(const LinArgs a, const int ncol, const int nrow, const int pw) {
     extern __shared__ __attribute__((aligned(16))) half_t lds_h[];
     half_t * As = lds_h;                                    // [2][TN][FT_LDK]
     half_t * Bs = lds_h + 2 * TN * FT_LDK;                  // [2][TM][FT_LDK]
-    constexpr int IT = TN / 64, JT = TM / 64;               // 32 x 32 MFMA tiles per wave and dimension (waves as 2 x 2)
-    constexpr int CA = TN / 32, CB = TM / 32;               // 16-byte chunks per thread and K step
+    constexpr int NT = 128 * WM;                            // threads
+    constexpr int IT = TN / 64, JT = TM / (32 * WM);        // 32 x 32 MFMA tiles per wave and dimension (waves as 2 x WM)
+    constexpr int CA = TN * 8 / NT, CB = TM * 8 / NT;       // 16-byte chunks per thread and K step
+    static_assert(JT >= 1 && CA >= 1 && CB >= 1, "tile too small for this many waves");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int wn = w >> 1, wm = w & 1;
+    const int wn = w / WM, wm = w % WM;
     int trow, tcol;
     panel_tile(xcd_rank(blockIdx.x, ncol * nrow), nrow, ncol, pw, trow, tcol);      // XCD-aware: consecutive ranks = a compact block of tiles
     const int n0 = trow * TN, m0 = tcol * TM;
@@ -125,13 +130,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_tile_kernel(const LinArgs a, 
     int adst[CA], bdst[CB];
     #pragma unroll
     for (int i = 0; i < CA; i++) {
-        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+        const int c = tid + NT * i, row = c >> 3, ch = c & 7;
         xsrc[i] = a.x_f16 + (size_t) min(n0 + row, a.N - 1) * K + ch * 8;
         adst[i] = row * FT_LDK + ch * 8;
     }
     #pragma unroll
     for (int i = 0; i < CB; i++) {
-        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+        const int c = tid + NT * i, row = c >> 3, ch = c & 7;
         wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + ch * 8;
         bdst[i] = row * FT_LDK + ch * 8;
     }
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_tile_kernel(const LinArgs a, 
           _Pragma("unroll") for (int i = 0; i < IT; i++)                                                     \
               _Pragma("unroll") for (int jj = 0; jj < JT; jj++) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[jj], acc[i][jj], 0, 0, 0); \
       } }
-    const int aoff = (wn * (TN / 2) + l31) * FT_LDK + half * 8, boff = (wm * (TM / 2) + l31) * FT_LDK + half * 8;
+    const int aoff = (wn * (TN / 2) + l31) * FT_LDK + half * 8, boff = (wm * (TM / WM) + l31) * FT_LDK + half * 8;
     #pragma unroll
     for (int j = 0; j < D - 1; j++) if (j < nkt) FT_FETCH(j, j)
     FT_STAGE(0, 0)
@@ -195,18 +200,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_tile_kernel(const LinArgs a, 
     const int n_past = (a.epi == EPI_QKV && a.st) ? a.st->n_past : 0;
     #pragma unroll
     for (int j = 0; j < JT; j++) {
-        const int m = m0 + wm * (TM / 2) + j * 32 + l31;
+        const int m = m0 + wm * (TM / WM) + j * 32 + l31;
         if (m >= a.M) continue;
         #pragma unroll
         for (int i = 0; i < IT; i++) fast_tile_epilogue(a, acc[i][j], n0 + wn * (TN / 2) + i * 32, half, m, n_past);
     }
 }
 
-template <int TN, int TM, int D>
+template <int TN, int TM, int D, int WM>
 static void launch_tile(hipStream_t s, const LinArgs & a) {
     const size_t lds = (size_t) 2 * (TN + TM) * FT_LDK * sizeof(half_t);
     const int ncol = (a.M + TM - 1) / TM, nrow = (a.N + TN - 1) / TN;
-    hipLaunchKernelGGL((gemm_f16_tile_kernel<TN, TM, D>), dim3(ncol * nrow), dim3(256), lds, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+    hipLaunchKernelGGL((gemm_f16_tile_kernel<TN, TM, D, WM>), dim3(ncol * nrow), dim3(128 * WM), lds, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
 }
 
 void launch_linear_fast(hipStream_t s, const LinArgs & a) {
@@ -214,7 +219,9 @@ void launch_linear_fast(hipStream_t s, const LinArgs & a) {
     if (a.epi == EPI_QKV16 && (!a.q16 || !a.k16 || !a.vt16 || a.seq <= 0 || (a.seq & 31) || a.N % a.seq)) kernel_fail("bark-hip: QKV16 epilogue needs whole sequences of a multiple of 32 rows");
     // three register sets (a tile is requested two K steps ahead): 1.34 / 1.12 / 1.12 ms per fine pass at D = 2 / 3 / 4 (profiles/r03_fine_ab_fast.txt)
     const long tiles128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (tiles128 >= 128) launch_tile<128, 128, 3>(s, a); else launch_tile<64, 64, 3>(s, a);
+    // 128 x 128 tiles: eight waves (2 x 4), four per SIMD with two workgroups per CU - 1.37 -> 1.01 ms per fine pass, 0.67 -> 0.50 ms per window
+    // with eight side by side against the four-wave form (profiles/r03_fine_ab_fast.txt); 64 x 64 tiles (fewer than 128 large tiles): four waves
+    if (tiles128 >= 128) launch_tile<128, 128, 3, 4>(s, a); else launch_tile<64, 64, 3, 2>(s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,7 +366,7 @@ void launch_attn_flash(hipStream_t s, const AttnFlashArgs & a) {
 
 void init_fast_attributes() {
     const int lds = 2 * (128 + 128) * FT_LDK * (int) sizeof(half_t);
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_tile_kernel<128, 128, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace barkhip
