@@ -77,13 +77,13 @@ DEVINL void fast_tile_epilogue(const LinArgs & a, const floatx16 & acc, int tile
             break;
         }
         case EPI_QKV16: {
-            // operands of attn_flash_f16_kernel: q (pre-scaled by 1/sqrt(64): exact in f16) and k as f16 rows [n][E]; v transposed
+            // operands of attn_flash_f16_kernel: q (pre-scaled by log2(e) / sqrt(64): the scores arrive in log2 units) and k as f16 rows [n][E]; v transposed
             // [sequence][E][seq] with the keys of each group of 16 in the order 0-3, 8-11, 4-7, 12-15 - registers 0..7 of a lane are then
             // 8 consecutive positions (one 16-byte store) and exactly the 8 key slots the lane feeds to the second product
             const int E = a.E;
             if (m < 2 * E) {
                 half_t * dst = m < E ? a.q16 + m : a.k16 + (m - E);
-                const float sc = m < E ? 0.125f : 1.0f;
+                const float sc = m < E ? 0.125f * 1.44269504088896340736f : 1.0f;
                 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int n = nb + (r & 3) + 8 * (r >> 2);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
     // running maximum in log2 units; it is raised lazily: while the block maximum stays below mrun + 8 the exponentials are formed
     // against the old maximum (at most 2^8: harmless in f32 and in the f16 operand) and the 32 accumulators are not rescaled
     float mrun = -INFINITY, lrun = 0.0f;
-    constexpr float L2E = 1.44269504088896340736f, LAZY = 8.0f;
+    constexpr float LAZY = 8.0f;
     // NB register sets: key block b travels in set b % NB and is requested NB - 1 blocks ahead (the operands were written by the
     // previous kernel on other XCDs: every request goes to the memory side)
     half8 kr[NB][4], vr[NB][2][2];
@@ -268,13 +268,15 @@ __global__ __launch_bounds__(64 * KS) void attn_flash_f16_kernel(const AttnFlash
         for (int r = 0; r < 16; r++) sc[r] = 0.0f;
         #pragma unroll
         for (int s = 0; s < 4; s++) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kk_[s], qf[s], sc, 0, 0, 0);
-        float t2[16];
+        float t2[16];                                                   // scores in log2 units (q carries log2(e) / 8)
         #pragma unroll
-        for (int r = 0; r < 16; r++) t2[r] = sc[r] * L2E;
+        for (int r = 0; r < 16; r++) t2[r] = sc[r];
         float mx = fmaxf(fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3])), fmaxf(fmaxf(t2[4], t2[5]), fmaxf(t2[6], t2[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(t2[8], t2[9]), fmaxf(t2[10], t2[11])), fmaxf(fmaxf(t2[12], t2[13]), fmaxf(t2[14], t2[15]))));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // the two halves of a query exchange their maxima only when one of them outgrows the running maximum (mrun is the same in both halves
+        // at all times): the cross-lane round trip is off the common path
         if (__builtin_amdgcn_ballot_w64(mx > mrun + LAZY) != 0) {       // some query of the wave needs a new maximum (rare after the first blocks)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(mrun, mx);
             const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
             lrun *= alpha;
