@@ -37,5 +37,5 @@ for p in "${pids[@]}"; do wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libbark.so" "${OBJS[@]}"
 echo "built $OUT/libbark.so"
 # native batching HTTP front end (examples/batch_server.cpp): same protocol as the reference's example server, requests travel as lock-step batches
-g++ -O2 -std=c++17 -Wall -I"$HERE/../include" "$HERE/examples/batch_server.cpp" -L"$OUT" -lbark -lpthread -Wl,-rpath,'$ORIGIN' -o "$OUT/bark_batch_server"
+g++ -O2 -std=c++17 -Wall -I"$HERE/../include" -I"$HERE/examples" "$HERE/examples/batch_server.cpp" -L"$OUT" -lbark -lpthread -Wl,-rpath,'$ORIGIN' -o "$OUT/bark_batch_server"
 echo "built $OUT/bark_batch_server"

@@ -10,6 +10,7 @@
 //   bark_batch_server -m model.bin [-a 127.0.0.1] [-p 1337] [-s seed] [--max-batch 32] [--max-wait-ms 5] [--temp t] [--fine-temp t]
 #include "bark.h"
 #include "bark_mi355x.h"
+#include "http_util.h"
 
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -26,6 +27,8 @@
 #include <vector>
 
 namespace {
+
+using barkhttp::json_string; using barkhttp::json_uint; using barkhttp::wav_f32;
 
 struct Options {
     std::string model, host = "127.0.0.1";
@@ -47,66 +50,6 @@ void respond(int fd, int status, const char * reason, const char * type, const s
     char head[256];
     const int n = snprintf(head, sizeof(head), "HTTP/1.1 %d %s\r\nContent-Type: %s\r\nContent-Length: %zu\r\nConnection: close\r\n\r\n", status, reason, type, body.size());
     if (send_all(fd, head, (size_t) n)) send_all(fd, body.data(), body.size());
-}
-
-// the string value of `key` in a flat JSON object (escapes \" \\ \/ \n \t \r \b \f and \uXXXX below 0x80 are decoded; that is all a prompt needs)
-bool json_string(const std::string & js, const char * key, std::string & out) {
-    const std::string pat = std::string("\"") + key + "\"";
-    size_t p = js.find(pat);
-    if (p == std::string::npos) return false;
-    p = js.find(':', p + pat.size());
-    if (p == std::string::npos) return false;
-    p = js.find('"', p);
-    if (p == std::string::npos) return false;
-    out.clear();
-    for (size_t i = p + 1; i < js.size(); i++) {
-        const char ch = js[i];
-        if (ch == '"') return true;
-        if (ch != '\\') { out.push_back(ch); continue; }
-        if (++i >= js.size()) return false;
-        switch (js[i]) {
-            case 'n': out.push_back('\n'); break;
-            case 't': out.push_back('\t'); break;
-            case 'r': out.push_back('\r'); break;
-            case 'b': out.push_back('\b'); break;
-            case 'f': out.push_back('\f'); break;
-            case 'u': {
-                if (i + 4 >= js.size()) return false;
-                const unsigned cp = (unsigned) strtoul(js.substr(i + 1, 4).c_str(), nullptr, 16);
-                i += 4;
-                if (cp < 0x80) out.push_back((char) cp);
-                else if (cp < 0x800) { out.push_back((char) (0xC0 | (cp >> 6))); out.push_back((char) (0x80 | (cp & 0x3F))); }
-                else { out.push_back((char) (0xE0 | (cp >> 12))); out.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); out.push_back((char) (0x80 | (cp & 0x3F))); }
-                break;
-            }
-            default: out.push_back(js[i]); break;            // \" \\ \/
-        }
-    }
-    return false;
-}
-bool json_uint(const std::string & js, const char * key, uint32_t & out) {
-    const std::string pat = std::string("\"") + key + "\"";
-    size_t p = js.find(pat);
-    if (p == std::string::npos) return false;
-    p = js.find(':', p + pat.size());
-    if (p == std::string::npos) return false;
-    p++;
-    while (p < js.size() && (js[p] == ' ' || js[p] == '\t')) p++;
-    if (p >= js.size() || js[p] < '0' || js[p] > '9') return false;
-    out = (uint32_t) strtoul(js.c_str() + p, nullptr, 10);
-    return true;
-}
-
-std::string wav_f32(const float * pcm, int n, int rate) {
-    auto u32 = [](std::string & s, uint32_t v) { s.append(reinterpret_cast<const char *>(&v), 4); };
-    auto u16 = [](std::string & s, uint16_t v) { s.append(reinterpret_cast<const char *>(&v), 2); };
-    std::string s;
-    const uint32_t bytes = (uint32_t) n * 4;
-    s += "RIFF"; u32(s, 36 + bytes); s += "WAVE";
-    s += "fmt "; u32(s, 16); u16(s, 3 /* IEEE float */); u16(s, 1); u32(s, (uint32_t) rate); u32(s, (uint32_t) rate * 4); u16(s, 4); u16(s, 32);
-    s += "data"; u32(s, bytes);
-    s.append(reinterpret_cast<const char *>(pcm), bytes);
-    return s;
 }
 
 std::atomic<uint32_t> next_seed{0};
