@@ -272,7 +272,7 @@ class BarkContext:
 
     def coarse(self, semantic) -> np.ndarray:
         sem = _i32(semantic)
-        p = self._params                                # T = floor(n_sem * coarse_rate / semantic_rate) with the context's own rates
+        p = self._params if self._params is not None else default_params()      # T = floor(n_sem * coarse_rate / semantic_rate) with the context's own rates
         cap = int(len(sem) * max(p.coarse_rate_hz, 1e-3) / max(p.semantic_rate_hz, 1e-3)) + 8
         out = np.zeros((cap, 2), np.int32)
         T = self._lib.bark_hip_coarse(self._h, sem.ctypes.data, len(sem), out.ctypes.data, cap)
@@ -350,7 +350,10 @@ class BarkContext:
         h = self._lib.bark_hip_clone_context(self._h, seed)
         if not h:
             raise RuntimeError("bark_hip_clone_context failed")
-        return BarkContext(h, self._lib)
+        ctx = BarkContext(h, self._lib)
+        ctx._cb = self._cb                              # the clone copies the parameters (and the callback pointer) of its source
+        ctx._params = self._params
+        return ctx
 
     @staticmethod
     def generate_audio_batch(ctxs, texts) -> int:
@@ -419,9 +422,22 @@ class Batcher:
 
     def __init__(self, ctx: "BarkContext", max_batch: int = 32, max_wait_ms: int = 2):
         self._lib = ctx._lib
+        self._ctx = ctx                                 # the worker thread runs on this context: it must outlive the batcher
         self._b = self._lib.bark_hip_batcher_create(ctx._h, max_batch, max_wait_ms)
         if not self._b:
             raise RuntimeError("bark_hip_batcher_create failed")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
     def submit(self, text: str, seed: int = 0) -> int:
         t = self._lib.bark_hip_batcher_submit(self._b, text.encode("utf-8"), seed)
@@ -448,3 +464,4 @@ class Batcher:
         if self._b:
             self._lib.bark_hip_batcher_free(self._b)
             self._b = None
+        self._ctx = None
