@@ -12,6 +12,7 @@
 #include "model_file.h"
 #include "tokenizer.h"
 
+#include <map>
 #include <memory>
 #include <random>
 #include <string>
@@ -120,7 +121,8 @@ struct bark_context {
         float * sc = nullptr;                            // [cap][max_H][P] attention scores of a lock step (scores kernel -> mix kernel)
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
-        hipGraphExec_t graph[2] = {nullptr, nullptr}; int graph_B[2] = {0, 0};
+        float * slot_par = nullptr; std::vector<float> h_slot_par;   // the slots' own temperatures [cap] and min_eos_p [cap] (bark_hip_request_params), host mirror
+        std::map<int, hipGraphExec_t> graphs;            // captured lock steps by (model, active slots, kinds of sampling)
         // window prompts of all slots in ONE pass (batch_prefill_many): row scratch for cap * P rows, the prompts' ids, the sequence table
         float * pf_x = nullptr, * pf_q = nullptr; barkhip::half_t * pf_xn = nullptr, * pf_att = nullptr, * pf_h = nullptr;
         int32_t * pf_tokens = nullptr; barkhip::SeqTab * pf_tab = nullptr;

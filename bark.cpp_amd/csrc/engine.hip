@@ -34,6 +34,12 @@ float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
 float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.kv_layer_stride * (size_t) l : nullptr; }
 
+// BARK_HIP_CROSSCHECK bit 8 (256) keeps the fine model on the C1 chains of the f32 matrix cores (gemm_kernel) - the order of rounds 1 - 3, which the
+// oracle reproduces with set_fine_mfma(False)
+bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool causal) {
+    return !causal && &m == &c->gpt[2] && !m.q4 && !m.w32 && (m.hp.n_embd & 63) == 0 && !(crosscheck_mask() & 256);
+}
+
 RowBufs own_rows(bark_context * c) {
     RowBufs r; r.x = c->x; r.q = c->q; r.xn = c->xn; r.att = c->att; r.hbuf = c->hbuf; r.q16 = c->q16; r.k16 = c->k16; r.vt16 = c->vt16;
     r.logits = c->logits; r.tokens = c->d_tokens; r.plane = 1024;
@@ -48,9 +54,11 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     const RowBufs own = own_rows(c);
     const RowBufs & rb = rbp ? *rbp : own;
     if (rbp && (m.q4 || m.w32)) throw std::runtime_error("row scratch other than the context's own: f16 model files only");
-    const int fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
+    // fine model, f16 file: the products run on the f16 matrix cores, whose accumulation IS the canonical order of that model (C1m: stated in
+    // oracle/mfma_f16_emu.h from device probes; the fine model never shares a row with a decode step, so the other models keep C1)
+    const int fast = fine_products_on_f16_mfma(c, m, causal) ? 1 : (!m.q4 && !m.w32) ? c->fast_gemm : 0;
     const int Z = seq > 0 ? N / seq : 1;
-    const bool flash = fast && !causal && pos0 == 0 && N % 1024 == 0 && (seq == 0 || seq == 1024) && (rbp || (!kbase && !vbase)) && rb.q16 && E % 64 == 0;
+    const bool flash = c->fast_gemm && fast && !causal && pos0 == 0 && N % 1024 == 0 && (seq == 0 || seq == 1024) && (rbp || (!kbase && !vbase)) && rb.q16 && E % 64 == 0;
     // kbase / vbase: another utterance slot's cache (batched decode) or the fine batch's; default: the context's own cache
     auto layer_k = [&](const GptModel & mm, int l) { return (kbase ? kbase : mm.kcache) + mm.kv_layer_stride * (size_t) l; };
     auto layer_v = [&](const GptModel & mm, int l) { return (vbase ? vbase : mm.vcache) + mm.kv_layer_stride * (size_t) l; };
@@ -380,7 +388,7 @@ void run_fine_forward(bark_context * c, int nn, int n_rows, const RowBufs * rbp,
     else           launch_ln_rows(c->stream, rb.x, N, E, m.lnf_g, m.lnf_b, rb.xn);
     LinArgs a;
     a.W = m.lm_head[nn - 1]; a.wq = m.lm_head_q[nn - 1]; a.xq = c->xq; if (m.w32) a.x_f32 = c->xn32; a.M = n_rows; a.K = E; a.N = N; a.x_f16 = rb.xn; a.epi = EPI_LOGITS; a.out = rb.logits; a.ld_out = n_rows;
-    a.fast = (!m.q4 && !m.w32) ? c->fast_gemm : 0;
+    a.fast = fine_products_on_f16_mfma(c, m, false) ? 1 : (!m.q4 && !m.w32) ? c->fast_gemm : 0;
     launch_linear(c->stream, a);                           // lm_heads[codebook_idx - n_codes_given], bark.cpp:1573
 }
 }  // namespace detail

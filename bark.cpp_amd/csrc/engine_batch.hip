@@ -49,7 +49,38 @@ void ensure_batch(bark_context * c, int B) {
     bb.u = dev_alloc<double>(c, (size_t) B * 8192);
     bb.sc = dev_alloc<float>(c, (size_t) B * c->max_H * c->P);
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
+    bb.slot_par = dev_alloc<float>(c, (size_t) 2 * B);               // [0, B): temperatures, [B, 2 B): min_eos_p
+    bb.h_slot_par.assign((size_t) 2 * B, 0.0f);
     bb.cap = B;
+}
+
+// the slots' own sampling parameters (bark_hip_request_params): host mirror -> device
+void upload_slot_params(bark_context * c) {
+    bark_context::Batch & bb = c->batch;
+    HIP_OK(hipMemcpyAsync(bb.slot_par, bb.h_slot_par.data(), bb.h_slot_par.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+// 1: greedy slots among [slot0, slot0 + n), 2: sampled slots among them
+int slot_kinds(const bark_context * c, int slot0, int n) {
+    int k = 0;
+    for (int b = slot0; b < slot0 + n; b++) k |= c->batch.h_slot_par[(size_t) b] > 0.0f ? 2 : 1;
+    return k;
+}
+// the sampler's arguments for slots [slot0, slot0 + nb) of the batch
+SampleArgs slot_sample_args(bark_context * c, const StageCfg & s, const bark_context::Batch & bb, int slot0, int nb, int n_past_add) {
+    const GptModel & m = c->gpt[s.which];
+    SampleArgs sa;
+    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
+    sa.logits = bb.logits + bb.ld_logits * (size_t) slot0; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
+    sa.token_base = s.token_base; sa.n_past_add = n_past_add; sa.out_tokens = bb.out_tokens + (size_t) slot0 * 2048;
+    sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot0 * 2048 : nullptr;
+    sa.st = bb.state + slot0; sa.nbatch = nb; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
+    sa.temp = s.temp; sa.u = bb.u + (size_t) slot0 * 8192; sa.u_stride = 8192;
+    // bb.slot_par belongs to the context's own batch (slot_view copies share it): slot b's entries sit at [b] and [cap + b]
+    sa.slot_temp = c->batch.slot_par + slot0; sa.slot_min_eos_p = s.mode == 0 ? c->batch.slot_par + c->batch.cap + slot0 : nullptr;
+    sa.kinds = slot_kinds(c, (int) (bb.state - c->batch.state) + slot0, nb);
+    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot0 * m.hp.n_embd;
+    return sa;
 }
 
 void set_slot_state(bark_context * c, int slot, const StepState & st) {
@@ -128,31 +159,26 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
     product(h, m.lnf_g, m.lnf_b);
-    SampleArgs sa;
-    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
-    sa.logits = bb.logits; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
-    sa.token_base = s.token_base; sa.n_past_add = 1; sa.out_tokens = bb.out_tokens; sa.eos_trace = s.mode == 0 ? bb.eos_trace : nullptr;
-    sa.st = bb.state; sa.nbatch = B; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
-    sa.temp = s.temp; sa.u = bb.u; sa.u_stride = 8192;
-    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x;
-    launch_sample_greedy(st, sa);
+    launch_sample_greedy(st, slot_sample_args(c, s, bb, 0, B, 1));
 }
 
 void batch_step(bark_context * c, const StageCfg & s, int B) {
     bark_context::Batch & bb = c->batch;
     if (c->use_graph) {
-        if (bb.graph[s.which] && bb.graph_B[s.which] != B) { (void) hipGraphExecDestroy(bb.graph[s.which]); bb.graph[s.which] = nullptr; }
-        if (!bb.graph[s.which]) {
+        // one captured lock step per (model, active slots, kinds of sampling among them); a batch that shrinks slot by slot meets each
+        // size once per context (the executables are kept)
+        const int key = s.which | (B << 1) | (slot_kinds(c, 0, B) << 12);
+        hipGraphExec_t & exec = bb.graphs[key];
+        if (!exec) {
             hipGraph_t graph = nullptr;
             HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             try { enqueue_batch_step(c, s, B, bb); }
             catch (...) { hipGraph_t g2 = nullptr; (void) hipStreamEndCapture(c->stream, &g2); if (g2) (void) hipGraphDestroy(g2); throw; }
             HIP_OK(hipStreamEndCapture(c->stream, &graph));
-            HIP_OK(hipGraphInstantiate(&bb.graph[s.which], graph, nullptr, nullptr, 0));
+            HIP_OK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             (void) hipGraphDestroy(graph);
-            bb.graph_B[s.which] = B;
         }
-        HIP_OK(hipGraphLaunch(bb.graph[s.which], c->stream));
+        HIP_OK(hipGraphLaunch(exec, c->stream));
         c->stats.graph_replays++;
     } else {
         enqueue_batch_step(c, s, B, bb);
@@ -167,7 +193,7 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
     v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
     if (v.att32) { v.att32 += E * b; v.h32 += 4 * E * b; }
     v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b; v.u += (size_t) b * 8192;
-    v.graph[0] = v.graph[1] = nullptr;
+    v.graphs.clear(); v.h_slot_par.clear();
     return v;
 }
 void embed_slot(bark_context * c, const StageCfg & s, int b) {
@@ -205,14 +231,7 @@ void batch_prefill_and_sample(bark_context * c, const StageCfg & s, int slot, co
     h.x_f32 = c->x + (size_t) (N - 1) * m.hp.n_embd; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
     h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
     launch_linear(c->stream, h);
-    SampleArgs sa;
-    { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
-    sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
-    sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
-    sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
-    sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
-    sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot * m.hp.n_embd;
-    launch_sample_greedy(c->stream, sa);
+    launch_sample_greedy(c->stream, slot_sample_args(c, s, bb, slot, 1, N));
 }
 
 
@@ -270,14 +289,7 @@ void batch_prefill_many(bark_context * c, const StageCfg & s, const std::vector<
         h.x_f32 = bb.pf_x + ((size_t) z * seq + (size_t) (N - 1)) * E; h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.epi = EPI_LOGITS;
         h.out = bb.logits + bb.ld_logits * (size_t) slot; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state + slot;
         launch_linear(st, h);
-        SampleArgs sa;
-        { static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0; sa.force_exact = force_exact; }
-        sa.logits = bb.logits + bb.ld_logits * (size_t) slot; sa.n = s.lm_rows; sa.mode = s.mode; sa.min_eos_p = s.min_eos_p; sa.eos_token = s.eos_token;
-        sa.token_base = s.token_base; sa.n_past_add = N; sa.out_tokens = bb.out_tokens + (size_t) slot * 2048;
-        sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot * 2048 : nullptr; sa.st = bb.state + slot;
-        sa.temp = s.temp; sa.u = bb.u + (size_t) slot * 8192;
-        sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = E; sa.n_in = m.hp.n_in_vocab; sa.P = P; sa.x = bb.x + (size_t) slot * E;
-        launch_sample_greedy(st, sa);
+        launch_sample_greedy(st, slot_sample_args(c, s, bb, slot, 1, N));
     }
     HIP_OK(hipStreamSynchronize(st));                           // tok / tab / sts are stack objects
 }

@@ -55,6 +55,7 @@ float * layer_vt(const GptModel & m, int l);
 // the many-row scratch a forward pass works in: the context's own (P rows), or the fine batch's (several windows back to back)
 struct RowBufs { float * x, * q; half_t * xn, * att, * hbuf, * q16, * k16, * vt16; float * logits; const int32_t * tokens; int plane; };
 RowBufs own_rows(bark_context * c);
+bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool causal);
 // seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
                      const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0, const SeqTab * seqtab = nullptr);

@@ -189,6 +189,10 @@ struct SampleArgs {
     int n_past_add = 1;                    // rows the evaluated step appended to the KV cache (prefill: N)
     int32_t * out_tokens = nullptr; float * eos_trace = nullptr; StepState * st = nullptr;
     int nbatch = 1; int ld_logits = 0; int out_stride = 0;   // batched decode: slot b reads logits + b*ld_logits, writes out_tokens + b*out_stride, x + b*E
+    // lock-step batches whose utterances carry their own parameters: slot b samples with slot_temp[b] (0: greedy) and stops on slot_min_eos_p[b].
+    // With slot_temp set the launch runs the greedy kernel for the slots with temperature 0 and / or the multinomial kernel for the others
+    // (`kinds`: 1 greedy slots present, 2 sampled slots present); a kernel leaves the other kind's slots untouched.
+    const float * slot_temp = nullptr; const float * slot_min_eos_p = nullptr; int kinds = 0;
     // embedding of the sampled token for the NEXT decode step, written by the same kernel (x == nullptr: skip)
     const half_t * wte = nullptr; const float * wpe = nullptr; int E = 0, n_in = 0, P = 1024; float * x = nullptr;
     QMat wte_q;
@@ -211,6 +215,8 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 //  32  lock-step batches: the decode attention always as one workgroup per (head, slot) (attn_fused_kernel), also above 256 pairs
 //  64  lock-step batches: the decode attention always as the scores / mix pair of launches, also below 256 (head, slot) pairs
 // 128  lock-step batches: the LayerNorm of the slot rows as a launch of its own in front of the QKV / FC / LM-head products instead of inside them
+// 256  fine model: products as C1 chains on the f32 matrix cores (the canonical order of rounds 1 - 3) instead of C1m on the f16 matrix cores;
+//      the oracle follows with set_fine_mfma(False)
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();

@@ -794,12 +794,12 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         return;
     }
     if (a.x_f32 || a.parity_rows) { kernel_fail("bark-hip: batched linear op needs f16 rows"); }
+    if (a.fast == 1) { launch_linear_fast(s, a); return; }          // f16 matrix cores: the fine model's canonical order C1m, or the tolerance route
     if (crosscheck_mask() & 1) {
         dim3 grid((a.M + 15) / 16, a.N), block(256);
         hipLaunchKernelGGL((gemv_rows_kernel<32>), grid, block, 0, s, a);
         return;
     }
-    if (a.fast == 1) { launch_linear_fast(s, a); return; }
     if (a.epi == EPI_QKV16) kernel_fail("bark-hip: the f16 QKV epilogue exists on the tolerance route only");
     const int ncol = (a.M + GEMM_TM - 1) / GEMM_TM, nrow = (a.N + GEMM_TN - 1) / GEMM_TN;
     static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     __shared__ float e_all[12288];                             // exact path only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x;                               // sequence slot (batched decode); 0 otherwise
+    if (a.slot_temp && a.slot_temp[slot] > 0.0f) return;       // a sampled slot of a mixed batch: sample_multinomial_kernel's
+    const float min_eos_p = a.slot_min_eos_p ? a.slot_min_eos_p[slot] : a.min_eos_p;
     const float * logits = logits0 + (size_t) slot * ld_logits;
     StepState * st = st0 + slot;
     // everything the end of the kernel needs from memory is requested now: the stage state, and the position row of the next
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     bool exact = a.force_exact || close > 1;
     if (a.mode == 0) {
         eos_p = (float) exp((double) (last_logit - mx)) / sum;
-        if (fabsf(eos_p - a.min_eos_p) <= kEosBand * a.min_eos_p) exact = true;
+        if (fabsf(eos_p - min_eos_p) <= kEosBand * min_eos_p) exact = true;
     }
     if (exact) {                                               // uniform: the reference's arithmetic, literally
         #pragma unroll
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     if (tid == 0) {
         if (a.mode == 0) {
             // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
-            if ((tok == a.eos_token || eos_p >= a.min_eos_p) && s0.eos_step == INT32_MAX) st->eos_step = step;
+            if ((tok == a.eos_token || eos_p >= min_eos_p) && s0.eos_step == INT32_MAX) st->eos_step = step;
             if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = eos_p;
         }
         if (exact) st->near_tie = s0.near_tie + 1;            // samples settled by the exact path
@@ -348,6 +350,9 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     __shared__ int next_tok, next_pos;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x;
+    if (a.slot_temp && !(a.slot_temp[slot] > 0.0f)) return;    // a greedy slot of a mixed batch: sample_greedy_kernel's
+    const float temp = a.slot_temp ? a.slot_temp[slot] : a.temp;
+    const float min_eos_p = a.slot_min_eos_p ? a.slot_min_eos_p[slot] : a.min_eos_p;
     const float * logits = a.logits + (size_t) slot * a.ld_logits;
     StepState * st = a.st + slot;
     const int step = st->step;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int i = tid * CH + k;
-        pv[k] = i < a.n ? logits[i] / a.temp : -INFINITY;
+        pv[k] = i < a.n ? logits[i] / temp : -INFINITY;
         mx = fmaxf(mx, pv[k]);
     }
     mx = wave_max(mx);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
         float ep = 0.0f;
         if (a.mode == 0) {
             ep = red_f[0];                                      // probability of the LAST logit (bark.cpp:217-218)
-            if ((tok == a.eos_token || ep >= a.min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
+            if ((tok == a.eos_token || ep >= min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
             if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = ep;
         } else {
             tok += a.token_base + ((step & 1) ? 1024 : 0);
@@ -482,6 +487,11 @@ void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld,
 
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
     if (a.x && a.E > 1024) kernel_fail("bark-hip: the sampler writes the next token's embedding with one thread per element (n_embd <= 1024)");
+    if (a.slot_temp) {
+        if (a.kinds & 1) hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a.logits, a.st, a.n, a.ld_logits, a);
+        if (a.kinds & 2) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
+        return;
+    }
     if (a.temp > 0.0f) hipLaunchKernelGGL(sample_multinomial_kernel, dim3(a.nbatch), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a.logits, a.st, a.n, a.ld_logits, a);
 }

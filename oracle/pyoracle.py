@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "build", "libbark_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "bark_oracle.cpp")):
+    srcs = [os.path.join(_HERE, f) for f in ("bark_oracle.cpp", "mfma_f16_emu.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
@@ -47,6 +48,7 @@ class Oracle:
         lib.orc_close.argtypes = [C.c_void_p]
         lib.orc_set_numerics.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_set_dot_order.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_set_fine_mfma.argtypes = [C.c_void_p, C.c_int]
         lib.orc_seed.argtypes = [C.c_void_p, C.c_uint32]
         lib.orc_gelu_table.restype = C.POINTER(C.c_uint16)
         lib.orc_gelu_table.argtypes = [C.c_void_p]
@@ -84,6 +86,10 @@ class Oracle:
     def set_dot_order(self, order: int = 0):
         """0 canonical (what the engine reproduces), 1 ggml's AVX2 order, 2 one sequential chain - study modes (Numerics::dot_order)."""
         self.lib.orc_set_dot_order(self.h, int(order))
+
+    def set_fine_mfma(self, on: bool = True):
+        """The fine model's weight products in the f16 matrix cores' order (default, what the engine computes) or as C1 chains (Numerics::fine_mfma)."""
+        self.lib.orc_set_fine_mfma(self.h, int(on))
 
     def seed(self, s: int):
         self.lib.orc_seed(self.h, s)
