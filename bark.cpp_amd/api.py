@@ -32,6 +32,11 @@ class BarkContextParams(C.Structure):
     ]
 
 
+class BarkHipRequestParams(C.Structure):
+    """struct bark_hip_request_params (bark_mi355x.h): what an utterance of a lock-step job may set for itself."""
+    _fields_ = [("temp", C.c_float), ("fine_temp", C.c_float), ("min_eos_p", C.c_float), ("n_steps_text_encoder", C.c_int32), ("seed", C.c_uint32)]
+
+
 class BarkHipStats(C.Structure):
     _fields_ = [
         ("t_load_us", C.c_int64), ("t_eval_us", C.c_int64), ("t_semantic_us", C.c_int64), ("t_coarse_us", C.c_int64),
@@ -68,9 +73,9 @@ EXPORTS = [
     # bark_mi355x.h
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
-    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
+    "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_generate_batch_ex", "bark_hip_reserve_batch", "bark_hip_profile_lock_step", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe",
-    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_free",
+    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_free",
 ]
 
 
@@ -116,6 +121,9 @@ def load_library() -> C.CDLL:
     lib.bark_hip_codec_tap.argtypes = [vp, ip, C.c_int, C.c_int, C.c_int, fp, C.c_int]
     lib.bark_hip_generate_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
     lib.bark_hip_generate_batch_seeded.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint32)]
+    lib.bark_hip_generate_batch_ex.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(BarkHipRequestParams)]
+    lib.bark_hip_reserve_batch.argtypes = [vp, C.c_int]
+    lib.bark_hip_profile_lock_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.bark_hip_batch_audio.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float))]
     lib.bark_hip_batch_tokens.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
     lib.bark_hip_clone_context.restype = vp
@@ -137,6 +145,8 @@ def load_library() -> C.CDLL:
     lib.bark_hip_batcher_create.argtypes = [vp, C.c_int, C.c_int]
     lib.bark_hip_batcher_submit.restype = C.c_int64
     lib.bark_hip_batcher_submit.argtypes = [vp, C.c_char_p, C.c_uint32]
+    lib.bark_hip_batcher_submit_ex.restype = C.c_int64
+    lib.bark_hip_batcher_submit_ex.argtypes = [vp, C.c_char_p, C.POINTER(BarkHipRequestParams)]
     lib.bark_hip_batcher_wait.argtypes = [vp, C.c_int64, fp, C.c_int]
     lib.bark_hip_batcher_stats.restype = None
     lib.bark_hip_batcher_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -320,11 +330,27 @@ class BarkContext:
             raise RuntimeError("bark_hip_codec_tap failed")
         return out[:n].copy()
 
-    def generate_batch(self, texts, seeds=None) -> list:
-        """In-engine batching (bark_hip_generate_batch[_seeded]): returns one dict per utterance (or None if it failed)."""
+    def request_params(self, **over) -> BarkHipRequestParams:
+        """The context's own values of the per-utterance parameters, with overrides (temp, fine_temp, min_eos_p, n_steps_text_encoder, seed)."""
+        p = self._params if self._params is not None else default_params()
+        r = BarkHipRequestParams(p.temp, p.fine_temp, p.min_eos_p, p.n_steps_text_encoder, 0)
+        for k, v in over.items():
+            setattr(r, k, v)
+        return r
+
+    def reserve_batch(self, slots: int):
+        if self._lib.bark_hip_reserve_batch(self._h, slots) != 0:
+            raise RuntimeError("bark_hip_reserve_batch failed")
+
+    def generate_batch(self, texts, seeds=None, params=None) -> list:
+        """In-engine batching (bark_hip_generate_batch[_seeded|_ex]): returns one dict per utterance (or None if it failed).
+        params: one BarkHipRequestParams per utterance (request_params(...))."""
         n = len(texts)
         ts = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
-        if seeds is None:
+        if params is not None:
+            assert len(params) == n and seeds is None
+            good = self._lib.bark_hip_generate_batch_ex(self._h, ts, n, (BarkHipRequestParams * n)(*params))
+        elif seeds is None:
             good = self._lib.bark_hip_generate_batch(self._h, ts, n)
         else:
             assert len(seeds) == n
@@ -404,6 +430,15 @@ class BarkContext:
             raise RuntimeError("bark_hip_time_slots failed")
         return us
 
+    def profile_lock_step(self, which: int, n_slots: int, ctx: int, reps: int = 20) -> list:
+        """[{"site", "us"}] per launch site of one lock step in launch order (kernel + the gap in front), closed by the graph-replayed step."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        n = self._lib.bark_hip_profile_lock_step(self._h, which, n_slots, ctx, reps, buf, len(buf))
+        if n < 0:
+            raise RuntimeError("bark_hip_profile_lock_step failed")
+        return json.loads(buf.value.decode())
+
     def time_fine_pass(self, iters: int, n_windows: int = 1):
         """us per forward pass of the fine model over n_windows windows side by side, flops of that pass"""
         f = C.c_double(0)
@@ -439,8 +474,11 @@ class Batcher:
         except Exception:
             pass
 
-    def submit(self, text: str, seed: int = 0) -> int:
-        t = self._lib.bark_hip_batcher_submit(self._b, text.encode("utf-8"), seed)
+    def submit(self, text: str, seed: int = 0, params: "BarkHipRequestParams | None" = None) -> int:
+        if params is not None:
+            t = self._lib.bark_hip_batcher_submit_ex(self._b, text.encode("utf-8"), C.byref(params))
+        else:
+            t = self._lib.bark_hip_batcher_submit(self._b, text.encode("utf-8"), seed)
         if t <= 0:
             raise RuntimeError("bark_hip_batcher_submit failed")
         return t

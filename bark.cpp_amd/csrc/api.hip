@@ -258,6 +258,32 @@ int bark_hip_generate_batch_seeded(struct bark_context * bctx, const char * cons
     for (int i = 0; i < n; i++) if (!texts[i]) return -1;
     return guarded("bark_hip_generate_batch_seeded", -1, [&] { return engine_generate_batch(bctx, texts, n, seeds); });
 }
+int bark_hip_generate_batch_ex(struct bark_context * bctx, const char * const * texts, int n, const struct bark_hip_request_params * per_utterance) {
+    if (!bctx || !texts || !per_utterance || n <= 0) return -1;
+    for (int i = 0; i < n; i++) if (!texts[i]) return -1;
+    return guarded("bark_hip_generate_batch_ex", -1, [&] { return engine_generate_batch(bctx, texts, n, nullptr, per_utterance); });
+}
+int bark_hip_profile_lock_step(struct bark_context * bctx, int which, int n_slots, int ctx, int reps, char * json_out, int capacity) {
+    if (!bctx || !json_out || capacity < 2) return -1;
+    return guarded("bark_hip_profile_lock_step", -1, [&] {
+        std::vector<std::pair<std::string, double>> tl;
+        engine_profile_lock_step(bctx, which, n_slots, ctx, reps, tl);
+        std::string js = "[";
+        for (size_t i = 0; i < tl.size(); i++) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "%s{\"site\": \"%s\", \"us\": %.3f}", i ? ", " : "", tl[i].first.c_str(), tl[i].second);
+            js += buf;
+        }
+        js += "]";
+        if ((int) js.size() + 1 > capacity) return -1;
+        memcpy(json_out, js.c_str(), js.size() + 1);
+        return (int) js.size();
+    });
+}
+int bark_hip_reserve_batch(struct bark_context * bctx, int slots) {
+    if (!bctx) return -1;
+    return guarded("bark_hip_reserve_batch", -1, [&] { engine_reserve_batch(bctx, slots); return 0; });
+}
 int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data) {
     if (!bctx || i < 0 || i >= (int) bctx->batch_results.size() || !bctx->batch_results[(size_t) i].ok) return -1;
     if (data) *data = bctx->batch_results[(size_t) i].audio.data();

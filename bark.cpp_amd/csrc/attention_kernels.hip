@@ -34,6 +34,10 @@ DEVINL float score_chain(const float4 (&kv)[16], const float * __restrict__ qh) 
 // K is loaded two 256-key groups ahead, every V row group of the live context is requested before the
 // first arithmetic instruction.
 // ------------------------------------------------------------------------------------------------
+// VS = 2 (lock-step batches with at most half as many (head, slot) pairs as CUs): the 64 value dims of a pair are shared by two workgroups
+// (blockIdx.z = half; both form all scores, lanes 0..7 of every 16-lane group mix 32 dims) - a CU pulls ~24 bytes / ns from the memory side,
+// and a pair's K + V (328 KB at 640 keys) through ONE CU is what the kernel's time is made of: 246 KB per workgroup instead.  Same chains.
+template <int VS>
 __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a) {
     __shared__ float es[1024];
     __shared__ float red_f[4];
@@ -45,7 +49,10 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     const float * __restrict__ qh = a.q + (size_t) slot * E + h * 64;            // wave-uniform: scalar loads
     const float * kc = a.kc + (size_t) slot * a.kv_slot_stride, * vc = a.vc + (size_t) slot * a.kv_slot_stride;
     const float4 * kp = reinterpret_cast<const float4 *>(kc) + (size_t) h * 16 * P + tid;
-    const int chain = 4 * wave + (lane >> 4), d4 = lane & 15;
+    const int chain = 4 * wave + (lane >> 4);
+    const int vhalf = VS == 2 ? (int) blockIdx.z : 0;
+    const bool mixer = VS == 1 || (lane & 15) < 8;             // VS = 2: lanes 8..15 of a group hold no values
+    const int d4 = VS == 2 ? 8 * vhalf + (lane & 7) : (lane & 15);
     const float4 * vp = reinterpret_cast<const float4 *>(vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;   // row `chain`, dims 4*d4..
     float4 k0[16], k1[16];
     load_k_group<0>(k0, kp, P);                                // keys 0..255: always inside the cache
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     float4 vv[64];
     #pragma unroll
     for (int g = 0; g < 4; g++) {
-        if (g == 0 || ctx > 256 * g) {
+        if ((g == 0 || ctx > 256 * g) && mixer) {
             #pragma unroll
             for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 256];     // key chain + 16*(16g+i): 16 rows = 256 float4
         }
@@ -101,17 +108,18 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
             }
         }
     }
-    *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
+    if (mixer) *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 / VS) {
+        const int d = VS == 2 ? 32 * vhalf + tid : tid;
         float p[16];
         #pragma unroll
-        for (int c = 0; c < 16; c++) p[c] = part[c][tid];
+        for (int c = 0; c < 16; c++) p[c] = part[c][d];
         #pragma unroll
         for (int st = 1; st < 16; st <<= 1)
             #pragma unroll
             for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
-        if (a.att32) a.att32[(size_t) slot * E + h * 64 + tid] = p[0]; else a.att[(size_t) slot * E + h * 64 + tid] = to_half(p[0]);
+        if (a.att32) a.att32[(size_t) slot * E + h * 64 + d] = p[0]; else a.att[(size_t) slot * E + h * 64 + d] = to_half(p[0]);
     }
 }
 
@@ -365,7 +373,9 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
         hipLaunchKernelGGL((attn_slots_mix_kernel<2>), dim3(2, a.H, a.nbatch), dim3(256), 0, s, a, a.sc);
         return;
     }
-    hipLaunchKernelGGL(attn_fused_kernel, dim3(a.H, a.nbatch), dim3(256), 0, s, a);
+    // few pairs: two workgroups per pair share its value dims (BARK_HIP_CROSSCHECK bit 32 keeps one workgroup per pair)
+    if (a.nbatch > 1 && 2 * a.H * a.nbatch <= n_cu && !(crosscheck_mask() & 32)) { hipLaunchKernelGGL((attn_fused_kernel<2>), dim3(a.H, a.nbatch, 2), dim3(256), 0, s, a); return; }
+    hipLaunchKernelGGL((attn_fused_kernel<1>), dim3(a.H, a.nbatch), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 using namespace barkhip;
 
 struct bark_hip_batcher {
-    struct Req { std::string text; uint32_t seed = 0; std::vector<float> pcm; bool done = false, ok = false; };
+    struct Req { std::string text; bark_hip_request_params rp{}; std::vector<float> pcm; bool done = false, ok = false; };
     bark_context * ctx = nullptr;
     int max_batch = 32;
     std::chrono::microseconds max_wait{2000};
@@ -31,7 +31,7 @@ struct bark_hip_batcher {
     std::unordered_map<int64_t, std::shared_ptr<Req>> tickets;
     int64_t next_ticket = 1;
     bool stop = false;
-    int n_batches = 0, n_requests = 0, largest = 0;
+    int n_batches = 0, n_requests = 0, largest = 0, n_admitted = 0;      // n_admitted: requests that joined a running job
     std::thread worker;
 
     void run() {
@@ -45,10 +45,21 @@ struct bark_hip_batcher {
             std::vector<std::shared_ptr<Req>> batch;
             while (!queue.empty() && (int) batch.size() < max_batch) { batch.push_back(queue.front().second); queue.pop_front(); }
             lk.unlock();
-            std::vector<const char *> texts; std::vector<uint32_t> seeds;
-            for (auto & r : batch) { texts.push_back(r->text.c_str()); seeds.push_back(r->seed); }
+            std::vector<const char *> texts; std::vector<bark_hip_request_params> rps;
+            for (auto & r : batch) { texts.push_back(r->text.c_str()); rps.push_back(r->rp); }
+            // continuous admission: requests that arrive while the job's semantic stage has free slots join it (engine_generate_batch asks here)
+            BatchAdmit admit;
+            admit.max_job = max_batch;
+            admit.next = [&](std::string & text, bark_hip_request_params & rp) {
+                std::lock_guard<std::mutex> g(mu);
+                if (queue.empty() || (int) batch.size() >= max_batch) return false;
+                batch.push_back(queue.front().second); queue.pop_front();
+                text = batch.back()->text; rp = batch.back()->rp;
+                n_admitted++;
+                return true;
+            };
             bool failed = false;
-            try { engine_generate_batch(ctx, texts.data(), (int) texts.size(), seeds.data()); }
+            try { engine_generate_batch(ctx, texts.data(), (int) texts.size(), nullptr, rps.data(), &admit); }
             catch (const std::exception & e) { fprintf(stderr, "bark_hip_batcher: batch failed: %s\n", e.what()); failed = true; }
             lk.lock();
             for (size_t i = 0; i < batch.size(); i++) {
@@ -65,9 +76,9 @@ struct bark_hip_batcher {
 extern "C" {
 
 BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context * bctx, int max_batch, int max_wait_ms) {
-    if (!bctx || max_batch < 1 || max_batch > 32 || max_wait_ms < 0) return nullptr;
+    if (!bctx || max_batch < 1 || max_batch > 256 || max_wait_ms < 0) return nullptr;
     try {
-        engine_reserve_batch(bctx, max_batch);                 // the context's batch capacity is fixed by its first use
+        engine_reserve_batch(bctx, std::min(max_batch, 64));   // the context's slot count is fixed by its first use; a larger job queues for the slots
         std::unique_ptr<bark_hip_batcher> b(new bark_hip_batcher());
         b->ctx = bctx; b->max_batch = max_batch; b->max_wait = std::chrono::microseconds((int64_t) max_wait_ms * 1000);
         bark_hip_batcher * raw = b.get();
@@ -79,10 +90,9 @@ BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context *
     }
 }
 
-BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed) {
-    if (!b || !text) return -1;
+static int64_t batcher_enqueue(struct bark_hip_batcher * b, const char * text, const bark_hip_request_params & rp) {
     auto r = std::make_shared<bark_hip_batcher::Req>();
-    r->text = text; r->seed = seed;
+    r->text = text; r->rp = rp;
     std::lock_guard<std::mutex> lk(b->mu);
     if (b->stop) return -1;
     const int64_t t = b->next_ticket++;
@@ -90,6 +100,19 @@ BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char
     b->queue.emplace_back(t, r);
     b->cv_work.notify_all();
     return t;
+}
+static bark_hip_request_params context_request_params(const bark_context * c, uint32_t seed) {
+    bark_hip_request_params rp{};
+    rp.temp = c->params.temp; rp.fine_temp = c->params.fine_temp; rp.min_eos_p = c->params.min_eos_p; rp.n_steps_text_encoder = c->params.n_steps_text_encoder; rp.seed = seed;
+    return rp;
+}
+BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed) {
+    if (!b || !text) return -1;
+    return batcher_enqueue(b, text, context_request_params(b->ctx, seed));
+}
+BARK_API int64_t bark_hip_batcher_submit_ex(struct bark_hip_batcher * b, const char * text, const struct bark_hip_request_params * params) {
+    if (!b || !text) return -1;
+    return batcher_enqueue(b, text, params ? *params : context_request_params(b->ctx, 0));
 }
 
 BARK_API int bark_hip_batcher_wait(struct bark_hip_batcher * b, int64_t ticket, float * pcm, int capacity) {
@@ -119,6 +142,7 @@ BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b) {
     if (!b) return;
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }
     if (b->worker.joinable()) b->worker.join();                // pending requests are still served
+    { std::lock_guard<std::mutex> lk(b->mu); b->tickets.clear(); }   // tickets nobody waited for
     delete b;
 }
 

@@ -12,6 +12,7 @@
 #include "model_file.h"
 #include "tokenizer.h"
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <random>
@@ -121,12 +122,14 @@ struct bark_context {
         float * sc = nullptr;                            // [cap][max_H][P] attention scores of a lock step (scores kernel -> mix kernel)
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
-        float * slot_par = nullptr; std::vector<float> h_slot_par;   // the slots' own temperatures [cap] and min_eos_p [cap] (bark_hip_request_params), host mirror
-        std::map<int, hipGraphExec_t> graphs;            // captured lock steps by (model, active slots, kinds of sampling)
+        float * slot_par = nullptr;                      // the slots' own temperatures [cap] and min_eos_p [cap] (bark_hip_request_params)
         // window prompts of all slots in ONE pass (batch_prefill_many): row scratch for cap * P rows, the prompts' ids, the sequence table
         float * pf_x = nullptr, * pf_q = nullptr; barkhip::half_t * pf_xn = nullptr, * pf_att = nullptr, * pf_h = nullptr;
         int32_t * pf_tokens = nullptr; barkhip::SeqTab * pf_tab = nullptr;
     } batch;
+    std::vector<float> h_slot_par;                      // host mirror of batch.slot_par
+    std::vector<std::pair<std::string, hipEvent_t>> * step_marks = nullptr;      // engine_profile_lock_step: events behind the launch sites of a lock step
+    std::map<int, hipGraphExec_t> batch_graphs;         // captured lock steps by (model, active slots, kinds of sampling among them)
     // fine windows of several utterances in one forward pass (engine_fine_many): rows = cap * 1024
     struct FineBatch {
         int cap = 0;
@@ -174,13 +177,19 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * ctx, con
                                                          int tap_stage, std::vector<float> * tap);
 bool engine_generate(bark_context * ctx, const char * text);
 // seeds: one std::mt19937 seed per utterance (temp > 0); nullptr: drawn from the context's generator, in order.  Returns #ok
-int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n, const uint32_t * seeds);
+// Continuous admission: while the semantic stage of a job has free slots and nobody of the job waits for them, next() may hand over further
+// requests (false: none pending); they join the job - results are appended behind the n given ones - up to max_job utterances in total.
+struct BatchAdmit { std::function<bool(std::string & text, bark_hip_request_params & rp)> next; int max_job = 0; };
+// rps: per-utterance parameters (nullptr: the context's for everyone); seeds override rps[i].seed when both are given
+int  engine_generate_batch(bark_context * ctx, const char * const * texts, int n, const uint32_t * seeds, const bark_hip_request_params * rps = nullptr,
+                           const BatchAdmit * admit = nullptr);
 void engine_reserve_batch(bark_context * ctx, int slots);          // fixes the lock-step capacity (otherwise the first batch call does)
 
 double engine_time_decode_step(bark_context * ctx, int which, int ctxlen, int iters, double * bytes_per_step);
 double engine_time_gemv(bark_context * ctx, int which, int op, int iters, double * bytes_per_launch);
 double engine_time_fine_pass(bark_context * ctx, int iters, double * flops_per_pass, int Z = 1);     // Z windows side by side (engine_fine_many's pass)
 double engine_time_slots(bark_context * c, int which, int op, int B, int kind, int ctxlen, int iters);
+void engine_profile_lock_step(bark_context * c, int which, int B, int ctxlen, int reps, std::vector<std::pair<std::string, double>> & out);
 #ifdef BARK_TRACE
 int engine_trace_decode_step(bark_context * ctx, int which, int ctxlen, int replays, unsigned long long * out6, int cap_records);
 #endif

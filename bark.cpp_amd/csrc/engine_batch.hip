@@ -24,6 +24,8 @@ namespace barkhip {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int kMaxSlots = 64;                            // lock-step slots of a context (KV caches of both causal models per slot: 151 MB at bark-small)
+
 void ensure_batch(bark_context * c, int B) {
     bark_context::Batch & bb = c->batch;
     if (bb.cap >= B) return;
@@ -50,20 +52,20 @@ void ensure_batch(bark_context * c, int B) {
     bb.sc = dev_alloc<float>(c, (size_t) B * c->max_H * c->P);
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.slot_par = dev_alloc<float>(c, (size_t) 2 * B);               // [0, B): temperatures, [B, 2 B): min_eos_p
-    bb.h_slot_par.assign((size_t) 2 * B, 0.0f);
+    c->h_slot_par.assign((size_t) 2 * B, 0.0f);
     bb.cap = B;
 }
 
 // the slots' own sampling parameters (bark_hip_request_params): host mirror -> device
 void upload_slot_params(bark_context * c) {
     bark_context::Batch & bb = c->batch;
-    HIP_OK(hipMemcpyAsync(bb.slot_par, bb.h_slot_par.data(), bb.h_slot_par.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(bb.slot_par, c->h_slot_par.data(), c->h_slot_par.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
 }
 // 1: greedy slots among [slot0, slot0 + n), 2: sampled slots among them
 int slot_kinds(const bark_context * c, int slot0, int n) {
     int k = 0;
-    for (int b = slot0; b < slot0 + n; b++) k |= c->batch.h_slot_par[(size_t) b] > 0.0f ? 2 : 1;
+    for (int b = slot0; b < slot0 + n; b++) k |= c->h_slot_par[(size_t) b] > 0.0f ? 2 : 1;
     return k;
 }
 // the sampler's arguments for slots [slot0, slot0 + nb) of the batch
@@ -76,9 +78,10 @@ SampleArgs slot_sample_args(bark_context * c, const StageCfg & s, const bark_con
     sa.eos_trace = s.mode == 0 ? bb.eos_trace + (size_t) slot0 * 2048 : nullptr;
     sa.st = bb.state + slot0; sa.nbatch = nb; sa.ld_logits = (int) bb.ld_logits; sa.out_stride = 2048;
     sa.temp = s.temp; sa.u = bb.u + (size_t) slot0 * 8192; sa.u_stride = 8192;
-    // bb.slot_par belongs to the context's own batch (slot_view copies share it): slot b's entries sit at [b] and [cap + b]
-    sa.slot_temp = c->batch.slot_par + slot0; sa.slot_min_eos_p = s.mode == 0 ? c->batch.slot_par + c->batch.cap + slot0 : nullptr;
-    sa.kinds = slot_kinds(c, (int) (bb.state - c->batch.state) + slot0, nb);
+    // the parameter arrays belong to the context's own batch (`bb` may be a slot_view of it): slot b's entries sit at [b] and [cap + b]
+    const int first = (int) (bb.state - c->batch.state) + slot0;
+    sa.slot_temp = c->batch.slot_par + first; sa.slot_min_eos_p = s.mode == 0 ? c->batch.slot_par + c->batch.cap + first : nullptr;
+    sa.kinds = slot_kinds(c, first, nb);
     sa.wte = m.wte[0]; sa.wte_q = m.wte_q[0]; sa.wpe = m.wpe; sa.E = m.hp.n_embd; sa.n_in = m.hp.n_in_vocab; sa.P = c->P; sa.x = bb.x + (size_t) slot0 * m.hp.n_embd;
     return sa;
 }
@@ -99,6 +102,12 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     GptModel & m = c->gpt[s.which];
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t st = c->stream;
+    // time line of a lock step (engine_profile_lock_step): an event behind every launch site, named
+    auto mark = [&](const char * name) {
+        if (!c->step_marks) return;
+        hipEvent_t e; HIP_OK(hipEventCreate(&e)); HIP_OK(hipEventRecord(e, st));
+        c->step_marks->emplace_back(name, e);
+    };
     float * kc0 = bb.kc[s.which], * vc0 = bb.vc[s.which];
     const size_t slot = bb.slot_stride[s.which];
     // LayerNorm statistics: recomputed inside every GEMV wave for small batches (an extra launch costs ~2 us), hoisted into
@@ -132,25 +141,30 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
         product(a, L.ln1_g, L.ln1_b);
+        mark("ln1+qkv");
         AttnDecodeArgs at;
         at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
         at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
         at.sc = bb.sc;
         launch_attn_decode(st, at);
+        mark("attention");
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
         product(p, nullptr, nullptr);
+        mark("proj");
         if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
         product(f, L.ln2_g, L.ln2_b);
+        mark("ln2+fc+gelu");
         LinArgs o;
         o.batched = 1; o.nbatch = B;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
         product(o, nullptr, nullptr);
+        mark("mlp_proj");
     }
     if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
     LinArgs h;
@@ -159,7 +173,9 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
     product(h, m.lnf_g, m.lnf_b);
+    mark("lnf+lm_head");
     launch_sample_greedy(st, slot_sample_args(c, s, bb, 0, B, 1));
+    mark("sample+embed");
 }
 
 void batch_step(bark_context * c, const StageCfg & s, int B) {
@@ -168,7 +184,7 @@ void batch_step(bark_context * c, const StageCfg & s, int B) {
         // one captured lock step per (model, active slots, kinds of sampling among them); a batch that shrinks slot by slot meets each
         // size once per context (the executables are kept)
         const int key = s.which | (B << 1) | (slot_kinds(c, 0, B) << 12);
-        hipGraphExec_t & exec = bb.graphs[key];
+        hipGraphExec_t & exec = c->batch_graphs[key];
         if (!exec) {
             hipGraph_t graph = nullptr;
             HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -193,7 +209,6 @@ bark_context::Batch slot_view(const bark_context * c, const StageCfg & s, int b)
     v.x += E * b; v.q += E * b; v.att += E * b; v.h += 4 * E * b; v.logits += v.ld_logits * (size_t) b;
     if (v.att32) { v.att32 += E * b; v.h32 += 4 * E * b; }
     v.state += b; v.out_tokens += (size_t) b * 2048; v.eos_trace += (size_t) b * 2048; v.ln_stats += 2 * (size_t) b; v.u += (size_t) b * 8192;
-    v.graphs.clear(); v.h_slot_par.clear();
     return v;
 }
 void embed_slot(bark_context * c, const StageCfg & s, int b) {
@@ -301,7 +316,7 @@ void batch_prefill_many(bark_context * c, const StageCfg & s, const std::vector<
 // `ctxlen`.  kind: route of the products - 0 the VALU GEMV (LayerNorm fused for ops 0 / 2), >= 1 launch_linear_slots(kind) on rows
 // that are already normalised.  Returns the average device time per launch in microseconds.
 double engine_time_slots(bark_context * c, int which, int op, int B, int kind, int ctxlen, int iters) {
-    if (which < 0 || which > 1 || op < 0 || op > 5 || B < 1 || B > 32) throw std::runtime_error("time_slots: bad arguments");
+    if (which < 0 || which > 1 || op < 0 || op > 5 || B < 1 || B > kMaxSlots) throw std::runtime_error("time_slots: bad arguments");
     HIP_OK(hipSetDevice(c->device));
     GptModel & m = c->gpt[which];
     if (m.q4 || c->any_w32) throw std::runtime_error("time_slots: f16 model files only");
@@ -377,121 +392,294 @@ double engine_time_slots(bark_context * c, int which, int op, int B, int kind, i
     return (double) ms * 1000.0 / (reps * per_graph);
 }
 
+// Time line of ONE lock step over B slots at context `ctxlen`: the step is enqueued eagerly `reps` times with an event behind every launch
+// site of enqueue_batch_step; out[i] = {site, average microseconds from the previous event to this one} - kernel time plus the gap in front
+// of it, in launch order (the profiler view of the lock-step path: rocprofv3 cannot follow bark_hip_generate_batch, profiles/README.md).
+// which: 0 semantic, 1 coarse.  The step's total is also returned as the last entry "step (graph replay)": the same step replayed from a hipGraph.
+void engine_profile_lock_step(bark_context * c, int which, int B, int ctxlen, int reps, std::vector<std::pair<std::string, double>> & out) {
+    if (which < 0 || which > 1 || B < 1 || B > kMaxSlots || reps < 1) throw std::runtime_error("profile_lock_step: bad arguments");
+    HIP_OK(hipSetDevice(c->device));
+    GptModel & m = c->gpt[which];
+    ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
+    bark_context::Batch & bb = c->batch;
+    if (B > bb.cap) throw std::runtime_error("profile_lock_step: more slots than the capacity fixed by the first call");
+    const StageCfg s = stage_cfg(c, which);
+    ctxlen = std::max(2, std::min(ctxlen, m.hp.block_size - reps - 40));
+    auto reset = [&] {
+        std::vector<StepState> sts((size_t) B, fresh_state());
+        for (auto & v : sts) { v.n_past = ctxlen - 1; v.cur_token = 1; }
+        HIP_OK(hipMemcpyAsync(bb.state, sts.data(), sizeof(StepState) * B, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    };
+    HIP_OK(hipMemsetAsync(bb.x, 0, (size_t) B * m.hp.n_embd * 4, c->stream));
+    HIP_OK(hipMemsetAsync(bb.kc[which], 0, bb.slot_stride[which] * (size_t) B * 4, c->stream));
+    HIP_OK(hipMemsetAsync(bb.vc[which], 0, bb.slot_stride[which] * (size_t) B * 4, c->stream));
+    for (int b = 0; b < B; b++) { c->h_slot_par[(size_t) b] = 0.0f; c->h_slot_par[(size_t) bb.cap + b] = 0.2f; }
+    upload_slot_params(c);
+    reset();
+    enqueue_batch_step(c, s, B, bb);                               // warm-up (first-use costs)
+    reset();
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    std::vector<double> acc;
+    std::vector<std::string> names;
+    for (int r = 0; r < reps; r++) {
+        marks.clear();
+        hipEvent_t e0; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventRecord(e0, c->stream));
+        c->step_marks = &marks;
+        try { enqueue_batch_step(c, s, B, bb); } catch (...) { c->step_marks = nullptr; throw; }
+        c->step_marks = nullptr;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (acc.empty()) { acc.assign(marks.size(), 0.0); for (auto & mk : marks) names.push_back(mk.first); }
+        hipEvent_t prev = e0;
+        for (size_t i = 0; i < marks.size(); i++) {
+            float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, prev, marks[i].second));
+            acc[i] += (double) ms * 1000.0;
+            prev = marks[i].second;
+        }
+        (void) hipEventDestroy(e0);
+        for (auto & mk : marks) (void) hipEventDestroy(mk.second);
+    }
+    out.clear();
+    for (size_t i = 0; i < acc.size(); i++) out.emplace_back(names[i], acc[i] / reps);
+    // the same step from a hipGraph (what the stage loops replay)
+    reset();
+    batch_step(c, s, B);
+    HIP_OK(hipStreamSynchronize(c->stream));
+    reset();
+    hipEvent_t g0, g1; HIP_OK(hipEventCreate(&g0)); HIP_OK(hipEventCreate(&g1));
+    HIP_OK(hipEventRecord(g0, c->stream));
+    for (int r = 0; r < reps; r++) batch_step(c, s, B);
+    HIP_OK(hipEventRecord(g1, c->stream));
+    HIP_OK(hipEventSynchronize(g1));
+    float ms = 0.f; HIP_OK(hipEventElapsedTime(&ms, g0, g1));
+    (void) hipEventDestroy(g0); (void) hipEventDestroy(g1);
+    out.emplace_back("step (graph replay)", (double) ms * 1000.0 / reps);
+}
+
 void engine_reserve_batch(bark_context * c, int slots) {
     HIP_OK(hipSetDevice(c->device));
-    if (slots < 1 || slots > 32) throw std::runtime_error("reserve_batch: 1..32 slots");
+    if (slots < 1 || slots > kMaxSlots) throw std::runtime_error("reserve_batch: 1..64 slots");
     if (c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) return;          // these contexts run batches sequentially
     ensure_batch(c, std::max(slots, 8));
 }
 
-int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds) {
+namespace {
+
+// one utterance of a job on its way through the stages
+struct Utt {
+    std::string text;
+    bark_hip_request_params rp{};
+    std::mt19937 rng;
+    std::vector<int32_t> coarse_out;                     // raw coarse ids of the windows done so far
+    std::vector<int32_t> cached;                         // coarse: ids whose K / V rows sit in the utterance's slot cache
+    int n_steps = 0, step_idx = 0;                       // coarse steps in total / done
+    int issued = 0, cap = 0;                             // semantic: lock steps run for it / its step cap
+};
+
+// slot `from` becomes slot `to` (the batch stays a compact range of slots when an utterance in its middle retires): caches of model g,
+// the decode row, the stage state, the sampled ids, the uniform draws
+void move_slot(bark_context * c, int g, int from, int to) {
+    bark_context::Batch & bb = c->batch;
+    const GptModel & m = c->gpt[g];
+    hipStream_t st = c->stream;
+    const size_t ss = bb.slot_stride[g];
+    HIP_OK(hipMemcpyAsync(bb.kc[g] + ss * (size_t) to, bb.kc[g] + ss * (size_t) from, ss * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.vc[g] + ss * (size_t) to, bb.vc[g] + ss * (size_t) from, ss * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.x + (size_t) to * m.hp.n_embd, bb.x + (size_t) from * m.hp.n_embd, (size_t) m.hp.n_embd * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.state + to, bb.state + from, sizeof(StepState), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.out_tokens + (size_t) to * 2048, bb.out_tokens + (size_t) from * 2048, 2048 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.eos_trace + (size_t) to * 2048, bb.eos_trace + (size_t) from * 2048, 2048 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(bb.u + (size_t) to * 8192, bb.u + (size_t) from * 8192, 8192 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    c->h_slot_par[(size_t) to] = c->h_slot_par[(size_t) from];
+    c->h_slot_par[(size_t) bb.cap + to] = c->h_slot_par[(size_t) bb.cap + from];
+}
+
+void set_slot_params(bark_context * c, int slot, const Utt & u) {
+    c->h_slot_par[(size_t) slot] = u.rp.temp;
+    c->h_slot_par[(size_t) c->batch.cap + slot] = u.rp.min_eos_p;
+}
+
+}  // namespace
+
+// A job of n utterances on the context's lock-step slots (bark.cpp:2125-2172 per utterance).  The stages run one after the other for the
+// whole job; inside the semantic and the coarse stage the utterances travel through S = capacity slots: a slot whose utterance has
+// finished (its own step cap / stop rule, its own number of coarse windows) is handed to the next waiting utterance, and once nobody
+// waits the batch is compacted (the last slot moves into the hole), so every lock step runs over live utterances only.
+int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds, const bark_hip_request_params * rps, const BatchAdmit * admit) {
     HIP_OK(hipSetDevice(c->device));
     const bark_context_params & p = c->params;
-    if (n <= 0 || n > 32) throw std::runtime_error("generate_batch: batch size must be in 1..32");
+    if (n <= 0 || n > 4096) throw std::runtime_error("generate_batch: 1..4096 utterances per call");
+    if (admit && (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32)) admit = nullptr;     // the sequential fallback takes the job as given
     c->batch_results.assign((size_t) n, bark_context::BatchResult());
     // one generator per utterance (bark.cpp:1179 seeds one per context): utterance i of a batch is what a fresh context with
     // seed seeds[i] would generate.  Without explicit seeds they are drawn from the context's generator, in order.
-    std::vector<std::mt19937> slot_rng((size_t) n);
-    for (int i = 0; i < n; i++) slot_rng[(size_t) i] = std::mt19937(seeds ? seeds[i] : (uint32_t) c->rng());
-    const bool sampled = p.temp != 0.0f;
+    std::vector<Utt> us((size_t) n);
+    for (int i = 0; i < n; i++) {
+        Utt & u = us[(size_t) i];
+        u.text = texts[i];
+        if (rps) u.rp = rps[i];
+        else { u.rp.temp = p.temp; u.rp.fine_temp = p.fine_temp; u.rp.min_eos_p = p.min_eos_p; u.rp.n_steps_text_encoder = p.n_steps_text_encoder; u.rp.seed = seeds ? seeds[i] : (uint32_t) c->rng(); }
+        if (rps && seeds) u.rp.seed = seeds[i];
+        if (!(u.rp.temp >= 0.0f) || !(u.rp.fine_temp >= 0.0f)) throw std::runtime_error("generate_batch: temperatures must be >= 0");
+        u.rng = std::mt19937(u.rp.seed);
+    }
     if (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) {
         // host-side sampling and f32 model files keep one utterance in flight: fall back to the sequential loop
         int good = 0;
+        const bark_context_params saved = c->params;
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];
-            std::swap(c->rng, slot_rng[(size_t) i]);
-            try { r.ok = engine_generate(c, texts[i]); } catch (...) { std::swap(c->rng, slot_rng[(size_t) i]); throw; }
-            std::swap(c->rng, slot_rng[(size_t) i]);
+            Utt & u = us[(size_t) i];
+            c->params.temp = u.rp.temp; c->params.fine_temp = u.rp.fine_temp; c->params.min_eos_p = u.rp.min_eos_p; c->params.n_steps_text_encoder = u.rp.n_steps_text_encoder;
+            std::swap(c->rng, u.rng);
+            try { r.ok = engine_generate(c, u.text.c_str()); } catch (...) { std::swap(c->rng, u.rng); c->params = saved; throw; }
+            std::swap(c->rng, u.rng);
             if (r.ok) { r.semantic = c->semantic_tokens; r.coarse = c->coarse_tokens; r.fine = c->fine_tokens; r.audio = c->audio; good++; }
         }
+        c->params = saved;
         return good;
     }
     const int64_t t0 = now_us();
     const int64_t t_load = c->stats.t_load_us;
     c->stats = bark_hip_stats{};
     c->stats.t_load_us = t_load;
-    const int B = n;
     // the prompts of all slots in one pass (batch_prefill_many) instead of slot by slot; BARK_HIP_CROSSCHECK bit 4 (16) keeps the slot-by-slot route
     const bool prefill_many = !(crosscheck_mask() & 16);
-    ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(B, 8));
+    ensure_batch(c, c->batch.cap ? c->batch.cap : std::max(std::min(n, kMaxSlots), 8));
     bark_context::Batch & bb = c->batch;
-    if (B > bb.cap) throw std::runtime_error("generate_batch: batch larger than the capacity fixed by the first call");
+    const int S = bb.cap;
 
-    // ---- semantic (bark.cpp:1645-1701), lock step -----------------------------------------------------
+    // ---- semantic (bark.cpp:1645-1701): lock steps over the live slots, slots refilled from the queue ------------------------------------
     int64_t t = now_us();
     {
         GptModel & m = c->gpt[0];
         const StageCfg s = stage_cfg(c, 0);
-        const int n_steps = std::max(0, std::min(p.n_steps_text_encoder, m.hp.block_size - 257 + 1));
+        const int cap_max = m.hp.block_size - 257 + 1;              // 257 prompt rows + one row per further step must fit the context
         PromptParams pp;
         pp.block_size = m.hp.block_size; pp.text_encoding_offset = p.text_encoding_offset; pp.text_pad_token = p.text_pad_token;
         pp.semantic_pad_token = p.semantic_pad_token; pp.semantic_infer_token = p.semantic_infer_token;
-        if (n_steps > 0) {
-            if (sampled) for (int b = 0; b < B; b++) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps);
-            if (prefill_many && !m.q4 && !m.w32) {
-                std::vector<std::vector<int32_t>> prompts((size_t) B);
-                std::vector<const std::vector<int32_t> *> pp_ids; std::vector<int> sl, l0((size_t) B, 0), s0((size_t) B, 0);
-                for (int b = 0; b < B; b++) { prompts[(size_t) b] = build_semantic_prompt(c->vocab, pp, texts[b], true); pp_ids.push_back(&prompts[(size_t) b]); sl.push_back(b); }
-                batch_prefill_many(c, s, sl, pp_ids, l0, true, s0);
-            } else {
-                for (int b = 0; b < B; b++) batch_prefill_and_sample(c, s, b, build_semantic_prompt(c->vocab, pp, texts[b], true), true, 0);
+        std::deque<int> queue;
+        int total_steps = 0, done_steps = 0;
+        for (int i = 0; i < n; i++) {
+            us[(size_t) i].cap = std::max(0, std::min(us[(size_t) i].rp.n_steps_text_encoder, cap_max));
+            if (us[(size_t) i].cap > 0) { queue.push_back(i); total_steps += us[(size_t) i].cap; }
+        }
+        std::vector<int> slot_utt;                                  // slot -> utterance, a compact range [0, active)
+        std::vector<std::vector<int32_t>> prompts((size_t) n);
+        auto retire = [&](int slot, const StepState & st) {
+            Utt & u = us[(size_t) slot_utt[(size_t) slot]];
+            const int keep = std::min(st.eos_step, u.cap);
+            auto & out = c->batch_results[(size_t) slot_utt[(size_t) slot]].semantic;
+            out.resize((size_t) keep);
+            if (keep) HIP_OK(hipMemcpy(out.data(), bb.out_tokens + (size_t) slot * 2048, (size_t) keep * 4, hipMemcpyDeviceToHost));
+            const int n_used = st.eos_step == INT32_MAX ? u.cap : std::min(u.cap, st.eos_step + 1);
+            c->stats.n_sample_semantic += n_used;
+            if (u.rp.temp > 0.0f) u.rng.discard(2ull * (unsigned long long) n_used);        // as consume_uniforms()
+            c->stats.n_near_tie += st.near_tie;
+            done_steps += u.cap;
+        };
+        while (!queue.empty() || !slot_utt.empty()) {
+            // continuous admission (the request collector, batcher.hip): while slots are free and nobody of this job waits for them, requests
+            // that arrived in the meantime join the job - they ride along through the remaining stages
+            while (admit && queue.empty() && (int) slot_utt.size() < S && n < admit->max_job) {
+                Utt u;
+                if (!admit->next(u.text, u.rp)) break;
+                u.rng = std::mt19937(u.rp.seed);
+                u.cap = std::max(0, std::min(u.rp.n_steps_text_encoder, cap_max));
+                us.push_back(std::move(u)); c->batch_results.emplace_back(); prompts.emplace_back();
+                if (us.back().cap > 0 && us.back().rp.temp >= 0.0f && us.back().rp.fine_temp >= 0.0f) { queue.push_back(n); total_steps += us.back().cap; }
+                n++;
             }
-            int issued = 1;
-            std::vector<StepState> st;
-            while (true) {
-                const int batch_end = std::min(n_steps, issued + 32);
-                for (; issued < batch_end; issued++) { batch_step(c, s, B); progress(c, SEMANTIC, 100 * (issued + 1) / std::max(1, p.n_steps_text_encoder)); }
-                st = get_slot_states(c, B);
-                bool all_done = true;
-                for (auto & v : st) all_done = all_done && v.eos_step != INT32_MAX;
-                if (all_done || issued >= n_steps) break;
+            // hand free slots to waiting utterances: their prompts go through the model in one pass, which also takes their first sample
+            std::vector<int> fresh;
+            while (!queue.empty() && (int) slot_utt.size() < S) { fresh.push_back((int) slot_utt.size()); slot_utt.push_back(queue.front()); queue.pop_front(); }
+            if (!fresh.empty()) {
+                for (int slot : fresh) {
+                    Utt & u = us[(size_t) slot_utt[(size_t) slot]];
+                    set_slot_params(c, slot, u);
+                    if (u.rp.temp > 0.0f) upload_slot_uniforms(c, slot, u.rng, u.cap);
+                    prompts[(size_t) slot_utt[(size_t) slot]] = build_semantic_prompt(c->vocab, pp, u.text.c_str(), true);
+                    u.issued = 1;
+                }
+                upload_slot_params(c);
+                if (prefill_many && !m.q4 && !m.w32) {
+                    std::vector<const std::vector<int32_t> *> ids; std::vector<int> l0(fresh.size(), 0), s0(fresh.size(), 0);
+                    for (int slot : fresh) ids.push_back(&prompts[(size_t) slot_utt[(size_t) slot]]);
+                    batch_prefill_many(c, s, fresh, ids, l0, true, s0);
+                } else {
+                    for (int slot : fresh) batch_prefill_and_sample(c, s, slot, prompts[(size_t) slot_utt[(size_t) slot]], true, 0);
+                }
             }
-            for (int b = 0; b < B; b++) {
-                const int keep = std::min(st[(size_t) b].eos_step, issued);
-                auto & out = c->batch_results[(size_t) b].semantic;
-                out.resize((size_t) keep);
-                if (keep) HIP_OK(hipMemcpy(out.data(), bb.out_tokens + (size_t) b * 2048, (size_t) keep * 4, hipMemcpyDeviceToHost));
-                const int n_used = std::min(issued, st[(size_t) b].eos_step == INT32_MAX ? issued : st[(size_t) b].eos_step + 1);
-                c->stats.n_sample_semantic += n_used;
-                if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_used);      // as consume_uniforms()
-                c->stats.n_near_tie += st[(size_t) b].near_tie;
+            const int B = (int) slot_utt.size();
+            // lock steps until the next poll: at most 32, no further than the utterance with the most steps left needs, and never past the
+            // end of a slot's context (an utterance that has met its stop rule or cap keeps stepping until the poll; its ids are discarded)
+            int most_left = 0, room = INT32_MAX;
+            for (int b = 0; b < B; b++) { const Utt & u = us[(size_t) slot_utt[(size_t) b]]; most_left = std::max(most_left, u.cap - u.issued); room = std::min(room, cap_max - u.issued); }
+            const int k = std::max(0, std::min(32, std::min(most_left, room)));
+            for (int j = 0; j < k; j++) batch_step(c, s, B);
+            for (int b = 0; b < B; b++) us[(size_t) slot_utt[(size_t) b]].issued += k;
+            std::vector<StepState> st = get_slot_states(c, B);
+            for (auto & v : st) if (v.fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
+            // retire from the back so that a move never touches a slot that is still to be looked at
+            bool moved = false;
+            for (int b = B - 1; b >= 0; b--) {
+                const Utt & u = us[(size_t) slot_utt[(size_t) b]];
+                if (st[(size_t) b].eos_step == INT32_MAX && u.issued < u.cap) continue;
+                retire(b, st[(size_t) b]);
+                const int last = (int) slot_utt.size() - 1;
+                // the last slot moves into the hole: the live slots stay a compact range, and the refill appends behind them
+                if (b != last) { move_slot(c, 0, last, b); slot_utt[(size_t) b] = slot_utt[(size_t) last]; moved = true; }
+                slot_utt.pop_back();
             }
+            if (moved) upload_slot_params(c);
+            progress(c, SEMANTIC, total_steps ? (int) (100ll * done_steps / total_steps) : 100);
         }
     }
     c->stats.t_semantic_us = now_us() - t;
 
-    // ---- coarse (bark.cpp:1745-1863), windows in lock step ---------------------------------------------
+    // ---- coarse (bark.cpp:1745-1863): windows in lock step, slots refilled at window boundaries ------------------------------------------
     t = now_us();
-    std::vector<std::vector<int32_t>> coarse_out((size_t) B);
     {
         GptModel & m = c->gpt[1];
         const StageCfg s = stage_cfg(c, 1);
         if (p.n_coarse_codebooks != 2 || p.codebook_size != 1024 || p.sliding_window_size <= 0 || p.max_coarse_history < 0)
             throw std::runtime_error("coarse: unsupported parameters");
+        if (p.sliding_window_size & 1) throw std::runtime_error("coarse: lock-step batches need an even sliding_window_size (the slots share the codebook parity of a step)");
         if (s.lm_row0 + 2 * s.lm_rows > m.hp.n_out_vocab) throw std::runtime_error("coarse: vocabulary too small");
         const float stc_ratio = p.coarse_rate_hz / p.semantic_rate_hz * p.n_coarse_codebooks;
         const int max_semantic_history = (int) floorf(p.max_coarse_history / stc_ratio);
-        std::vector<int> n_steps((size_t) B, 0), step_idx((size_t) B, 0);
-        int max_windows = 0;
-        for (int b = 0; b < B; b++) {
-            const auto & sem = c->batch_results[(size_t) b].semantic;
+        std::deque<int> queue;
+        long total_steps = 0, done_steps = 0;
+        for (int i = 0; i < n; i++) {
+            const auto & sem = c->batch_results[(size_t) i].semantic;
             if (sem.empty()) continue;
-            n_steps[(size_t) b] = (int) (floorf(sem.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);
-            max_windows = std::max(max_windows, (int) ceilf((float) n_steps[(size_t) b] / p.sliding_window_size));
-            if (sampled) upload_slot_uniforms(c, b, slot_rng[(size_t) b], n_steps[(size_t) b]);          // indexed by the slot's step_idx
+            us[(size_t) i].n_steps = (int) (floorf(sem.size() * stc_ratio / p.n_coarse_codebooks) * p.n_coarse_codebooks);
+            if (us[(size_t) i].n_steps > 0) { queue.push_back(i); total_steps += us[(size_t) i].n_steps; }
         }
-        std::vector<std::vector<int32_t>> cached((size_t) B);          // per slot: ids whose K/V rows are in its cache
         const bool reuse_prefix = !(crosscheck_mask() & 8);
-        for (int w = 0; w < max_windows; w++) {
+        std::vector<int> slot_utt;
+        while (!queue.empty() || !slot_utt.empty()) {
+            bool params_dirty = false;
+            while (!queue.empty() && (int) slot_utt.size() < S) {
+                const int slot = (int) slot_utt.size();
+                slot_utt.push_back(queue.front()); queue.pop_front();
+                Utt & u = us[(size_t) slot_utt.back()];
+                set_slot_params(c, slot, u); params_dirty = true;
+                if (u.rp.temp > 0.0f) upload_slot_uniforms(c, slot, u.rng, u.n_steps);          // indexed by the utterance's step_idx
+                u.cached.clear();
+            }
+            if (params_dirty) upload_slot_params(c);
+            const int B = (int) slot_utt.size();
+            // ---- one window for every live slot ----
             int max_here = 0;
             std::vector<int> here((size_t) B, 0), Ls((size_t) B, 0);
             std::vector<std::vector<int32_t>> ins((size_t) B);
-            bool all_single = true;                                      // every live slot needs exactly one new row
+            bool all_single = true;                                      // every slot needs exactly one new row
             for (int b = 0; b < B; b++) {
-                if (step_idx[(size_t) b] >= n_steps[(size_t) b]) continue;
-                const auto & sem = c->batch_results[(size_t) b].semantic;
-                auto & out = coarse_out[(size_t) b];
-                const int semantic_idx = (int) roundf(step_idx[(size_t) b] / stc_ratio);
+                Utt & u = us[(size_t) slot_utt[(size_t) b]];
+                const auto & sem = c->batch_results[(size_t) slot_utt[(size_t) b]].semantic;
+                const auto & out = u.coarse_out;
+                const int semantic_idx = (int) roundf(u.step_idx / stc_ratio);
                 std::vector<int32_t> in(sem.begin() + std::max(semantic_idx - max_semantic_history, 0), sem.end());
                 const size_t had = in.size();
                 in.resize(256);
@@ -499,12 +687,12 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 in.push_back(p.coarse_infer_token);
                 const int nh = std::min(p.max_coarse_history, (int) out.size());
                 in.insert(in.end(), out.end() - nh, out.end());
-                here[(size_t) b] = std::min(p.sliding_window_size, n_steps[(size_t) b] - step_idx[(size_t) b]);
+                here[(size_t) b] = std::min(p.sliding_window_size, u.n_steps - u.step_idx);
                 if ((int) in.size() + here[(size_t) b] - 1 > m.hp.block_size) throw std::runtime_error("coarse: window exceeds the context");
                 check_ids(in.data(), in.size(), m.hp.n_in_vocab, "coarse");
                 int L = 0;
                 if (reuse_prefix) {
-                    const auto & cd = cached[(size_t) b];
+                    const auto & cd = u.cached;
                     while (L < (int) in.size() && L < (int) cd.size() && cd[(size_t) L] == in[(size_t) L]) L++;
                     if (L >= (int) in.size()) L = (int) in.size() - 1;
                 }
@@ -513,66 +701,73 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 ins[(size_t) b] = std::move(in);
                 max_here = std::max(max_here, here[(size_t) b]);
             }
-            int lock_steps = max_here - 1;                               // batched steps after every live slot has its first sample
+            // a slot whose last window is shorter than the others' steps on to the end of the window: its rows must fit its context too
+            for (int b = 0; b < B; b++)
+                if ((int) ins[(size_t) b].size() + max_here - 1 > m.hp.block_size) throw std::runtime_error("coarse: a lock-step window exceeds the context of a slot (history + sliding window too long for a batch)");
+            int lock_steps = max_here - 1;                               // batched steps after every slot has its first sample
             std::vector<int> pf_slots, pf_L, pf_step; std::vector<const std::vector<int32_t> *> pf_ids;
             for (int b = 0; b < B; b++) {
-                if (!here[(size_t) b]) {                                 // finished (or empty) slot: park it at position 0
-                    StepState idle = fresh_state(); idle.cur_token = 0;
-                    // same codebook parity as the live slots DURING THE LOCK STEPS (slot 0's step selects the LM-head rows of every slot): in a
-                    // window whose first samples come from prompts (not from a lock step) the live slots have already taken one step by then
-                    idle.step = w * p.sliding_window_size + (all_single ? 0 : 1);
-                    set_slot_state(c, b, idle);
-                    continue;
-                }
+                Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 const auto & in = ins[(size_t) b];
                 const int L = Ls[(size_t) b];
                 c->stats.n_prefix_rows_reused += L;
                 if ((int) in.size() - L == 1) {
                     // the prompt is the cached sequence plus one token: a decode step (prefix reuse, see engine_coarse)
-                    StepState st1 = fresh_state(); st1.step = step_idx[(size_t) b]; st1.n_past = L; st1.cur_token = in[(size_t) L];
+                    StepState st1 = fresh_state(); st1.step = u.step_idx; st1.n_past = L; st1.cur_token = in[(size_t) L];
                     set_slot_state(c, b, st1);
                     embed_slot(c, s, b);
                     if (!all_single) enqueue_batch_step(c, s, 1, slot_view(c, s, b));      // mixed window: this slot alone, eagerly
                 } else if (prefill_many && !m.q4 && !m.w32) {
-                    pf_slots.push_back(b); pf_ids.push_back(&ins[(size_t) b]); pf_L.push_back(L); pf_step.push_back(step_idx[(size_t) b]);
+                    pf_slots.push_back(b); pf_ids.push_back(&ins[(size_t) b]); pf_L.push_back(L); pf_step.push_back(u.step_idx);
                 } else {
-                    batch_prefill_and_sample(c, s, b, in, false, step_idx[(size_t) b], L);
+                    batch_prefill_and_sample(c, s, b, in, false, u.step_idx, L);
                 }
             }
             if (!pf_slots.empty()) batch_prefill_many(c, s, pf_slots, pf_ids, pf_L, false, pf_step);
-            if (all_single && max_here > 0) lock_steps = max_here;       // the first sample of the window is a lock-step too
+            if (all_single && max_here > 0) lock_steps = max_here;       // the first sample of the window is a lock step too
+            // a slot whose last window is shorter than the others' keeps stepping to the end of the window (its further ids are discarded;
+            // window prompt + sliding_window_size rows fit the context by the check above, as every window is even the parity stays shared)
             for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
             const std::vector<StepState> st = get_slot_states(c, B);
             for (int b = 0; b < B; b++) {
-                if (!here[(size_t) b]) continue;
+                Utt & u = us[(size_t) slot_utt[(size_t) b]];
+                if (st[(size_t) b].fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
                 std::vector<int32_t> got((size_t) here[(size_t) b]);
                 HIP_OK(hipMemcpy(got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4, hipMemcpyDeviceToHost));
-                coarse_out[(size_t) b].insert(coarse_out[(size_t) b].end(), got.begin(), got.end());
-                // rows now in the slot's cache: its prompt and every token fed back (a parked tail of lock steps past `here`
-                // wrote further rows, but those are never matched because the ids are not recorded)
-                cached[(size_t) b] = ins[(size_t) b];
-                cached[(size_t) b].insert(cached[(size_t) b].end(), got.begin(), got.end() - 1);
-                step_idx[(size_t) b] += here[(size_t) b];
+                u.coarse_out.insert(u.coarse_out.end(), got.begin(), got.end());
+                // rows now in the slot's cache: its prompt and every token fed back (steps past `here` wrote further rows, but those are
+                // never matched because the ids are not recorded)
+                u.cached = ins[(size_t) b];
+                u.cached.insert(u.cached.end(), got.begin(), got.end() - 1);
+                u.step_idx += here[(size_t) b];
+                done_steps += here[(size_t) b];
                 c->stats.n_sample_coarse += here[(size_t) b];
                 c->stats.n_near_tie += st[(size_t) b].near_tie;
             }
-            progress(c, COARSE, 100 * (w + 1) / std::max(1, max_windows));
-        }
-        for (int b = 0; b < B; b++) {
-            if (sampled) slot_rng[(size_t) b].discard(2ull * (unsigned long long) n_steps[(size_t) b]);
-            auto & res = c->batch_results[(size_t) b].coarse;
-            const auto & out = coarse_out[(size_t) b];
-            for (size_t i = 0; i + 1 < out.size(); i += 2) {
-                res.push_back(out[i] - p.semantic_vocab_size);
-                res.push_back(out[i + 1] - p.semantic_vocab_size - p.codebook_size);
+            // retire the finished utterances (from the back: a move never touches a slot still to be looked at)
+            bool moved = false;
+            for (int b = B - 1; b >= 0; b--) {
+                Utt & u = us[(size_t) slot_utt[(size_t) b]];
+                if (u.step_idx < u.n_steps) continue;
+                if (u.rp.temp > 0.0f) u.rng.discard(2ull * (unsigned long long) u.n_steps);
+                auto & res = c->batch_results[(size_t) slot_utt[(size_t) b]].coarse;
+                for (size_t i = 0; i + 1 < u.coarse_out.size(); i += 2) {
+                    res.push_back(u.coarse_out[i] - p.semantic_vocab_size);
+                    res.push_back(u.coarse_out[i + 1] - p.semantic_vocab_size - p.codebook_size);
+                }
+                const int last = (int) slot_utt.size() - 1;
+                if (b != last) { move_slot(c, 1, last, b); slot_utt[(size_t) b] = slot_utt[(size_t) last]; moved = true; }
+                slot_utt.pop_back();
             }
+            if (moved) upload_slot_params(c);
+            progress(c, COARSE, total_steps ? (int) (100 * done_steps / total_steps) : 100);
         }
     }
     c->stats.t_coarse_us = now_us() - t;
 
     // ---- fine (bark.cpp:1961-2059): the windows of up to `chunk` utterances side by side in every forward pass (engine_fine_many): the
     // products then see thousands of rows (whole waves of tiles on every CU instead of 0.75 - 2.25 rounds), the attention runs per window.
-    // Quantised / f32 model files keep the per-utterance loop.
+    // Utterances are grouped by their fine temperature.  Quantised / f32 model files keep the per-utterance loop.
     int good = 0;
     std::vector<int> live;                                           // utterances that reach the codec
     std::vector<std::vector<int32_t>> codes;
@@ -580,27 +775,37 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         static const int chunk_env = getenv("BARK_HIP_FINE_BATCH") ? atoi(getenv("BARK_HIP_FINE_BATCH")) : 8;
         const bool many = chunk_env > 1 && !c->gpt[2].q4 && !c->gpt[2].w32 && !c->host_sampling;
         std::vector<int> todo;
-        for (int b = 0; b < B; b++) if (!c->batch_results[(size_t) b].coarse.empty()) todo.push_back(b);
+        for (int b = 0; b < n; b++) if (!c->batch_results[(size_t) b].coarse.empty()) todo.push_back(b);
+        std::stable_sort(todo.begin(), todo.end(), [&](int a, int b2) { return us[(size_t) a].rp.fine_temp < us[(size_t) b2].rp.fine_temp; });
         t = now_us();
-        for (size_t k0 = 0; k0 < todo.size(); k0 += (size_t) std::max(1, chunk_env)) {
-            const size_t k1 = std::min(todo.size(), k0 + (size_t) std::max(1, chunk_env));
-            if (many) {
-                std::vector<const std::vector<int32_t> *> co;
-                std::vector<std::mt19937> rr;
-                for (size_t k = k0; k < k1; k++) { co.push_back(&c->batch_results[(size_t) todo[k]].coarse); rr.push_back(slot_rng[(size_t) todo[k]]); }
-                std::vector<std::vector<int32_t>> fine = engine_fine_many(c, co, &rr);
-                for (size_t k = k0; k < k1; k++) { c->batch_results[(size_t) todo[k]].fine = std::move(fine[k - k0]); slot_rng[(size_t) todo[k]] = rr[k - k0]; }
-            } else {
-                for (size_t k = k0; k < k1; k++) {
-                    const int b = todo[k];
-                    bark_context::BatchResult & r = c->batch_results[(size_t) b];
-                    std::swap(c->rng, slot_rng[(size_t) b]);                        // the fine stage draws from the utterance's generator
-                    try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, slot_rng[(size_t) b]); throw; }
-                    std::swap(c->rng, slot_rng[(size_t) b]);
+        const float saved_fine_temp = c->params.fine_temp;
+        try {
+            for (size_t k0 = 0; k0 < todo.size();) {
+                const float ft = us[(size_t) todo[k0]].rp.fine_temp;
+                size_t k1 = k0;
+                while (k1 < todo.size() && k1 - k0 < (size_t) std::max(1, chunk_env) && us[(size_t) todo[k1]].rp.fine_temp == ft) k1++;
+                c->params.fine_temp = ft;
+                if (many) {
+                    std::vector<const std::vector<int32_t> *> co;
+                    std::vector<std::mt19937> rr;
+                    for (size_t k = k0; k < k1; k++) { co.push_back(&c->batch_results[(size_t) todo[k]].coarse); rr.push_back(us[(size_t) todo[k]].rng); }
+                    std::vector<std::vector<int32_t>> fine = engine_fine_many(c, co, &rr);
+                    for (size_t k = k0; k < k1; k++) { c->batch_results[(size_t) todo[k]].fine = std::move(fine[k - k0]); us[(size_t) todo[k]].rng = rr[k - k0]; }
+                } else {
+                    for (size_t k = k0; k < k1; k++) {
+                        const int b = todo[k];
+                        bark_context::BatchResult & r = c->batch_results[(size_t) b];
+                        std::swap(c->rng, us[(size_t) b].rng);                        // the fine stage draws from the utterance's generator
+                        try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, us[(size_t) b].rng); throw; }
+                        std::swap(c->rng, us[(size_t) b].rng);
+                    }
                 }
+                k0 = k1;
             }
-        }
+        } catch (...) { c->params.fine_temp = saved_fine_temp; throw; }
+        c->params.fine_temp = saved_fine_temp;
         c->stats.t_fine_us += now_us() - t;
+        std::sort(todo.begin(), todo.end());
         for (int b : todo) {
             bark_context::BatchResult & r = c->batch_results[(size_t) b];
             const int T = (int) r.fine.size() / 8;
@@ -610,16 +815,17 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             c->stats.n_frames += T; c->stats.n_semantic += (int32_t) r.semantic.size();
         }
     }
-    // ---- codec: every utterance of the batch in one pass (engine_codec.hip) ----------------------------------------------------
-    if (!live.empty()) {
+    // ---- codec: the utterances of the job in passes of up to 32 (engine_codec.hip) -----------------------------------------------------------
+    for (size_t k0 = 0; k0 < live.size(); k0 += 32) {
+        const size_t k1 = std::min(live.size(), k0 + 32);
         t = now_us();
         std::vector<const int32_t *> cp; std::vector<int> Ts;
-        for (size_t k = 0; k < live.size(); k++) { cp.push_back(codes[k].data()); Ts.push_back((int) codes[k].size() / 8); }
+        for (size_t k = k0; k < k1; k++) { cp.push_back(codes[k].data()); Ts.push_back((int) codes[k].size() / 8); }
         std::vector<std::vector<float>> pcm = engine_codec_decode_many(c, cp, 8, Ts, -1, nullptr);
         c->stats.t_codec_us += now_us() - t;
-        for (size_t k = 0; k < live.size(); k++) {
+        for (size_t k = k0; k < k1; k++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) live[k]];
-            r.audio = std::move(pcm[k]);
+            r.audio = std::move(pcm[k - k0]);
             c->stats.n_samples += (int32_t) r.audio.size();
             r.ok = true; good++;
         }

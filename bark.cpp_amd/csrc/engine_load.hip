@@ -82,7 +82,7 @@ bark_context::~bark_context() {
         for (auto & e : g.decode_graph8) if (e) (void) hipGraphExecDestroy(e);
         if (g.bench_graph) (void) hipGraphExecDestroy(g.bench_graph);
     }
-    for (auto & g : batch.graphs) if (g.second) (void) hipGraphExecDestroy(g.second);
+    for (auto & g : batch_graphs) if (g.second) (void) hipGraphExecDestroy(g.second);
     if (lstm_graph.exec) (void) hipGraphExecDestroy(lstm_graph.exec);
     if (codec_graph.exec) (void) hipGraphExecDestroy(codec_graph.exec);
     for (auto & g : fine_graphs) if (g) (void) hipGraphExecDestroy(g);
@@ -99,8 +99,8 @@ bark_context::SharedWeights::~SharedWeights() {
 namespace barkhip {
 
 void engine_invalidate_graphs(bark_context * ctx) {
-    for (auto & g : ctx->batch.graphs) if (g.second) (void) hipGraphExecDestroy(g.second);
-    ctx->batch.graphs.clear();
+    for (auto & g : ctx->batch_graphs) if (g.second) (void) hipGraphExecDestroy(g.second);
+    ctx->batch_graphs.clear();
     for (auto & g : ctx->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
     for (auto & g : ctx->gpt) {
         for (auto & e : g.decode_graph) if (e) { (void) hipGraphExecDestroy(e); e = nullptr; }

@@ -745,7 +745,7 @@ static void launch_slots16_n(hipStream_t s, const LinArgs & a) {
 bool linear_slots_fuses_ln(int K) { return K % 256 == 0 && K <= 1024; }
 
 void launch_linear_slots(hipStream_t s, const LinArgs & a) {
-    if (!a.batched || (!a.x_f16 && !(a.x_f32 && a.ln_g)) || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 32) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows (or f32 rows + LayerNorm) of up to 32 slots and f16 weights");
+    if (!a.batched || (!a.x_f16 && !(a.x_f32 && a.ln_g)) || a.wq.qs || (a.K & 127) != 0 || a.nbatch > 64) kernel_fail("bark-hip: the lock-step MFMA product takes f16 rows (or f32 rows + LayerNorm) of up to 64 slots and f16 weights");
     switch (a.K >> 7) {
         case 1:  launch_slots16_n<1>(s, a); break;
         case 2:  launch_slots16_n<2>(s, a); break;

@@ -82,15 +82,32 @@ BARK_API struct bark_context * bark_hip_clone_context(struct bark_context * src,
  * from each context with bark_get_audio_data[_size]. */
 BARK_API int bark_hip_generate_audio_batch(struct bark_context ** ctxs, const char * const * texts, int n);
 
-/* In-engine batching: n utterances (n <= 32) advance in lock step through the semantic and coarse decode loops of ONE
- * context, so every decode kernel reads the weights once per step for all of them; the prompts of all slots go through the model
- * in one pass, the fine windows of 8 utterances side by side, the codec of all utterances in one pass.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context.  With temp > 0 every
+/* In-engine batching: a job of n utterances (n <= 4096) travels through the lock-step slots of ONE context (up to 64; the first call or
+ * bark_hip_reserve_batch fixes the number): the live slots advance together through the semantic and coarse decode loops, so every decode
+ * kernel reads the weights once per step for all of them; a slot whose utterance has finished (its own step cap / stop rule, its own number
+ * of coarse windows) is handed to the next waiting utterance, and when nobody waits the batch is compacted, so no lock step is spent on a
+ * finished utterance.  The prompts of the slots go through the model in one pass, the fine windows of 8 utterances side by side, the codec
+ * of the utterances in one pass.  Per-utterance results are bit-identical to bark_generate_audio on a fresh context with the same
+ * parameters, whatever the job size, the slot count or the company an utterance travels in.  With temp > 0 every
  * utterance has its own std::mt19937 (the reference seeds one per context, bark.cpp:1179): utterance i is what a context
  * loaded with seed seeds[i] would generate; the unseeded call draws those seeds from the context's generator, in order.
- * BARK_HIP_HOST_SAMPLING degrades the call to a sequential loop.  The first call fixes the batch capacity.
+ * BARK_HIP_HOST_SAMPLING degrades the call to a sequential loop.
  * Returns the number of utterances that produced audio.  Results: bark_hip_batch_audio / bark_hip_batch_tokens. */
 BARK_API int bark_hip_generate_batch(struct bark_context * bctx, const char * const * texts, int n);
 BARK_API int bark_hip_generate_batch_seeded(struct bark_context * bctx, const char * const * texts, int n, const uint32_t * seeds);
+/* The same with per-utterance parameters - the fields of bark_context_params a request may set for itself (the loops they steer:
+ * bark.cpp:1669-1695 step cap and stop rule, :201-247 temperatures); everything else comes from the context.  A server mixes
+ * requests with different settings in one job; tests make slots stop at chosen steps. */
+struct bark_hip_request_params {
+    float    temp;                  /* semantic / coarse sampling temperature, 0 = greedy (bark_context_params::temp)  */
+    float    fine_temp;             /* fine sampling temperature, 0 = greedy                                           */
+    float    min_eos_p;             /* stop rule of the semantic loop                                                  */
+    int32_t  n_steps_text_encoder;  /* step cap of the semantic loop                                                   */
+    uint32_t seed;                  /* seed of the utterance's own std::mt19937 (temp > 0 / fine_temp > 0)             */
+};
+BARK_API int bark_hip_generate_batch_ex(struct bark_context * bctx, const char * const * texts, int n, const struct bark_hip_request_params * per_utterance);
+/* Fixes the number of lock-step slots (1..64; at least 8 are allocated) before the first job; returns 0 or -1. */
+BARK_API int bark_hip_reserve_batch(struct bark_context * bctx, int slots);
 /* audio of utterance i of the last batch: returns the sample count (-1 on error), *data points into the context */
 BARK_API int bark_hip_batch_audio(struct bark_context * bctx, int i, float ** data);
 /* token stream of utterance i: stage 0 semantic, 1 coarse [T][2], 2 fine [T][8]; returns the id count or -1 */
@@ -98,16 +115,20 @@ BARK_API int bark_hip_batch_tokens(struct bark_context * bctx, int i, int stage,
 
 /* Request collector in front of bark_hip_generate_batch - what a server puts where the reference's example holds one mutex around
  * bark_generate_audio (examples/server/server.cpp:76-94,128-163).  Any number of host threads submit; one worker thread owns `bctx`
- * (nobody else may use it while the batcher lives), collects pending requests - up to max_batch (<= 32), waiting at most max_wait_ms
+ * (nobody else may use it while the batcher lives), collects pending requests - up to max_batch (<= 256; the context's slots, at most 64,
+ * serve them as one job), waiting at most max_wait_ms
  * for a batch to fill once one request is pending - and runs them as ONE lock-step batch.  A request's result is what a fresh context
  * seeded with its `seed` generates, whatever batch it travelled in (seed is irrelevant for temp == 0).
  *   submit: thread-safe, returns a ticket > 0 (or -1).
  *   wait  : blocks until the request is done; copies the PCM (24 kHz mono) and returns the sample count, -1 if the generation failed,
  *           -(2 + samples) if `capacity` is too small (the ticket stays valid).  A ticket is consumed by a successful or failed wait.
- *   free  : serves what is pending, then stops the worker. */
+ *   free  : serves what is pending, then stops the worker.  No thread may still be inside submit / wait of this batcher; tickets that were
+ *           never waited for are dropped. */
 struct bark_hip_batcher;
 BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context * bctx, int max_batch, int max_wait_ms);
 BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed);
+/* a request with its own parameters (nullptr: the context's) */
+BARK_API int64_t bark_hip_batcher_submit_ex(struct bark_hip_batcher * b, const char * text, const struct bark_hip_request_params * params);
 BARK_API int bark_hip_batcher_wait(struct bark_hip_batcher * b, int64_t ticket, float * pcm, int capacity);
 BARK_API void bark_hip_batcher_stats(struct bark_hip_batcher * b, int * n_batches, int * n_requests, int * largest_batch);
 BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b);
@@ -147,6 +168,12 @@ BARK_API double bark_hip_time_gemv(struct bark_context * bctx, int which, int op
  * (ops 0 / 2) and, for op 5, one workgroup per (head, slot); 6 = the matrix-core product with the LayerNorm fused (ops 0 / 2); any other value =
  * the matrix-core product on normalised f16 rows and, for op 5, the scores + mix pair of launches where the engine would use it.  f16 model files only. */
 BARK_API double bark_hip_time_slots(struct bark_context * bctx, int which, int op, int n_slots, int kind, int ctx, int iters);
+
+/* Time line of ONE lock step over n_slots slots of model `which` (0 semantic, 1 coarse) at context `ctx`: the step is enqueued eagerly `reps`
+ * times with a HIP event behind every launch site; writes a JSON array [{"site": ..., "us": average time from the previous event}, ...] in
+ * launch order (kernel time + the gap in front of it), closed by {"site": "step (graph replay)", "us": the same step replayed from its
+ * hipGraph}.  Returns the length written, or -1 (error / capacity too small). */
+BARK_API int bark_hip_profile_lock_step(struct bark_context * bctx, int which, int n_slots, int ctx, int reps, char * json_out, int capacity);
 
 /* Device time (us) of one fine forward pass (N = 1024), averaged over iters. */
 BARK_API double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, double * flops_per_pass);

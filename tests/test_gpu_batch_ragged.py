@@ -1,0 +1,129 @@
+"""Lock-step jobs (bark_hip_generate_batch_ex) under raggedness: every utterance of a job carries its own step cap, stop threshold,
+temperatures and seed, jobs are larger than the slot count (slots are refilled from the queue, the batch is compacted when nobody waits),
+and each utterance must equal ITS OWN oracle run - ids of all three stages and the PCM, bit for bit (reference loops:
+/root/reference/bark.cpp:1669-1695 step cap / stop rule, :1787-1845 coarse windows, :1998-2038 fine windows)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pkg():
+    from bark_amd_loader import load_package
+    return load_package()
+
+
+def _exact(name, got, ref):
+    got = np.asarray(got); ref = np.asarray(ref)
+    assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
+    if not np.array_equal(got, ref):
+        bad = np.flatnonzero(got.ravel() != ref.ravel())
+        raise AssertionError(f"{name}: {bad.size}/{got.size} elements differ, first at {bad[0]}")
+
+
+def _check_job(tag, res, orc, texts, reqs):
+    for i, (text, rq, r) in enumerate(zip(texts, reqs, res)):
+        orc.seed(int(rq.seed))
+        ref = orc.generate(text, orc.params(temp=rq.temp, fine_temp=rq.fine_temp, min_eos_p=rq.min_eos_p, n_steps_text_encoder=rq.n_steps_text_encoder))
+        t = f"{tag} utterance {i} (cap {rq.n_steps_text_encoder}, temp {rq.temp:.2f}/{rq.fine_temp:.2f}, min_eos_p {rq.min_eos_p:.2g}, seed {rq.seed})"
+        if len(ref["semantic"]) == 0 or ref["n_frames"] == 0:
+            assert r is None or len(r["pcm"]) == 0, t + ": the oracle produced no audio"
+            continue
+        assert r is not None, t + ": no audio"
+        _exact(t + " semantic", r["semantic"], ref["semantic"])
+        _exact(t + " coarse", r["coarse"], ref["coarse"])
+        _exact(t + " fine", r["fine"], ref["fine"])
+        _exact(t + " pcm", r["pcm"], ref["pcm"])
+
+
+@pytest.mark.parametrize("preset", ["toy", "mini"])
+def test_randomised_lock_step_jobs_against_the_oracle(preset):
+    """A seeded sweep: job sizes 2..40 on 8 / 16 / 64 slots, per-utterance caps 1..120 (one utterance per preset runs past 1024 frames:
+    several fine windows), stop thresholds that fire at different steps (mini), greedy and sampled utterances mixed in one job with their
+    own seeds."""
+    import bench
+    from oracle.pyoracle import Oracle
+    from tools.make_synth_model import ensure_model
+    pkg = _pkg()
+    path = ensure_model(preset, 0)
+    rng = np.random.default_rng({"toy": 4242, "mini": 2424}[preset])
+    words = " ".join(bench.synth_prompts(16)).split()
+    orc = Oracle(path, n_threads=4)
+    eos_choices = [0.2, 0.05] if preset == "toy" else [1.4e-4, 2.5e-4, 0.2]
+    trials = [(8, 21), (16, 5), (64, 40), (8, 2), (16, 33)] if preset == "toy" else [(8, 13), (16, 24), (64, 9)]
+    try:
+        for it, (slots, n) in enumerate(trials):
+            ctx = pkg.BarkContext.load_model(path, pkg.default_params(), seed=int(rng.integers(0, 2**31)))
+            ctx.reserve_batch(slots)
+            texts, reqs = [], []
+            for i in range(n):
+                texts.append(" ".join(rng.choice(words, size=int(rng.integers(1, 40)))))
+                sampled = rng.random() < 0.4
+                reqs.append(ctx.request_params(temp=float(rng.choice([0.7, 1.0])) if sampled else 0.0,
+                                               fine_temp=float(rng.choice([0.0, 0.5])) if sampled else 0.0,
+                                               min_eos_p=float(rng.choice(eos_choices)), n_steps_text_encoder=int(rng.integers(1, 121)),
+                                               seed=int(rng.integers(0, 2**31))))
+            if it == 0:
+                reqs[n // 2].n_steps_text_encoder = 700          # > 1024 frames unless the stop rule fires: windows of 1024 hopping by 512
+                reqs[n // 2].min_eos_p = 0.9
+            res = ctx.generate_batch(texts, params=reqs)
+            _check_job(f"{preset} job {it} ({n} utterances on {slots} slots)", res, orc, texts, reqs)
+            if it == 0:
+                assert len(res[n // 2]["fine"]) > 1024 or preset == "mini"
+            # the same context again with another job: slots, caches and graphs are reused
+            res2 = ctx.generate_batch(texts[:3][::-1], params=reqs[:3][::-1])
+            _check_job(f"{preset} job {it}, second job on the context", res2, orc, texts[:3][::-1], reqs[:3][::-1])
+            ctx.free()
+    finally:
+        orc.close()
+
+
+def test_job_larger_than_the_slots_equals_the_job_on_enough_slots(toy_model):
+    """23 utterances through 8 slots (queue, refills, compaction) against the same 23 on 32 slots: the company an utterance travels in
+    changes nothing."""
+    import bench
+    pkg = _pkg()
+    texts = bench.synth_prompts(23)
+    outs = []
+    for slots in (8, 32):
+        ctx = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=40), 0)
+        ctx.reserve_batch(slots)
+        reqs = [ctx.request_params(n_steps_text_encoder=10 + 7 * (i % 9)) for i in range(len(texts))]
+        outs.append(ctx.generate_batch(texts, params=reqs))
+        ctx.free()
+    for i, (a, b) in enumerate(zip(*outs)):
+        for k in ("semantic", "coarse", "fine", "pcm"):
+            _exact(f"utterance {i} {k}", a[k], b[k])
+
+
+@pytest.mark.slow
+def test_small_ragged_job_matches_committed_oracle_outputs(small_model):
+    """bark-small shapes, 16 slots, the ragged form of BASELINE config 5 (bench.ragged_caps: step caps 64..256 by prompt length): every
+    16th... every 4th of the 64 bench prompts against oracle outputs committed as tests/golden/oracle_small_ragged16.npz
+    (tools/make_oracle_golden.py ragged; the CPU suite re-derives a sample of them)."""
+    import bench
+    pkg = _pkg()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_small_ragged16.npz"))
+    prompts = bench.synth_prompts(64)
+    caps = bench.ragged_caps(prompts)
+    idx = [int(i) for i in g["prompt_index"]]
+    ctx = pkg.BarkContext.load_model(small_model, pkg.default_params(temp=0.0, fine_temp=0.0), 0)
+    ctx.reserve_batch(16)
+    reqs = [ctx.request_params(n_steps_text_encoder=caps[i]) for i in idx]
+    res = ctx.generate_batch([prompts[i] for i in idx], params=reqs)
+    import hashlib
+    for k, i in enumerate(idx):
+        assert res[k] is not None
+        assert len(res[k]["semantic"]) == caps[i]
+        _exact(f"prompt {i} semantic", res[k]["semantic"], g[f"semantic{k}"].astype(np.int32))
+        _exact(f"prompt {i} coarse", res[k]["coarse"], g[f"coarse{k}"].astype(np.int32))
+        _exact(f"prompt {i} fine", res[k]["fine"], g[f"fine{k}"].astype(np.int32))
+        pcm = np.ascontiguousarray(res[k]["pcm"], np.float32)
+        assert pcm.size == int(g[f"pcm_len{k}"])
+        assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), g[f"pcm_sha256_{k}"]), f"prompt {i}: PCM differs from the oracle's"
+    ctx.free()
