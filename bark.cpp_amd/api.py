@@ -75,7 +75,7 @@ EXPORTS = [
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_generate_batch_ex", "bark_hip_reserve_batch", "bark_hip_profile_lock_step", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe",
-    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_free",
+    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_admitted", "bark_hip_batcher_free",
 ]
 
 
@@ -150,6 +150,7 @@ def load_library() -> C.CDLL:
     lib.bark_hip_batcher_wait.argtypes = [vp, C.c_int64, fp, C.c_int]
     lib.bark_hip_batcher_stats.restype = None
     lib.bark_hip_batcher_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bark_hip_batcher_admitted.argtypes = [vp]
     lib.bark_hip_batcher_free.restype = None
     lib.bark_hip_batcher_free.argtypes = [vp]
     lib.bark_hip_time_fine_passes.restype = C.c_double
@@ -496,7 +497,7 @@ class Batcher:
     def stats(self) -> dict:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._lib.bark_hip_batcher_stats(self._b, C.byref(a), C.byref(b), C.byref(c))
-        return {"n_batches": a.value, "n_requests": b.value, "largest_batch": c.value}
+        return {"n_batches": a.value, "n_requests": b.value, "largest_batch": c.value, "n_admitted": int(self._lib.bark_hip_batcher_admitted(self._b))}
 
     def free(self):
         if self._b:

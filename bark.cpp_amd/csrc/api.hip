@@ -189,7 +189,7 @@ int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T,
 }
 
 int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat, const int * T, int n, int32_t * out_concat, int capacity_rows) {
-    if (!bctx || !coarse_concat || !T || n <= 0 || !out_concat) return -1;
+    if (!bctx || !coarse_concat || !T || n <= 0 || n > 64 || !out_concat) return -1;          // 64 windows side by side: 270 MB of logits
     return guarded("bark_hip_fine_many", -1, [&] {
         std::vector<std::vector<int32_t>> co((size_t) n);
         std::vector<const std::vector<int32_t> *> ptr;

@@ -315,9 +315,8 @@ __global__ __launch_bounds__(256) void attn_slots_mix_kernel(const AttnDecodeArg
     lsum = wave_sum(lsum);
     if (lane == 0) red_d[wave] = lsum;
     __syncthreads();
-    double sum = red_d[0];
-    #pragma unroll
-    for (int w = 1; w < NW; w++) sum += red_d[w];
+    static_assert(NW == 4, "the waves' partial sums are combined as in attn_fused_kernel");
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
     const float inv = (float) (1.0 / sum);
     float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     auto mix16 = [&](const float4 (&vv)[16], int g) {               // keys chain + 16 (16 g + i), i < 16

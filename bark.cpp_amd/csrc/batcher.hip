@@ -138,6 +138,12 @@ BARK_API void bark_hip_batcher_stats(struct bark_hip_batcher * b, int * n_batche
     if (largest_batch) *largest_batch = b->largest;
 }
 
+BARK_API int bark_hip_batcher_admitted(struct bark_hip_batcher * b) {
+    if (!b) return -1;
+    std::lock_guard<std::mutex> lk(b->mu);
+    return b->n_admitted;
+}
+
 BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b) {
     if (!b) return;
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }

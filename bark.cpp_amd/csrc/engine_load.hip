@@ -190,7 +190,12 @@ bark_context * engine_load(const char * path, const bark_context_params & params
     if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("BARK_HIP_DEVICE out of range");
     HIP_OK(hipSetDevice(ctx->device));
     if (const char * e = getenv("BARK_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
-    if (const char * e = getenv("BARK_HIP_FAST_GEMM")) ctx->fast_gemm = atoi(e);
+    if (const char * e = getenv("BARK_HIP_FAST_GEMM")) {
+        // "1" selects the tolerance route; anything else but "0" / "" is refused instead of silently meaning something (it once selected an
+        // instruction-order variant of the canonical route)
+        if (!strcmp(e, "1")) ctx->fast_gemm = 1;
+        else if (strcmp(e, "0") && *e) throw std::runtime_error("BARK_HIP_FAST_GEMM accepts 0 or 1");
+    }
     HIP_OK(hipStreamCreate(&ctx->stream));
     init_kernel_attributes();
 

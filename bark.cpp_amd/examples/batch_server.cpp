@@ -53,8 +53,13 @@ void respond(int fd, int status, const char * reason, const char * type, const s
 }
 
 std::atomic<uint32_t> next_seed{0};
+std::atomic<int> open_connections{0};
+constexpr int kMaxConnections = 512;                     // beyond that a connection is answered 503 at once
 
 void serve(int fd, bark_hip_batcher * batcher, int sample_rate) {
+    struct Guard { ~Guard() { open_connections.fetch_sub(1); } } guard;
+    timeval tv{10, 0};                                       // a client that stops sending does not park this thread for ever
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     std::string req;
     char buf[4096];
     size_t head_end = std::string::npos;
@@ -106,7 +111,7 @@ void serve(int fd, bark_hip_batcher * batcher, int sample_rate) {
 }
 
 void usage(const char * argv0) {
-    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 32)] [--max-wait-ms n] [--temp t] [--fine-temp t]\n", argv0);
+    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 256; the context serves up to 64 at a time)] [--max-wait-ms n] [--temp t] [--fine-temp t]\n", argv0);
 }
 
 }  // namespace
@@ -152,6 +157,12 @@ int main(int argc, char ** argv) {
     while (true) {
         const int fd = ::accept(lfd, nullptr, nullptr);
         if (fd < 0) continue;
+        if (open_connections.fetch_add(1) >= kMaxConnections) {
+            open_connections.fetch_sub(1);
+            respond(fd, 503, "Service Unavailable", "text/plain", "too many connections");
+            ::close(fd);
+            continue;
+        }
         std::thread(serve, fd, batcher, params.sample_rate).detach();
     }
 }

@@ -7,15 +7,16 @@
 
 namespace barkhttp {
 
-// the string value of `key` in a flat JSON object (escapes \" \\ \/ \n \t \r \b \f and \uXXXX below 0x80 are decoded; that is all a prompt needs)
+// the string value of `key` in a flat JSON object (escapes \" \\ \/ \n \t \r \b \f and \uXXXX incl. surrogate pairs are decoded to UTF-8)
 inline bool json_string(const std::string & js, const char * key, std::string & out) {
     const std::string pat = std::string("\"") + key + "\"";
     size_t p = js.find(pat);
     if (p == std::string::npos) return false;
     p = js.find(':', p + pat.size());
     if (p == std::string::npos) return false;
-    p = js.find('"', p);
-    if (p == std::string::npos) return false;
+    p++;
+    while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n' || js[p] == '\r')) p++;
+    if (p >= js.size() || js[p] != '"') return false;            // the value of `key` must itself be a string ({"text": 12, "x": "y"} has no text)
     out.clear();
     for (size_t i = p + 1; i < js.size(); i++) {
         const char ch = js[i];
@@ -30,9 +31,17 @@ inline bool json_string(const std::string & js, const char * key, std::string & 
             case 'f': out.push_back('\f'); break;
             case 'u': {
                 if (i + 4 >= js.size()) return false;
-                const unsigned cp = (unsigned) strtoul(js.substr(i + 1, 4).c_str(), nullptr, 16);
+                unsigned cp = (unsigned) strtoul(js.substr(i + 1, 4).c_str(), nullptr, 16);
                 i += 4;
-                if (cp < 0x80) out.push_back((char) cp);
+                if (cp >= 0xD800 && cp < 0xDC00 && i + 6 < js.size() && js[i + 1] == '\\' && js[i + 2] == 'u') {      // surrogate pair -> one code point
+                    const unsigned lo = (unsigned) strtoul(js.substr(i + 3, 4).c_str(), nullptr, 16);
+                    if (lo >= 0xDC00 && lo < 0xE000) { cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); i += 6; }
+                }
+                if (cp >= 0x10000) {
+                    out.push_back((char) (0xF0 | (cp >> 18))); out.push_back((char) (0x80 | ((cp >> 12) & 0x3F)));
+                    out.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); out.push_back((char) (0x80 | (cp & 0x3F)));
+                }
+                else if (cp < 0x80) out.push_back((char) cp);
                 else if (cp < 0x800) { out.push_back((char) (0xC0 | (cp >> 6))); out.push_back((char) (0x80 | (cp & 0x3F))); }
                 else { out.push_back((char) (0xE0 | (cp >> 12))); out.push_back((char) (0x80 | ((cp >> 6) & 0x3F))); out.push_back((char) (0x80 | (cp & 0x3F))); }
                 break;

@@ -61,8 +61,9 @@ BARK_API int bark_hip_fine_eval(struct bark_context * bctx, const int32_t * toke
 BARK_API int bark_hip_semantic(struct bark_context * bctx, const int32_t * prompt513, int32_t * out, int capacity, float * eos_trace);
 BARK_API int bark_hip_coarse(struct bark_context * bctx, const int32_t * semantic, int n_semantic, int32_t * out_Tx2, int capacity_rows);
 BARK_API int bark_hip_fine(struct bark_context * bctx, const int32_t * coarse_Tx2, int T, int32_t * out_Tx8, int capacity_rows);
-/* The fine stage of n utterances with their windows side by side in every forward pass (what bark_hip_generate_batch runs; greedy or
- * device multinomial drawn from the context's generator utterance by utterance; f16 model files).  coarse: the utterances' [T_i][2]
+/* The fine stage of n <= 64 utterances with their windows side by side in every forward pass (what bark_hip_generate_batch runs; f16 model
+ * files).  Greedy, or device multinomial with ONE std::mt19937 PER UTTERANCE, each seeded with the next draw of the context's generator
+ * (as the utterances of bark_hip_generate_batch are: with fine_temp > 0, fine_many(n = 1) is therefore not bark_hip_fine on the same context).  coarse: the utterances' [T_i][2]
  * arrays back to back, out: their [T_i][8] results back to back (capacity_rows >= sum T_i).  Returns sum T_i or -1. */
 BARK_API int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat, const int * T, int n, int32_t * out_concat, int capacity_rows);
 
@@ -131,6 +132,9 @@ BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char
 BARK_API int64_t bark_hip_batcher_submit_ex(struct bark_hip_batcher * b, const char * text, const struct bark_hip_request_params * params);
 BARK_API int bark_hip_batcher_wait(struct bark_hip_batcher * b, int64_t ticket, float * pcm, int capacity);
 BARK_API void bark_hip_batcher_stats(struct bark_hip_batcher * b, int * n_batches, int * n_requests, int * largest_batch);
+/* requests that joined a job that was already running (continuous admission: while the semantic stage of a job has free slots, requests
+ * arriving in the meantime are taken along, up to max_batch per job) */
+BARK_API int bark_hip_batcher_admitted(struct bark_hip_batcher * b);
 BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b);
 
 /* Token streams of the last bark_generate_audio call (copied out; returns counts). */

@@ -127,3 +127,40 @@ def test_small_ragged_job_matches_committed_oracle_outputs(small_model):
         assert pcm.size == int(g[f"pcm_len{k}"])
         assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), g[f"pcm_sha256_{k}"]), f"prompt {i}: PCM differs from the oracle's"
     ctx.free()
+
+
+def test_request_collector_admits_late_requests_with_their_own_parameters(toy_model, toy_oracle):
+    """bark_hip_batcher with continuous admission: a long request opens a job; requests submitted while it is in its semantic stage join the
+    running job (free slots, nobody of the job waiting) instead of waiting for the next one.  Every request carries its own parameters and
+    gets the PCM of its own oracle run."""
+    import threading
+    import time
+    import bench
+    pkg = _pkg()
+    texts = bench.synth_prompts(9)
+    c = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=24), 0)
+    b = pkg.Batcher(c, max_batch=16, max_wait_ms=1)
+    reqs = [c.request_params(n_steps_text_encoder=700, min_eos_p=0.9)]                       # the opener: hundreds of lock steps
+    reqs += [c.request_params(n_steps_text_encoder=8 + 5 * i, temp=0.7 if i % 3 == 0 else 0.0, fine_temp=0.5 if i % 3 == 0 else 0.0, seed=100 + i) for i in range(1, len(texts))]
+    out = [None] * len(texts)
+
+    def client(i, delay):
+        time.sleep(delay)
+        out[i] = b.wait(b.submit(texts[i], params=reqs[i]))
+
+    try:
+        th = [threading.Thread(target=client, args=(i, 0.0 if i == 0 else 0.02 + 0.004 * i)) for i in range(len(texts))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        st = b.stats()
+        assert st["n_requests"] == len(texts), st
+        assert st["n_admitted"] >= 1, f"no request joined the running job: {st}"
+        for i, (text, rq) in enumerate(zip(texts, reqs)):
+            toy_oracle.seed(int(rq.seed))
+            ref = toy_oracle.generate(text, toy_oracle.params(temp=rq.temp, fine_temp=rq.fine_temp, min_eos_p=rq.min_eos_p, n_steps_text_encoder=rq.n_steps_text_encoder))
+            _exact(f"request {i}", out[i], ref["pcm"])
+    finally:
+        b.free()
+        c.free()

@@ -170,6 +170,39 @@ def test_committed_batch_fixture_is_what_the_oracle_generates():
     assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), want[f"pcm_sha256_{i}"])
 
 
+def test_committed_ragged_fixture_is_what_the_oracle_generates():
+    """tests/golden/oracle_small_ragged16.npz (the ragged form of config 5: every 4th bench prompt with its step cap from bench.ragged_caps)
+    stands in for 16 live oracle runs in test_small_ragged_job_matches_committed_oracle_outputs; here the oracle re-derives one of them
+    (the index moves with the fixture's own content)."""
+    import hashlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench
+    import make_oracle_golden
+    from oracle.pyoracle import Oracle
+    from tools.make_synth_model import ensure_model
+    want = np.load(os.path.join(root, "tests", "golden", "oracle_small_ragged16.npz"))
+    prompts = bench.synth_prompts(64)
+    caps = bench.ragged_caps(prompts)
+    idx = [int(i) for i in want["prompt_index"]]
+    assert len(idx) == 16 and [caps[i] for i in idx] == [int(v) for v in want["caps"]]
+    path = ensure_model("small", 0)
+    assert np.array_equal(make_oracle_golden.file_sha256(path), want["model_sha256"])
+    k = int(want["pcm_sha256_0"][0]) % 16
+    orc = Oracle(path, n_threads=8)
+    try:
+        ref = orc.generate(prompts[idx[k]], orc.params(n_steps_text_encoder=caps[idx[k]]))
+    finally:
+        orc.close()
+    pcm = np.ascontiguousarray(ref["pcm"], np.float32)
+    assert np.array_equal(ref["semantic"], want[f"semantic{k}"]) and np.array_equal(ref["coarse"], want[f"coarse{k}"]) and np.array_equal(ref["fine"], want[f"fine{k}"])
+    assert pcm.size == int(want[f"pcm_len{k}"])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(pcm.tobytes()).digest(), np.uint8), want[f"pcm_sha256_{k}"])
+
+
 def test_large_256_step_fixture_extends_the_64_step_one():
     """tests/golden/oracle_large_256.npz (BASELINE config 3's full workload) takes four minutes of oracle time and is therefore not
     re-derived here; greedy decoding makes the 64-step run (re-derived above) a prefix of it, which ties the two files together."""
