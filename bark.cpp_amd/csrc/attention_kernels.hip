@@ -554,7 +554,158 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole-window attention of the fine model (non-causal, 1024 queries x 1024 keys per window and head; orders C2 / C4 / C5 as everywhere):
+// the scores never leave the registers.  One workgroup (8 waves) per (window, head, 32 queries); wave w OWNS the chains 2w and 2w + 1 of C5,
+// i.e. the 128 keys j with j mod 16 in {2w, 2w + 1}, for scores AND mix:
+//   1. S^T = K Q^T on the f32 matrix cores, the score tile TRANSPOSED (row = key, column = query): accumulator register r of lane
+//      (half h, query q) of tile t holds key  2w + (r >> 3) + 16 (16 t + 2 (r & 7) + h)  - the K rows a lane supplies are permuted accordingly.
+//      C2: one accumulator per block of 16 d, (c0 + c1) + (c2 + c3), * 0.125.
+//   2. softmax in place (C4): a lane holds 64 scores of ITS query; maximum and double sum meet across the two halves by a lane swap and
+//      across the waves through 2 x 1 KB of LDS; e = (float) exp((double)(s - max)), p = e * (float)(1 / sum).
+//   3. O = P V: register r of the lane IS the A operand of the MFMA that adds keys (.., h = 0) and (.., h = 1) - two consecutive keys of
+//      chain 2w + (r >> 3) - to that chain's accumulator: registers 8 b .. 8 b + 7 of tiles 0 .. 3 walk chain 2w + b in ascending key order.
+//   4. chains 2w + (2w + 1) meet in the wave, the eight waves through LDS in C5's tree order.
+// Against attn_rows_kernel (scores through a 128 KB LDS tile, one barrier per phase, each wave reading all probabilities of its chains back):
+// no score traffic at all, 64 exponentials per lane with full instruction-level parallelism.  Same operations per element: same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int FQ_LD = 68;                                            // floats per staged query row (64 + 4: a ds_read_b128 of 32 rows covers all banks)
+__global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillArgs a0) {
+    __shared__ __attribute__((aligned(16))) float qs[32 * FQ_LD];   // the query tile
+    __shared__ float red_m[8][32];
+    __shared__ double red_s[8][32];
+    __shared__ __attribute__((aligned(16))) float part[8 * 32 * 64];            // partial outputs of the waves (64 KB)
+    AttnPrefillArgs a = a0;
+    constexpr int S = 1024;
+    const int QT = S / 32, rank = xcd_rank(blockIdx.x, QT * a.H * max(1, a.Z));
+    const int hd = (rank / QT) % a.H, i0 = (rank % QT) * 32;
+    {
+        const size_t z = rank / (QT * a.H);
+        a.q += z * (size_t) S * a.ldq;
+        if (a.att) a.att += z * (size_t) S * a.ld_att;
+        if (a.att32) a.att32 += z * (size_t) S * a.ld_att;
+        a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    // query tile -> LDS (512 threads x one float4)
+    {
+        const int row = tid >> 4, c4 = tid & 15;
+        *reinterpret_cast<float4 *>(qs + row * FQ_LD + 4 * c4) = *reinterpret_cast<const float4 *>(a.q + (size_t) (i0 + row) * a.ldq + hd * 64 + 4 * c4);
+    }
+    // the key whose K row this lane supplies to tile t (A operand: lane l31 = tile row rho = (r & 3) + 8 (r >> 2) + 4 h')
+    const int hp = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
+    const int key_a0 = 2 * w + (rr >> 3) + 16 * (2 * (rr & 7) + hp);                 // + 256 t
+    const float4 * kbase = reinterpret_cast<const float4 *>(a.kc) + (size_t) hd * 16 * a.P + key_a0;
+    floatx16 sc[4];
+    // ---- 1. scores ------------------------------------------------------------------------------------
+    {
+        // block n = 4 t + b (tile t, 16-d block b): four register sets, a block's K rows are requested three blocks (24 MFMAs of this wave,
+        // twice that on the SIMD) before they are multiplied - one block ahead left the matrix cores waiting for memory
+        float4 ks[4][4];
+        auto load_blk = [&](float4 (&kv)[4], int n) {
+            #pragma unroll
+            for (int i = 0; i < 4; i++) kv[i] = kbase[(size_t) (4 * (n & 3) + i) * a.P + 256 * (n >> 2)];
+        };
+        load_blk(ks[0], 0); load_blk(ks[1], 1); load_blk(ks[2], 2);
+        __syncthreads();                                         // the query tile is in LDS (the first K rows are already on their way)
+        #pragma unroll
+        for (int t = 0; t < 4; t++) {
+            floatx16 acc[4];
+            #pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int n = 4 * t + b;
+                if (n + 3 < 16) load_blk(ks[(n + 3) & 3], n + 3);
+                #pragma unroll
+                for (int r = 0; r < 16; r++) acc[b][r] = 0.0f;
+                #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 kv = ks[n & 3][i];
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + l31 * FQ_LD + 4 * (4 * b + i));
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? kv.y : kv.x, half ? qv.y : qv.x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? kv.w : kv.z, half ? qv.w : qv.z, acc[b], 0, 0, 0);
+                }
+            }
+            #pragma unroll
+            for (int r = 0; r < 16; r++) sc[t][r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * 0.125f;      // 1/sqrt(64), bark.cpp:1318
+        }
+    }
+    // ---- 2. softmax of query l31 (this lane: 64 of its 1024 scores) -------------------------------------
+    float mx = -INFINITY;
+    #pragma unroll
+    for (int t = 0; t < 4; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (half == 0) red_m[w][l31] = mx;
+    __syncthreads();
+    mx = red_m[0][l31];
+    #pragma unroll
+    for (int i = 1; i < 8; i++) mx = fmaxf(mx, red_m[i][l31]);
+    double ls[4] = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+    for (int t = 0; t < 4; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) { const float e = (float) exp((double) (sc[t][r] - mx)); sc[t][r] = e; ls[r & 3] += (double) e; }
+    double lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (half == 0) red_s[w][l31] = lsum;
+    __syncthreads();
+    const double sum = ((red_s[0][l31] + red_s[1][l31]) + (red_s[2][l31] + red_s[3][l31])) + ((red_s[4][l31] + red_s[5][l31]) + (red_s[6][l31] + red_s[7][l31]));
+    const float inv = (float) (1.0 / sum);
+    #pragma unroll
+    for (int t = 0; t < 4; t++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) sc[t][r] = sc[t][r] * inv;                      // p = e * (float)(1/sum), as ggml_soft_max scales in place
+    // ---- 3. mix: chains 2w (b = 0) and 2w + 1 (b = 1), two 32-dim column tiles ---------------------------
+    floatx16 o[2][2];
+    #pragma unroll
+    for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) for (int r = 0; r < 16; r++) o[b][c][r] = 0.0f;
+    // B operand: V[key of (t, r, this lane's half)][2 l31 + c] - column l31 of dim tile c is dim 2 l31 + c, so that ONE 8-byte load feeds both tiles
+    const float2 * vlane = reinterpret_cast<const float2 *>(a.vc + (size_t) hd * a.P * 64 + (size_t) (2 * w + 16 * half) * 64) + l31;   // key = 2w + (r >> 3) + 16 (16 t + 2 (r & 7) + half)
+    // groups of 8 registers = 16 consecutive keys of ONE chain (group g: tile g >> 1, chain 2w + (g & 1)); four register sets, a group's
+    // values are requested three groups (48 MFMAs) ahead
+    float2 vs[4][8];
+    auto load_v = [&](float2 (&vv)[8], int g) {
+        #pragma unroll
+        for (int i = 0; i < 8; i++) vv[i] = vlane[(size_t) ((g & 1) + 16 * (16 * (g >> 1) + 2 * i)) * 32];
+    };
+    load_v(vs[0], 0); load_v(vs[1], 1); load_v(vs[2], 2);
+    #pragma unroll
+    for (int g = 0; g < 8; g++) {
+        if (g + 3 < 8) load_v(vs[(g + 3) & 3], g + 3);
+        #pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float2 v = vs[g & 3][i];
+            o[g & 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[g >> 1][8 * (g & 1) + i], v.x, o[g & 1][0], 0, 0, 0);
+            o[g & 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[g >> 1][8 * (g & 1) + i], v.y, o[g & 1][1], 0, 0, 0);
+        }
+    }
+    // ---- 4. the 16 chains meet: 2w + (2w + 1) here, the waves in LDS (tree levels xor 2, 4, 8) ------------
+    #pragma unroll
+    for (int c = 0; c < 2; c++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;         // accumulator row = query, column = dim
+            part[(w * 32 + row) * 64 + 2 * l31 + c] = o[0][c][r] + o[1][c][r];
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 64; idx += 512) {
+        const int row = idx >> 6, d = idx & 63;
+        float pp[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) pp[q] = part[(q * 32 + row) * 64 + d];
+        const float v = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+        const size_t oi = (size_t) (i0 + row) * a.ld_att + hd * 64 + d;
+        if (a.att32) a.att32[oi] = v; else a.att[oi] = to_half(v);
+    }
+}
+
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
+    // whole windows of the fine model: the register-resident kernel (BARK_HIP_CROSSCHECK bit 9 (512) keeps attn_rows_kernel)
+    if (!a.causal && a.N == 1024 && a.n_past == 0 && !a.seqtab && a.P >= 1024 && !(crosscheck_mask() & 512)) {
+        hipLaunchKernelGGL(attn_window_kernel, dim3(32 * a.H * std::max(1, a.Z)), dim3(512), 0, s, a);
+        return;
+    }
     hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32 * a.H * std::max(1, a.Z)), dim3(512), 32 * ATT_LD * sizeof(float), s, a);
 }
 

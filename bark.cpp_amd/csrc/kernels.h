@@ -217,6 +217,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 // 128  lock-step batches: the LayerNorm of the slot rows as a launch of its own in front of the QKV / FC / LM-head products instead of inside them
 // 256  fine model: products as C1 chains on the f32 matrix cores (the canonical order of rounds 1 - 3) instead of C1m on the f16 matrix cores;
 //      the oracle follows with set_fine_mfma(False)
+// 512  fine model: the attention of whole windows through attn_rows_kernel (scores in an LDS tile) instead of attn_window_kernel (scores in registers)
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
 void init_kernel_attributes();
