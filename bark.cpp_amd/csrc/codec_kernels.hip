@@ -2,9 +2,12 @@
 // transposed-conv stack).  Architecture restated from HF transformers modeling_encodec.py:82-450 (the
 // model the reference's convert.py converts from; the reference delegates this stage to the
 // un-vendored encodec.cpp, call site /root/reference/bark.cpp:2143-2167).
-// Convolutions are exact-order direct kernels (register-blocked, one fmaf chain per output in (ci, k) order).
-// Every kernel takes a CodecBatch: several utterances of different lengths run in one launch (grid.z = utterance), each on its own
-// compact [C][T] arrays laid back to back - the codec of a lock-step batch costs the launches of ONE utterance.
+// Activations are TIME-MAJOR [row][C] (row = frame of the stage; the utterances of a batch back to back: utterance b owns rows
+// [tm Tpre[b], tm Tpre[b + 1]) at a stage with upsampling factor tm), so that a convolution is a product on the f16 matrix cores: order
+// C9m = the arithmetic of v_mfma_f32_32x32x16_f16 (oracle/mfma_f16_emu.h) over the axis kd = k * cin + ci (transposed conv: one product
+// per output phase over tap * cin + ci).  Convolutions whose input channel count is not a multiple of 8 (toy models) keep order C9 (one fmaf
+// chain in (ci, k) order) in a plain kernel; BARK_HIP_CROSSCHECK bit 10 (1024) sends every convolution there (oracle: set_codec_mfma(False)).
+// Every kernel takes a CodecBatch: the codec of a lock-step batch costs the launches of ONE utterance.
 #include "kernels.h"
 
 namespace barkhip {
@@ -19,23 +22,34 @@ __device__ __forceinline__ UttView utt_view(const CodecBatch & cb, int T, int tm
     return UttView{cb.T[z] * tmul_in, (size_t) cin * tmul_in * cb.Tpre[z], (size_t) cout * tmul_out * cb.Tpre[z]};
 }
 
-__global__ void rvq_gather_kernel(const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T_, float * z, const CodecBatch cb) {
-    const UttView u = utt_view(cb, T_, 1, 1, n_q, Hd);
-    const int T = u.T;
-    codes += u.in_off; z += u.out_off;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int d = blockIdx.y;
-    if (t >= T) return;
-    float v = 0.0f;                                              // quantized_out = 0 + sum_q embed_q[code] (modeling_encodec.py:440-448)
-    for (int q = 0; q < n_q; q++) {
-        int id = codes[(size_t) q * T + t];
-        id = min(max(id, 0), n_bins - 1);
-        v = v + codebooks[((size_t) q * n_bins + id) * Hd + d];
-    }
-    z[(size_t) d * T + t] = v;
+// first row of the utterance that owns global row `row` at upsampling factor tm, and that utterance's row count
+__device__ __forceinline__ void utt_of_row(const CodecBatch & cb, int T_single, int tm, int row, int & row0, int & rows) {
+    if (!cb.T) { row0 = 0; rows = T_single * tm; return; }
+    int z = 0;
+    while (z + 1 < cb.B && row >= cb.Tpre[z + 1] * tm) z++;
+    row0 = cb.Tpre[z] * tm; rows = cb.T[z] * tm;
 }
-void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, float * z, const CodecBatch & cb) {
-    hipLaunchKernelGGL(rvq_gather_kernel, dim3((T + 127) / 128, Hd, cb.B), dim3(128), 0, s, codebooks, n_bins, Hd, codes, n_q, T, z, cb);
+
+// z[frame][h] = 0 + sum_q embed_q[code] (modeling_encodec.py:440-448); codes of utterance b: [n_q][T[b]] at n_q Tpre[b]
+__global__ void rvq_gather_kernel(const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T_, int rows_total, float * z, const CodecBatch cb) {
+    const int row = blockIdx.x;
+    if (row >= rows_total) return;
+    int row0, rows;
+    utt_of_row(cb, T_, 1, row, row0, rows);
+    const int32_t * cz = codes + (size_t) n_q * row0;
+    const int t = row - row0;
+    for (int d = threadIdx.x; d < Hd; d += blockDim.x) {
+        float v = 0.0f;
+        for (int q = 0; q < n_q; q++) {
+            int id = cz[(size_t) q * rows + t];
+            id = min(max(id, 0), n_bins - 1);
+            v = v + codebooks[((size_t) q * n_bins + id) * Hd + d];
+        }
+        z[(size_t) row * Hd + d] = v;
+    }
+}
+void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, int rows_total, float * z, const CodecBatch & cb) {
+    hipLaunchKernelGGL(rvq_gather_kernel, dim3(rows_total), dim3(128), 0, s, codebooks, n_bins, Hd, codes, n_q, T, rows_total, z, cb);
 }
 
 // see kernels.hip: keeps the compiler from fusing the producing multiply into the f16 conversion
@@ -56,154 +70,115 @@ void launch_act_round(hipStream_t s, const float * x, size_t n, int elu, half_t 
 
 // EncodecConv1d: causal, stride 1, pad_mode reflect (modeling_encodec.py:140-176): left pad K - 1; the reflect source of padded index
 // i < left is x[left - i]; inputs shorter than the pad are zero-extended first.
-// EncodecConvTranspose1d, causal: full output (T - 1) s + K, trimmed by K - s on the right (modeling_encodec.py:206-233).
-// Register-blocked kernels, one fmaf chain per output element: ci ascending, k ascending, bias last.
-// Weights are kept as f32 copies of the f16 file values (exact) so that a wave-uniform weight becomes a scalar load and an
-// SGPR operand of v_fma_f32; every x value loaded is reused by CO x (taps that touch it) multiply-adds.
-template <int CO, int TT, int K>
-__global__ __launch_bounds__(256) void conv1d_blocked_kernel(const float * __restrict__ w, const float * __restrict__ bias, int cout, int cin,
-                                                            const half_t * __restrict__ xh, int T_, const float * add, float * y, const CodecBatch cb, int tmul) {
-    const UttView u = utt_view(cb, T_, tmul, tmul, cin, cout);
-    const int T = u.T;
-    xh += u.in_off; y += u.out_off; if (add) add += u.out_off;
-    const int t0 = (blockIdx.x * blockDim.x + threadIdx.x) * TT;
-    const int co0 = blockIdx.y * CO;
-    if (t0 >= T) return;
-    float acc[CO][TT];
+// EncodecConvTranspose1d, causal, kernel 2 s: full output (T - 1) s + K trimmed by K - s on the right (modeling_encodec.py:206-233):
+// output row q s + r takes frame q - 1 through kernel element r + s and frame q through element r.
+// source row of tap kk for the output built from input row t of an utterance of `rows` rows; -1: the operand is zero
+__device__ __forceinline__ int conv_src_row(int convT, int K, int kk, int t, int rows) {
+    int j;
+    if (convT) j = t - 1 + kk;                                    // tap 0: the previous frame, tap 1: this frame
+    else { j = t + kk - (K - 1); j = j < 0 ? -j : j; }            // reflect on the left
+    return (j >= 0 && j < rows) ? j : -1;
+}
+
+// C9m: one wave = 32 input rows x 32 output channels of one output phase; A = kernel image rows (co), B = activation rows (time), both
+// 8 consecutive kd per lane = one 16-byte load; the accumulator walks kd in ascending blocks of 16 - the canonical chain.
+typedef float floatx16c __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void conv_tm_mfma_kernel(const ConvTmArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int row = (blockIdx.x * 4 + w) * 32 + l31;              // global input row of this lane's column
+    const int co0 = blockIdx.y * 32, phase = blockIdx.z;
+    const bool live = row < a.rows_in;
+    int row0 = 0, rows = 0;
+    if (live) utt_of_row(a.cb, a.T_single, a.tm_in, row, row0, rows);
+    const int t = row - row0;
+    const int nkb = a.kd16 >> 4;
+    const half_t * wrow = a.W + ((size_t) phase * a.cout32 + co0 + l31) * a.kd16 + 8 * half;
+    floatx16c acc;
     #pragma unroll
-    for (int c = 0; c < CO; c++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    auto load_b = [&](int kb) {
+        const int kdd = 16 * kb + 8 * half;
+        half8 bv;
         #pragma unroll
-        for (int j = 0; j < TT; j++) acc[c][j] = 0.0f;
-    const bool interior = t0 >= K - 1 && t0 + TT <= T;
-    for (int ci = 0; ci < cin; ci++) {
-        const half_t * xr = xh + (size_t) ci * T;
-        float xv[TT + K - 1];                                   // inputs t0-(K-1) .. t0+TT-1, reflect-padded on the left
-        if (interior) {
-            #pragma unroll
-            for (int i = 0; i < TT + K - 1; i++) xv[i] = (float) xr[t0 - (K - 1) + i];
-        } else {
-            #pragma unroll
-            for (int i = 0; i < TT + K - 1; i++) {
-                int j = t0 - (K - 1) + i;
-                j = j < 0 ? -j : j;
-                xv[i] = j < T ? (float) xr[j] : 0.0f;
-            }
+        for (int e = 0; e < 8; e++) bv[e] = (half_t) 0.0f;
+        if (live && kdd < a.kd) {
+            const int kk = kdd / a.cin, ci0 = kdd - kk * a.cin;
+            const int j = conv_src_row(a.convT, a.K, kk, t, rows);
+            if (j >= 0) bv = *reinterpret_cast<const half8 *>(a.xh + (size_t) (row0 + j) * a.cin + ci0);
         }
+        return bv;
+    };
+    // four kd blocks per trip: their eight operand loads are in flight together
+    int kb = 0;
+    for (; kb + 4 <= nkb; kb += 4) {
+        half8 av[4], bv[4];
         #pragma unroll
-        for (int c = 0; c < CO; c++) {
-            const float * wr = w + ((size_t) min(co0 + c, cout - 1) * cin + ci) * K;     // wave-uniform: scalar loads
-            #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const float wk = wr[k];
-                #pragma unroll
-                for (int j = 0; j < TT; j++) acc[c][j] = fmaf(wk, xv[j + k], acc[c][j]);
-            }
-        }
+        for (int i = 0; i < 4; i++) { av[i] = *reinterpret_cast<const half8 *>(wrow + 16 * (kb + i)); bv[i] = load_b(kb + i); }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[i], acc, 0, 0, 0);
     }
+    for (; kb < nkb; kb++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8 *>(wrow + 16 * kb), load_b(kb), acc, 0, 0, 0);
+    if (!live) return;
+    const size_t orow = a.convT ? (size_t) row * a.nphase + phase : (size_t) row;
     #pragma unroll
-    for (int c = 0; c < CO; c++) {
-        const int co = co0 + c;
-        if (co >= cout) break;
+    for (int g = 0; g < 4; g++) {
+        const int co = co0 + 8 * g + 4 * half;                     // accumulator registers 4 g .. 4 g + 3: channels co .. co + 3 of this lane's row
         #pragma unroll
-        for (int j = 0; j < TT; j++) {
-            const int t = t0 + j;
-            if (t >= T) break;
-            float v = acc[c][j] + bias[co];
-            if (add) v = v + add[(size_t) co * T + t];
-            y[(size_t) co * T + t] = v;
+        for (int e = 0; e < 4; e++) {
+            if (co + e >= a.cout) break;
+            float v = acc[4 * g + e] + a.bias[co + e];
+            const size_t o = orow * a.cout + co + e;
+            if (a.add) v = v + a.add[o];
+            if (a.y) a.y[o] = v;
+            if (a.yh_raw) a.yh_raw[o] = to_half(v);
+            if (a.yh_elu) a.yh_elu[o] = to_half(elu_canon(v));
         }
     }
 }
 
-// transposed conv with K == 2 * stride: output to = t*s + kk takes x[t-1] (tap kk+s) then x[t] (tap kk).
-// Thread = time step t; the block owns CO output channels x KB phases kk, whose weights are wave-uniform.
-template <int CO, int KB>
-__global__ __launch_bounds__(256) void convtr1d_blocked_kernel(const float * __restrict__ w, const float * __restrict__ bias, int cin, int cout,
-                                                              int stride, const half_t * __restrict__ xh, int T_, float * y, const CodecBatch cb, int tmul) {
-    const UttView u = utt_view(cb, T_, tmul, tmul * stride, cin, cout);
-    const int T = u.T;
-    xh += u.in_off; y += u.out_off;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nkb = stride / KB;                                  // phase groups per channel group (stride % KB == 0)
-    const int co0 = (blockIdx.y / nkb) * CO, kk0 = (blockIdx.y % nkb) * KB;
-    if (t >= T) return;
-    const int K = 2 * stride;
-    float acc[CO][KB];
-    #pragma unroll
-    for (int c = 0; c < CO; c++)
-        #pragma unroll
-        for (int q = 0; q < KB; q++) acc[c][q] = 0.0f;
-    for (int ci = 0; ci < cin; ci++) {
-        const half_t * xr = xh + (size_t) ci * T;
-        const float xp = t > 0 ? (float) xr[t - 1] : 0.0f, xc = (float) xr[t];
-        #pragma unroll
-        for (int c = 0; c < CO; c++) {
-            const float * wr = w + ((size_t) ci * cout + min(co0 + c, cout - 1)) * K + kk0;      // wave-uniform
-            #pragma unroll
-            for (int q = 0; q < KB; q++) {
-                if (t > 0) acc[c][q] = fmaf(wr[q + stride], xp, acc[c][q]);
-                acc[c][q] = fmaf(wr[q], xc, acc[c][q]);
-            }
+// C9: one fmaf chain per output in (ci, k) order, bias last (toy models' narrow convolutions; the cross-check route of C9m)
+__global__ __launch_bounds__(256) void conv_tm_chain_kernel(const ConvTmArgs a) {
+    const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const int phase = blockIdx.z;
+    if (idx >= (size_t) a.rows_in * a.cout) return;
+    const int row = (int) (idx / a.cout), co = (int) (idx % a.cout);
+    int row0, rows;
+    utt_of_row(a.cb, a.T_single, a.tm_in, row, row0, rows);
+    const int t = row - row0;
+    float acc = 0.0f;
+    if (a.convT) {
+        const int s = a.nphase, K = 2 * s;
+        for (int ci = 0; ci < a.cin; ci++) {
+            const float * wr = a.w32 + ((size_t) ci * a.cout + co) * K;
+            if (t > 0) acc = fmaf(wr[phase + s], (float) a.xh[(size_t) (row - 1) * a.cin + ci], acc);
+            acc = fmaf(wr[phase], (float) a.xh[(size_t) row * a.cin + ci], acc);
         }
-    }
-    const int Tout = T * stride;
-    #pragma unroll
-    for (int c = 0; c < CO; c++) {
-        const int co = co0 + c;
-        if (co >= cout) break;
-        #pragma unroll
-        for (int q = 0; q < KB; q++) y[(size_t) co * Tout + (size_t) t * stride + kk0 + q] = acc[c][q] + bias[co];
-    }
-}
-
-// T: frames of the (longest) utterance at this stage = cb.Tmax * tmul for a batch
-void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
-                        const float * add, float * y, const CodecBatch & cb, int tmul) {
-    constexpr int TT = 4;
-    const int co_grp = cout >= 4 ? 4 : 1;
-    dim3 grid((T + 256 * TT - 1) / (256 * TT), (cout + co_grp - 1) / co_grp, cb.B), block(256);
-#define LAUNCH_CONV(CO, KK) hipLaunchKernelGGL((conv1d_blocked_kernel<CO, TT, KK>), grid, block, 0, s, w, bias, cout, cin, xh, T, add, y, cb, tmul)
-    if (co_grp == 4) { if (K == 7) LAUNCH_CONV(4, 7); else if (K == 3) LAUNCH_CONV(4, 3); else if (K == 1) LAUNCH_CONV(4, 1); else kernel_fail("bark-hip: unsupported convolution kernel size %d", K); }
-    else             { if (K == 7) LAUNCH_CONV(1, 7); else if (K == 3) LAUNCH_CONV(1, 3); else if (K == 1) LAUNCH_CONV(1, 1); else kernel_fail("bark-hip: unsupported convolution kernel size %d", K); }
-#undef LAUNCH_CONV
-}
-bool conv1d_f32w_supported(int K) { return K == 7 || K == 3 || K == 1; }
-
-void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh, int T, float * y,
-                          const CodecBatch & cb, int tmul) {
-    if (K != 2 * stride) kernel_fail("bark-hip: transposed convolution needs kernel == 2 * stride (got %d, %d)", K, stride);
-    const int KB = stride % 4 == 0 ? 4 : (stride % 2 == 0 ? 2 : 1);
-    const int CO = cout >= 2 ? 2 : 1;
-    dim3 grid((T + 255) / 256, ((cout + CO - 1) / CO) * (stride / KB), cb.B), block(256);
-    if (CO == 2) {
-        if (KB == 4) hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 4>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
-        else if (KB == 2) hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 2>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
-        else hipLaunchKernelGGL((convtr1d_blocked_kernel<2, 1>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
     } else {
-        if (KB == 4) hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 4>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
-        else if (KB == 2) hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 2>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
-        else hipLaunchKernelGGL((convtr1d_blocked_kernel<1, 1>), grid, block, 0, s, w, bias, cin, cout, stride, xh, T, y, cb, tmul);
+        for (int ci = 0; ci < a.cin; ci++) {
+            const float * wr = a.w32 + ((size_t) co * a.cin + ci) * a.K;
+            for (int k = 0; k < a.K; k++) {
+                const int j = conv_src_row(0, a.K, k, t, rows);
+                const float xv = j >= 0 ? (float) a.xh[(size_t) (row0 + j) * a.cin + ci] : 0.0f;
+                acc = fmaf(wr[k], xv, acc);
+            }
+        }
     }
+    float v = acc + a.bias[co];
+    const size_t o = (a.convT ? (size_t) row * a.nphase + phase : (size_t) row) * a.cout + co;
+    if (a.add) v = v + a.add[o];
+    if (a.y) a.y[o] = v;
+    if (a.yh_raw) a.yh_raw[o] = to_half(v);
+    if (a.yh_elu) a.yh_elu[o] = to_half(elu_canon(v));
 }
 
-__global__ void transpose_round_kernel(const float * x, int C, int T_, half_t * xt, const CodecBatch cb) {
-    const UttView u = utt_view(cb, T_, 1, 1, C, C);
-    const int T = u.T;
-    x += u.in_off; xt += u.out_off;                             // [C][T] -> [T][C]: the utterances' rows stay back to back
-    __shared__ float tile[32][33];
-    const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-        const int c = c0 + r, t = t0 + threadIdx.x;
-        tile[r][threadIdx.x] = (c < C && t < T) ? x[(size_t) c * T + t] : 0.0f;
+void launch_conv_tm(hipStream_t s, const ConvTmArgs & a) {
+    if (a.convT && a.K != 2 * a.nphase) kernel_fail("bark-hip: transposed convolution needs kernel == 2 * stride (got %d, %d)", a.K, a.nphase);
+    if (a.W && !(crosscheck_mask() & 1024)) {
+        hipLaunchKernelGGL(conv_tm_mfma_kernel, dim3((a.rows_in + 127) / 128, a.cout32 / 32, a.nphase), dim3(256), 0, s, a);
+        return;
     }
-    __syncthreads();
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
-        const int t = t0 + r, c = c0 + threadIdx.x;
-        if (t < T && c < C) xt[(size_t) t * C + c] = to_half(tile[threadIdx.x][r]);
-    }
-}
-void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt, const CodecBatch & cb) {
-    hipLaunchKernelGGL(transpose_round_kernel, dim3((T + 31) / 32, (C + 31) / 32, cb.B), dim3(32, 8), 0, s, x, C, T, xt, cb);
+    const size_t n = (size_t) a.rows_in * a.cout;
+    hipLaunchKernelGGL(conv_tm_chain_kernel, dim3((unsigned) ((n + 255) / 256), 1, a.nphase), dim3(256), 0, s, a);
 }
 
 // one unit (d) of one layer at one step: the four gates in the four 16-lane groups of the wave, C1 dots, gate non-linearities in
@@ -254,7 +229,7 @@ __global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs 
         const float hn = o_t * (float) tanh((double) cn);
         cs[d] = cn;
         (second ? a.h2 : a.h1)[(row0 + t) * D + d] = to_half(hn);
-        if (second) a.out2[row0 * D + (size_t) d * T + t] = hn;
+        if (second) a.out2[(row0 + t) * D + d] = hn;                // time-major, as every activation of the codec
     }
 }
 void launch_lstm_pair_step(hipStream_t s, const LstmPairArgs & a) {

@@ -52,9 +52,10 @@ struct CodecModel {
     CodecHparams hp;
     int n_q = 0, D = 0;
     const float * codebooks = nullptr;                  // [n_q][n_bins][hidden_dim]
-    // w32: f32 copy of the f16 weights (exact), read through scalar loads by the register-blocked kernels
-    struct Conv { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; int cout = 0, cin = 0, k = 0; };
-    struct ConvT { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; int cin = 0, cout = 0, k = 0, stride = 0; };
+    // wm: kernel image for the matrix-core order C9m, [phases][cout32][kd16] f16 zero padded, kd = k * cin + ci (convT: one image per output
+    // phase over tap * cin + ci), nullptr when cin is not a multiple of 8; w32: f32 copy of the file's kernel (exact) for order C9
+    struct Conv { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; const half_t * wm = nullptr; int cout = 0, cin = 0, k = 0; };
+    struct ConvT { const half_t * w = nullptr; const float * w32 = nullptr; const float * b = nullptr; const half_t * wm = nullptr; int cin = 0, cout = 0, k = 0, stride = 0; };
     struct Lstm { const half_t * w_ih = nullptr, * w_hh = nullptr; const float * b_ih = nullptr, * b_hh = nullptr; };
     Conv init, fin;
     Lstm lstm[2];
@@ -102,7 +103,7 @@ struct bark_context {
     int max_E = 0, max_H = 0, P = 1024;
     // codec scratch (grown on demand)
     float * cbuf[3] = {nullptr, nullptr, nullptr}; size_t cbuf_elems = 0;
-    barkhip::half_t * cbuf_h = nullptr; size_t cbuf_h_elems = 0;
+    barkhip::half_t * cbuf_hh[3] = {nullptr, nullptr, nullptr};
     float * c_gi = nullptr, * c_cell = nullptr, * c_cell2 = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr, * c_hseq2_h = nullptr; size_t c_T = 0;
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
     hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook

@@ -12,8 +12,8 @@ using namespace barkhip::detail;
 
 namespace barkhip {
 
-// codes[b]: [n_q][T[b]] ids of utterance b.  Every activation is the utterances' compact [C][T] arrays back to back (CodecBatch,
-// kernels.h): one launch per operator for the whole batch, the 2 T + 1 strictly sequential LSTM launches of an utterance shared by all.
+// codes[b]: [n_q][T[b]] ids of utterance b.  Every activation is time-major [row][C] with the utterances' rows back to back (CodecBatch,
+// kernels.h): one launch per operator for the whole batch, the T + 1 strictly sequential LSTM launches of an utterance shared by all.
 // tap_stage >= 0 (one utterance only): *tap receives the activation after that stage (0 first conv, 1 LSTM + skip, 2..5 up-blocks).
 std::vector<std::vector<float>> engine_codec_decode_many(bark_context * c, const std::vector<const int32_t *> & codes, int n_q, const std::vector<int> & T,
                                                          int tap_stage, std::vector<float> * tap) {
@@ -34,12 +34,12 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * c, const
     const int Ts = Tpre[(size_t) B];                              // frames of the whole batch
     hipStream_t s = c->stream;
     const int D = cm.D;
-    // largest activation: channels x time at every stage
+    // largest activation: rows x channels at every stage (time-major; the hidden channels of a residual block are half its width)
     size_t need = (size_t) std::max(cm.hp.hidden_dim, D) * Ts;
     { int ch = D; size_t tt = (size_t) Ts; for (auto & b : cm.blocks) { ch = b.up.cout; tt *= b.up.stride; need = std::max(need, (size_t) ch * tt); } }
     if (need > c->cbuf_elems) {
         for (auto & b : c->cbuf) b = dev_alloc<float>(c, need);
-        c->cbuf_h = dev_alloc<half_t>(c, need);
+        for (auto & b : c->cbuf_hh) b = dev_alloc<half_t>(c, need);
         c->cbuf_elems = need;
     }
     if ((size_t) Ts > c->c_T) {
@@ -62,21 +62,32 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * c, const
         HIP_OK(hipStreamSynchronize(s));                        // hdr is a stack object
     }
     CodecBatch cb; cb.T = c->d_codec_T; cb.Tpre = c->d_codec_T + 40; cb.B = B;
+    // time-major buffers: three f32 (A / Bf / R) and three f16 (H0 / H1 / H2)
     float * A = c->cbuf[0], * Bf = c->cbuf[1], * R = c->cbuf[2];
-    half_t * Hh = c->cbuf_h;
+    half_t * H0 = c->cbuf_hh[0], * H1 = c->cbuf_hh[1], * H2 = c->cbuf_hh[2];
 
-    auto conv = [&](const CodecModel::Conv & cv, const float * in, bool elu, int tmul, const float * add, float * out) {
-        launch_act_round(s, in, (size_t) cv.cin * tmul * Ts, elu ? 1 : 0, Hh);
-        launch_conv1d_f32w(s, cv.w32, cv.b, cv.cout, cv.cin, cv.k, Hh, Tmax * tmul, add, out, cb, tmul);
+    // one convolution over time-major rows: xh [rows_in][cin] f16 -> any of y (f32), yh_raw, yh_elu (f16: what the next operators consume)
+    auto conv_args = [&](const half_t * wm, const float * w32, const float * bias, int cin, int cout, int K, int stride, const half_t * xh, int tm_in) {
+        ConvTmArgs a;
+        a.W = wm; a.w32 = w32; a.bias = bias; a.cin = cin; a.cout = cout; a.cout32 = (cout + 31) & ~31; a.K = K;
+        a.convT = stride > 0 ? 1 : 0; a.nphase = stride > 0 ? stride : 1;
+        a.kd = (stride > 0 ? 2 : K) * cin; a.kd16 = (a.kd + 15) & ~15;
+        a.xh = xh; a.rows_in = Ts * tm_in; a.tm_in = tm_in; a.cb = cb;
+        return a;
+    };
+    auto conv = [&](const CodecModel::Conv & cv, const half_t * xh, int tm, const float * add, float * y, half_t * yh_raw, half_t * yh_elu) {
+        ConvTmArgs a = conv_args(cv.wm, cv.w32, cv.b, cv.cin, cv.cout, cv.k, 0, xh, tm);
+        a.add = add; a.y = y; a.yh_raw = yh_raw; a.yh_elu = yh_elu;
+        launch_conv_tm(s, a);
     };
     // RVQ de-embedding, first conv
-    launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, Tmax, A, cb);
-    conv(cm.init, A, false, 1, nullptr, Bf);                    // Bf = x [D][T]
+    launch_rvq_gather(s, cm.codebooks, cm.hp.n_bins, cm.hp.hidden_dim, c->d_codes, n_q, Tmax, Ts, A, cb);
+    launch_act_round(s, A, (size_t) cm.hp.hidden_dim * Ts, 0, H0);
+    conv(cm.init, H0, 1, nullptr, Bf, c->c_xt_h, nullptr);      // Bf = x [row][D]; its f16 image is the LSTM's input
     // 2-layer LSTM + skip (modeling_encodec.py:236-249), both layers as a wave front: launch i = layer 1 at step i + layer 2 at step
     // i - 1 (its input projection formed in the same kernel): T + 1 strictly sequential launches instead of 2 T, for all utterances at
     // once.  64 of them are captured once as a hipGraph whose nodes take their launch index from a device counter, so one graph
     // serves every T (and is re-captured only when the batch size or a buffer changes).
-    launch_transpose_round(s, Bf, D, Tmax, c->c_xt_h, cb);
     {
         LinArgs g;
         g.W = cm.lstm[0].w_ih; g.M = 4 * D; g.K = D; g.N = Ts; g.x_f16 = c->c_xt_h; g.epi = EPI_LOGITS; g.out = c->c_gi; g.ld_out = 4 * D;
@@ -110,37 +121,41 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * c, const
         HIP_OK(hipStreamSynchronize(s));                         // hdr is a stack object
         for (int i0 = 0; i0 <= Tmax; i0 += kBlock) HIP_OK(hipGraphLaunch(slot.exec, s));
     }
-    auto grab = [&](int stage, const float * buf, size_t n) {
+    // parity taps are handed out channel-major [C][T'] (one utterance)
+    auto grab = [&](int stage, const float * buf, int C, size_t rows) {
         if (tap_stage != stage || !tap) return;
-        tap->resize(n);
-        HIP_OK(hipMemcpyAsync(tap->data(), buf, n * 4, hipMemcpyDeviceToHost, s));
+        std::vector<float> tm((size_t) C * rows);
+        HIP_OK(hipMemcpyAsync(tm.data(), buf, tm.size() * 4, hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        tap->resize(tm.size());
+        for (size_t r = 0; r < rows; r++) for (int ch = 0; ch < C; ch++) (*tap)[(size_t) ch * rows + r] = tm[r * (size_t) C + ch];
     };
-    grab(0, Bf, (size_t) D * Ts);
-    // skip connection + the four upsampling blocks + final conv: ~40 launches, replayed from a hipGraph captured per list of frame
+    grab(0, Bf, D, (size_t) Ts);
+    // skip connection + the four upsampling blocks + final conv: ~25 launches, replayed from a hipGraph captured per list of frame
     // counts (the buffers are the context's own, so a graph stays valid until they are re-allocated for a longer input)
     int tmul = 1;
-    float * cur = A, * other = Bf;
+    float * pcm_dev = nullptr;
     auto tail = [&](bool taps) {
-        float * Rb = R;
-        launch_add(s, Rb, Bf, (size_t) D * Ts, A);                  // y + x ; A = x
-        if (taps) grab(1, A, (size_t) D * Ts);
-        cur = A; other = Bf; tmul = 1;
+        launch_add(s, R, Bf, (size_t) D * Ts, A);                    // y + x
+        if (taps) grab(1, A, D, (size_t) Ts);
+        launch_act_round(s, A, (size_t) D * Ts, 1, H0);             // H0 = f16(ELU(x))
+        tmul = 1;
         for (int b = 0; b < 4; b++) {
             const CodecModel::Block & bl = cm.blocks[b];
-            launch_act_round(s, cur, (size_t) bl.up.cin * tmul * Ts, 1, Hh);
-            launch_convtr1d_f32w(s, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, Hh, Tmax * tmul, other, cb, tmul);
+            // upsampling of f16(ELU(x)) (H0): the next operators consume only the f16 images of its result - as it is (shortcut input, H1) and
+            // after the ELU (conv1 input, H2)
+            ConvTmArgs u = conv_args(bl.up.wm, bl.up.w32, bl.up.b, bl.up.cin, bl.up.cout, bl.up.k, bl.up.stride, H0, tmul);
+            u.yh_raw = H1; u.yh_elu = H2;
+            launch_conv_tm(s, u);
             tmul *= bl.up.stride;
-            std::swap(cur, other);                                  // cur = upsampled x
             // residual block: shortcut(x) + conv2(elu(conv1(elu(x))))   (modeling_encodec.py:252-282)
-            conv(bl.c1, cur, true, tmul, nullptr, Rb);
-            conv(bl.c2, Rb, true, tmul, nullptr, other);            // other = r
-            conv(bl.sc, cur, false, tmul, other, Rb);               // Rb = shortcut(x) + r
-            std::swap(cur, Rb);
-            // keep three distinct buffers: cur (result), other, Rb (old x)
-            if (taps) grab(2 + b, cur, (size_t) bl.up.cout * tmul * Ts);
+            conv(bl.c1, H2, tmul, nullptr, nullptr, nullptr, H0);           // H0 = f16(ELU(conv1(...)))
+            conv(bl.c2, H0, tmul, nullptr, R, nullptr, nullptr);            // R = r (f32: it is added, not multiplied)
+            conv(bl.sc, H1, tmul, R, taps ? A : nullptr, nullptr, H0);      // shortcut(x) + r; H0 = f16(ELU(..)): the next block's / the last conv's input
+            if (taps) grab(2 + b, A, bl.up.cout, (size_t) Ts * tmul);
         }
-        conv(cm.fin, cur, true, tmul, nullptr, other);
+        conv(cm.fin, H0, tmul, nullptr, Bf, nullptr, nullptr);
+        pcm_dev = Bf;
     };
     if (c->use_graph && tap_stage < 0) {
         auto & cg = c->codec_graph;
@@ -153,16 +168,16 @@ std::vector<std::vector<float>> engine_codec_decode_many(bark_context * c, const
             HIP_OK(hipStreamEndCapture(s, &graph));
             HIP_OK(hipGraphInstantiate(&cg.exec, graph, nullptr, nullptr, 0));
             (void) hipGraphDestroy(graph);
-            cg.T = T; cg.buf = A; cg.out = other; cg.tmul = tmul;
+            cg.T = T; cg.buf = A; cg.out = pcm_dev; cg.tmul = tmul;
         }
         HIP_OK(hipGraphLaunch(cg.exec, s));
         c->stats.graph_replays++;
-        other = cg.out; tmul = cg.tmul;
+        pcm_dev = cg.out; tmul = cg.tmul;
     } else {
         tail(true);
     }
     std::vector<float> all((size_t) Ts * tmul);                  // the final conv has one output channel: utterance b = samples [tmul Tpre[b], tmul Tpre[b + 1])
-    HIP_OK(hipMemcpyAsync(all.data(), other, all.size() * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(all.data(), pcm_dev, all.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     std::vector<std::vector<float>> pcm((size_t) B);
     for (int b = 0; b < B; b++) pcm[(size_t) b].assign(all.begin() + (size_t) tmul * Tpre[(size_t) b], all.begin() + (size_t) tmul * Tpre[(size_t) b + 1]);

@@ -293,7 +293,6 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         auto conv = [&](const std::string & p, CodecModel::Conv & cv) {
             const TensorRef & w = codec_weight(p + ".weight", 0, 0);
             if (w.n_dims != 3 || w.ne[3] != 1 || w.ne[0] > 64 || w.ne[1] > 4096 || w.ne[2] > 4096) throw std::runtime_error("codec conv weight '" + p + "' has an unexpected shape");
-            if (!conv1d_f32w_supported((int) w.ne[0])) throw std::runtime_error("codec conv '" + p + "': kernel sizes 1, 3 and 7 are implemented (EnCodec's)");
             cv.k = (int) w.ne[0]; cv.cin = (int) w.ne[1]; cv.cout = (int) w.ne[2];
             place(w, (const void **) &cv.w);
             const TensorRef & b = need(T, p + ".bias", 0, 0, 0);
@@ -417,6 +416,44 @@ bark_context * engine_load(const char * path, const bark_context_params & params
             cm.blocks[i].sc.w32 = cw("decoder.model." + std::to_string(idx + 1) + ".shortcut.conv.conv");
         }
         cm.fin.w32 = cw("decoder.model.15.conv.conv");
+        // kernel images for the f16 matrix cores (order C9m): rows = output channels padded to 32, columns kd padded to 16 with zeros
+        auto upload_h = [&](const std::vector<uint16_t> & h) -> const half_t * {
+            void * d = nullptr;
+            HIP_OK(hipMalloc(&d, h.size() * 2));
+            ctx->weights->extra.push_back(d);
+            HIP_OK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+            return (const half_t *) d;
+        };
+        auto conv_image = [&](const std::string & p, CodecModel::Conv & cv) {
+            if (cv.cin & 7) return;
+            const TensorRef & t = codec_weight(p + ".weight", 0, 0);                 // [cout][cin][k] f16
+            const int kd = cv.k * cv.cin, kd16 = (kd + 15) & ~15, c32 = (cv.cout + 31) & ~31;
+            std::vector<uint16_t> img((size_t) c32 * kd16, 0);
+            for (int co = 0; co < cv.cout; co++) for (int ci = 0; ci < cv.cin; ci++) for (int k = 0; k < cv.k; k++)
+                memcpy(&img[(size_t) co * kd16 + (size_t) k * cv.cin + ci], t.data + 2 * (((size_t) co * cv.cin + ci) * cv.k + k), 2);
+            cv.wm = upload_h(img);
+        };
+        auto convt_image = [&](const std::string & p, CodecModel::ConvT & cv) {
+            if (cv.cin & 7) return;
+            const TensorRef & t = codec_weight(p + ".weight", 0, 0);                 // [cin][cout][k] f16, k = 2 stride
+            const int s = cv.stride, kd = 2 * cv.cin, kd16 = (kd + 15) & ~15, c32 = (cv.cout + 31) & ~31;
+            std::vector<uint16_t> img((size_t) s * c32 * kd16, 0);
+            for (int r = 0; r < s; r++) for (int co = 0; co < cv.cout; co++) for (int ci = 0; ci < cv.cin; ci++) {
+                const uint8_t * w = t.data + 2 * (((size_t) ci * cv.cout + co) * cv.k);
+                memcpy(&img[((size_t) r * c32 + co) * kd16 + ci], w + 2 * (r + s), 2);              // tap 0: the previous frame, kernel element r + s
+                memcpy(&img[((size_t) r * c32 + co) * kd16 + cv.cin + ci], w + 2 * r, 2);           // tap 1: this frame, element r
+            }
+            cv.wm = upload_h(img);
+        };
+        conv_image("decoder.model.0.conv.conv", cm.init);
+        for (int i = 0; i < 4; i++) {
+            const int idx = 3 + 3 * i;
+            convt_image("decoder.model." + std::to_string(idx) + ".convtr.convtr", cm.blocks[i].up);
+            conv_image("decoder.model." + std::to_string(idx + 1) + ".block.1.conv.conv", cm.blocks[i].c1);
+            conv_image("decoder.model." + std::to_string(idx + 1) + ".block.3.conv.conv", cm.blocks[i].c2);
+            conv_image("decoder.model." + std::to_string(idx + 1) + ".shortcut.conv.conv", cm.blocks[i].sc);
+        }
+        conv_image("decoder.model.15.conv.conv", cm.fin);
     }
     {
         const size_t per = (size_t) cm.hp.n_bins * cm.hp.hidden_dim;

@@ -217,6 +217,7 @@ void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows,
 // 128  lock-step batches: the LayerNorm of the slot rows as a launch of its own in front of the QKV / FC / LM-head products instead of inside them
 // 256  fine model: products as C1 chains on the f32 matrix cores (the canonical order of rounds 1 - 3) instead of C1m on the f16 matrix cores;
 //      the oracle follows with set_fine_mfma(False)
+// 1024 codec: every convolution as one fmaf chain in (ci, k) order (C9) instead of the f16 matrix cores' order (C9m); oracle: set_codec_mfma(False)
 // 512  fine model: the attention of whole windows through attn_rows_kernel (scores in an LDS tile) instead of attn_window_kernel (scores in registers)
 int crosscheck_mask();
 int xcd_panel_width(int n_tiles, int ncol);            // column-panel width of the XCD-aware tile order (device_utils.h: panel_tile)
@@ -228,26 +229,29 @@ void launch_linear_q(hipStream_t s, const LinArgs & a);
 void launch_linear_w32(hipStream_t s, const LinArgs & a);
 
 // ---- EnCodec decoder (codec_kernels.hip) ---------------------------------------------------------
-// Activations are channel-major [C][T] f32; every conv / LSTM matmul consumes them rounded to f16
-// (ggml im2col / mul_mat) and accumulates in f32 as ONE fmaf chain in
-// (ci, k) order, bias added last - the order the oracle uses.
-// Several utterances in one launch (grid.z = utterance): utterance z has T[z] frames and every activation is the utterances' compact
-// [C][tmul T[z]] arrays back to back (utterance z starts at element C tmul Tpre[z]; Tpre = exclusive prefix sums of T, tmul = the stage's
-// upsampling factor).  T == nullptr: one utterance whose length is the launch's T argument.
+// Activations are time-major [row][C] f32 (row = frame at the stage's rate); every conv / LSTM matmul consumes them rounded to f16
+// (ggml im2col / mul_mat) and accumulates in f32: convolutions in the order of the f16 matrix cores over
+// kd = k * cin + ci (C9m; C9 - one fmaf chain in (ci, k) order - where the input channel count is not a multiple of 8), bias added last.
+// Several utterances in one launch: utterance z has T[z] frames and owns rows [tm Tpre[z], tm Tpre[z + 1]) of every activation at a stage
+// with upsampling factor tm (Tpre = exclusive prefix sums of T).  T == nullptr: one utterance whose length is the launch's T argument.
 struct CodecBatch { const int * T = nullptr; const int * Tpre = nullptr; int B = 1; };
-void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, float * z, const CodecBatch & cb);
+void launch_rvq_gather(hipStream_t s, const float * codebooks, int n_bins, int Hd, const int32_t * codes, int n_q, int T, int rows_total, float * z, const CodecBatch & cb);
 // out_h = f16(elu ? ELU(x) : x), n elements
 void launch_act_round(hipStream_t s, const float * x, size_t n, int elu, half_t * out_h);
-// causal stride-1 conv with reflect padding on the left (k-1): y[co][t] = b[co] + chain(w[co][ci][k] * xh[ci][t+k-(K-1)]) (+ add[co][t]);
-// register-blocked, f32 copies of the (f16-valued) weights, K in {1, 3, 7}.  T: frames of the longest utterance at this stage
-void launch_conv1d_f32w(hipStream_t s, const float * w, const float * bias, int cout, int cin, int K, const half_t * xh, int T,
-                        const float * add, float * y, const CodecBatch & cb, int tmul);
-bool conv1d_f32w_supported(int K);
-// causal transposed conv, stride s, kernel 2 s, output trimmed to T*s: y[co][to] = b[co] + chain over (ci, t) of w[ci][co][to - t*s] * xh[ci][t]
-void launch_convtr1d_f32w(hipStream_t s, const float * w, const float * bias, int cin, int cout, int K, int stride, const half_t * xh,
-                          int T, float * y, const CodecBatch & cb, int tmul);
-// xt[t][c] = f16(x[c][t])
-void launch_transpose_round(hipStream_t s, const float * x, int C, int T, half_t * xt, const CodecBatch & cb);
+// One convolution (convT = 0: causal stride-1 conv with reflect padding on the left, K taps) or transposed convolution (convT = 1: causal,
+// stride nphase, kernel 2 nphase, output trimmed to rows_in * nphase) over time-major rows:
+//   y[orow][co] = bias[co] + dot(kernel image of co, operand rows) (+ add[orow][co]);   orow = row (conv) or row * nphase + phase (convT)
+// W: kernel image for C9m [nphase][cout32][kd16] f16, zero padded (nullptr: order C9 on w32, the f32 copy of the file's kernel -
+// conv [cout][cin][K], convT [cin][cout][K]); outputs: any of y (f32), yh_raw (f16), yh_elu (f16 of ELU) - what the next operators consume
+struct ConvTmArgs {
+    const half_t * W = nullptr; const float * w32 = nullptr; const float * bias = nullptr;
+    int cin = 0, cout = 0, cout32 = 0, K = 0, kd = 0, kd16 = 0, nphase = 1, convT = 0;
+    const half_t * xh = nullptr; const float * add = nullptr;
+    float * y = nullptr; half_t * yh_raw = nullptr, * yh_elu = nullptr;
+    int rows_in = 0, tm_in = 1, T_single = 0;
+    CodecBatch cb;
+};
+void launch_conv_tm(hipStream_t s, const ConvTmArgs & a);
 // Both LSTM layers as a wave front (PyTorch gate order i,f,g,o): launch i runs layer 1 at step i and layer 2 at step i - 1 (whose input
 // projection W_ih2 h1[i-1] is formed in the same kernel, C1 order - the bits of the row-batched product), so a sequence of T frames takes
 // T + 1 dependent launches instead of 2 T - for every utterance of the batch at once.

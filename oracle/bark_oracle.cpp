@@ -340,8 +340,10 @@ static bool load_gpt(Reader & r, Gpt & m, bool need_kv) {
 }
 
 // EnCodec decoder weights, all widened to f32 at load (exact)
-struct Conv { std::vector<float> w, b; int cout = 0, cin = 0, k = 0; };          // w[cout][cin][k]
-struct ConvT { std::vector<float> w, b; int cin = 0, cout = 0, k = 0, stride = 0; }; // w[cin][cout][k]
+// wm: the f16 image of the kernel for the matrix-core order C9m, built on first use: conv [cout][k * cin + ci], transposed conv one matrix
+// per output phase r, [r][cout][tap * cin + ci] (tap 0 = the previous frame, kernel element r + stride; tap 1 = this frame, element r)
+struct Conv { std::vector<float> w, b; int cout = 0, cin = 0, k = 0; mutable std::vector<CanonW> wm; mutable std::vector<uint16_t> wm_bits; };          // w[cout][cin][k]
+struct ConvT { std::vector<float> w, b; int cin = 0, cout = 0, k = 0, stride = 0; mutable std::vector<CanonW> wm; mutable std::vector<uint16_t> wm_bits; }; // w[cin][cout][k]
 struct Lstm { CanonW w_ih, w_hh; std::vector<float> b_ih, b_hh; };
 struct Codec {
     int in_channels = 0, hidden_dim = 0, n_filters = 0, kernel = 0, res_kernel = 0, n_bins = 0, bandwidth = 0, sr = 0, ftype = 0;
@@ -444,6 +446,9 @@ struct Numerics {
     // instruction the engine runs them on - restated in mfma_f16_emu.h (C1m).  0: the C1 chains as for the other models
     // (the CPU-friendly order: what bench.py's cpu_baseline leg times, and what the fixtures of rounds 1 - 3 were made with).
     int fine_mfma = 1;
+    // The codec's convolutions (every one whose input channel count is a multiple of 8) in the same matrix-core order, over the axis
+    // kd = k * cin + ci (transposed conv: tap * cin + ci per output phase) - order C9m; 0: one fmaf chain in (ci, k) order (C9).
+    int codec_mfma = 1;
 };
 
 struct Oracle {
@@ -1282,11 +1287,33 @@ static std::vector<float> reflect_pad(const std::vector<float> & x, int C, int T
     return out;
 }
 
+// C9m: the convolution as a product on the f16 matrix cores (gemm_mfma), y[t][co] = C1m-dot(Wm[co], col_t) over kd = k * cin + ci
+static bool conv_uses_mfma(const Oracle & o, int cin) { return o.num.codec_mfma && o.num.act_round_f16 && o.num.dot_order == 0 && (cin & 7) == 0; }
+static std::vector<float> conv1d_mfma(const Conv & cv, const std::vector<float> & xp, int Tp, int T, int nth) {
+    const int kd = cv.k * cv.cin;
+    if (cv.wm.empty()) {
+        cv.wm_bits.resize((size_t) cv.cout * kd);
+        for (int co = 0; co < cv.cout; co++) for (int ci = 0; ci < cv.cin; ci++) for (int k = 0; k < cv.k; k++)
+            cv.wm_bits[(size_t) co * kd + (size_t) k * cv.cin + ci] = f2h(cv.w[((size_t) co * cv.cin + ci) * cv.k + k]);
+        cv.wm.resize(1);
+        CanonW & W = cv.wm[0]; W.M = cv.cout; W.K = kd; W.f16 = true; W.mfma = true; W.raw = (const uint8_t *) cv.wm_bits.data();
+    }
+    std::vector<float> X((size_t) T * kd), Y((size_t) T * cv.cout);
+    #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1)
+    for (int t = 0; t < T; t++)
+        for (int k = 0; k < cv.k; k++) for (int ci = 0; ci < cv.cin; ci++) X[(size_t) t * kd + (size_t) k * cv.cin + ci] = xp[(size_t) ci * Tp + t + k];
+    gemm_mfma(cv.wm[0], X.data(), kd, Y.data(), cv.cout, cv.cout, T, kd, nth);
+    std::vector<float> y((size_t) cv.cout * T);
+    for (int co = 0; co < cv.cout; co++) for (int t = 0; t < T; t++) y[(size_t) co * T + t] = Y[(size_t) t * cv.cout + co] + cv.b[co];
+    return y;
+}
+
 // causal stride-1 conv: out[co][t] = b[co] + sum_{ci,k} w[co][ci][k] * xpad[ci][t + k]   (modeling_encodec.py:159-176)
 static std::vector<float> conv1d(const Oracle & o, const Conv & cv, const std::vector<float> & x, int T, int nth) {
     int Tp = 0;
     std::vector<float> xp = reflect_pad(x, cv.cin, T, cv.k - 1, 0, Tp);
     if (o.num.act_round_f16) for (float & v : xp) v = round_h(v);       // im2col to f16
+    if (conv_uses_mfma(o, cv.cin)) return conv1d_mfma(cv, xp, Tp, T, nth);
     std::vector<float> y((size_t) cv.cout * T);
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1)
     for (int co = 0; co < cv.cout; co++) {
@@ -1310,6 +1337,31 @@ static std::vector<float> convtr1d(const Oracle & o, const ConvT & cv, const std
     Tout = T * s;                                  // (T-1)*s + K - (K - s)
     std::vector<float> xr = x;
     if (o.num.act_round_f16) for (float & v : xr) v = round_h(v);
+    if (conv_uses_mfma(o, cv.cin) && K == 2 * s) {
+        // C9m: output phase r (to = q s + r) is one product over kd = tap * cin + ci: tap 0 = frame q - 1 with kernel element r + s, tap 1 = frame q
+        // with element r (the frame in front of the first one is zero)
+        const int kd = 2 * cv.cin;
+        if (cv.wm.empty()) {
+            cv.wm_bits.resize((size_t) s * cv.cout * kd);
+            for (int r = 0; r < s; r++) for (int co = 0; co < cv.cout; co++) for (int ci = 0; ci < cv.cin; ci++) {
+                const float * w = cv.w.data() + ((size_t) ci * cv.cout + co) * K;
+                cv.wm_bits[((size_t) r * cv.cout + co) * kd + ci] = f2h(w[r + s]);
+                cv.wm_bits[((size_t) r * cv.cout + co) * kd + cv.cin + ci] = f2h(w[r]);
+            }
+            cv.wm.resize((size_t) s);
+            for (int r = 0; r < s; r++) { CanonW & W = cv.wm[(size_t) r]; W.M = cv.cout; W.K = kd; W.f16 = true; W.mfma = true; W.raw = (const uint8_t *) (cv.wm_bits.data() + (size_t) r * cv.cout * kd); }
+        }
+        std::vector<float> X((size_t) T * kd), Y((size_t) T * cv.cout), ym((size_t) cv.cout * Tout);
+        for (int q = 0; q < T; q++) for (int ci = 0; ci < cv.cin; ci++) {
+            X[(size_t) q * kd + ci] = q > 0 ? xr[(size_t) ci * T + q - 1] : 0.0f;
+            X[(size_t) q * kd + cv.cin + ci] = xr[(size_t) ci * T + q];
+        }
+        for (int r = 0; r < s; r++) {
+            gemm_mfma(cv.wm[(size_t) r], X.data(), kd, Y.data(), cv.cout, cv.cout, T, kd, nth);
+            for (int co = 0; co < cv.cout; co++) for (int q = 0; q < T; q++) ym[(size_t) co * Tout + (size_t) q * s + r] = Y[(size_t) q * cv.cout + co] + cv.b[co];
+        }
+        return ym;
+    }
     std::vector<float> y((size_t) cv.cout * Tout);
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1)
     for (int co = 0; co < cv.cout; co++) {
@@ -1432,6 +1484,7 @@ void * orc_open(const char * path) { return oracle_open(path); }
 void   orc_close(void * h) { delete (Oracle *) h; }
 void   orc_set_numerics(void * h, int act_round_f16, int gelu_mode) { auto * o = (Oracle *) h; o->num.act_round_f16 = act_round_f16; o->num.gelu_mode = gelu_mode; }
 void   orc_set_dot_order(void * h, int dot_order) { ((Oracle *) h)->num.dot_order = dot_order; }      // study modes, see Numerics
+void   orc_set_codec_mfma(void * h, int on) { ((Oracle *) h)->num.codec_mfma = on; }                      // 0: the codec's convolutions as (ci, k) fmaf chains (Numerics::codec_mfma)
 void   orc_set_fine_mfma(void * h, int on) { ((Oracle *) h)->num.fine_mfma = on; }                        // 0: C1 chains for the fine model too (Numerics::fine_mfma)
 // y[n][m] = C1m-dot(w[m], x[n]) through the 8-lane restatement (tests/test_mfma_f16_emu.py): w [M][K] f16 bits, x [N][K] floats (f16-representable)
 void   orc_test_mfma_gemm(const uint16_t * w, const float * x, int M, int N, int K, float * y) {

@@ -49,6 +49,7 @@ class Oracle:
         lib.orc_set_numerics.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.orc_set_dot_order.argtypes = [C.c_void_p, C.c_int]
         lib.orc_set_fine_mfma.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_set_codec_mfma.argtypes = [C.c_void_p, C.c_int]
         lib.orc_seed.argtypes = [C.c_void_p, C.c_uint32]
         lib.orc_gelu_table.restype = C.POINTER(C.c_uint16)
         lib.orc_gelu_table.argtypes = [C.c_void_p]
@@ -90,6 +91,10 @@ class Oracle:
     def set_fine_mfma(self, on: bool = True):
         """The fine model's weight products in the f16 matrix cores' order (default, what the engine computes) or as C1 chains (Numerics::fine_mfma)."""
         self.lib.orc_set_fine_mfma(self.h, int(on))
+
+    def set_codec_mfma(self, on: bool = True):
+        """The codec's convolutions in the f16 matrix cores' order over kd = k * cin + ci (default, C9m) or as (ci, k) fmaf chains (C9)."""
+        self.lib.orc_set_codec_mfma(self.h, int(on))
 
     def seed(self, s: int):
         self.lib.orc_seed(self.h, s)
