@@ -164,3 +164,24 @@ def test_request_collector_admits_late_requests_with_their_own_parameters(toy_mo
     finally:
         b.free()
         c.free()
+
+
+def test_lock_step_time_line_hook(toy_model):
+    """bark_hip_profile_lock_step: one entry per launch site of a lock step in launch order (5 per layer + LM head + sampler), closed by the
+    graph-replayed step; the eager sites add up to more than the replayed step (event records sit between the launches)."""
+    pkg = _pkg()
+    ctx = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=0.0), 0)
+    try:
+        ctx.reserve_batch(16)
+        n_layer = ctx.hparams(1)["n_layer"]
+        for which in (0, 1):
+            tl = ctx.profile_lock_step(which, 9, 300, 5)
+            sites = [e["site"] for e in tl]
+            assert sites[:5] == ["ln1+qkv", "attention", "proj", "ln2+fc+gelu", "mlp_proj"] and len(tl) == 5 * n_layer + 3
+            assert sites[-3:] == ["lnf+lm_head", "sample+embed", "step (graph replay)"]
+            assert all(e["us"] > 0 for e in tl) and tl[-1]["us"] < sum(e["us"] for e in tl[:-1])
+        # the hook leaves the context usable
+        res = ctx.generate_batch(["hello world", "the water is cold"], params=[ctx.request_params(n_steps_text_encoder=12)] * 2)
+        assert all(r is not None and len(r["pcm"]) > 0 for r in res)
+    finally:
+        ctx.free()
