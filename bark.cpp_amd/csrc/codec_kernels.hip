@@ -181,43 +181,55 @@ void launch_conv_tm(hipStream_t s, const ConvTmArgs & a) {
     hipLaunchKernelGGL(conv_tm_chain_kernel, dim3((unsigned) ((n + 255) / 256), 1, a.nphase), dim3(256), 0, s, a);
 }
 
-// one unit (d) of one layer at one step: the four gates in the four 16-lane groups of the wave, C1 dots, gate non-linearities in
-// double precision rounded once (C9), state update by lane 0
-__device__ __forceinline__ float lstm_dot(const half_t * wrow, const half_t * hrow, int nblk) {
+// one unit (d) of one layer at one step: the four gates in the four 16-lane groups of the wave, C1 dots (lane c of a group = chain c: its
+// 8-element chunk of every 128-block, ascending; tree over the 16 lanes), gate non-linearities in double precision rounded once (C9), state
+// update by lane 0.  Every operand chunk of the step's dots is requested before the first multiply-add (NBLK = D / 128 is a template
+// parameter: with the run-time loop each 128-block was a dependent round trip to L2, eight of them for a unit of the second layer).
+template <int NBLK>
+__device__ __forceinline__ void lstm_load(half8 (&v)[NBLK], const half_t * row) {
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++) v[b] = *reinterpret_cast<const half8 *>(row + (b << 7));
+}
+template <int NBLK>
+__device__ __forceinline__ float lstm_dot(const half8 (&w)[NBLK], const half8 (&h)[NBLK]) {
     float acc = 0.0f;
-    for (int b = 0; b < nblk; b++) {
-        const half8 wv = *reinterpret_cast<const half8 *>(wrow + (b << 7));
-        const half8 hv = *reinterpret_cast<const half8 *>(hrow + (b << 7));
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++)
         #pragma unroll
-        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[e], (float) hv[e], acc);
-    }
+        for (int e = 0; e < 8; e++) acc = fmaf((float) w[b][e], (float) h[b][e], acc);
     acc = acc + __shfl_xor(acc, 1, 64); acc = acc + __shfl_xor(acc, 2, 64);
     acc = acc + __shfl_xor(acc, 4, 64); acc = acc + __shfl_xor(acc, 8, 64);
     return acc;
 }
+template <int NBLK>
 __global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int D = a.D, nblk = D >> 7, nb1 = (D + 3) >> 2;
+    constexpr int D = NBLK * 128, nb1 = D / 4;
     const int i = a.t_base ? a.t_base[0] + a.t : a.t;              // launch index: layer 1 at step i, layer 2 at step i - 1
-    // utterance blockIdx.z of a batch: T frames, its rows of gi1 / h1 / h2 start at row0, its [D][T] output at D row0, its cells at D z
+    // utterance blockIdx.z of a batch: T frames, its rows of gi1 / h1 / h2 / out2 start at row0, its cells at D z
     const int z = blockIdx.z;
     const int T = a.cb.T ? a.cb.T[z] : (a.t_base ? a.t_base[1] : a.T);
     const size_t row0 = a.cb.T ? (size_t) a.cb.Tpre[z] : 0;
     const bool second = (int) blockIdx.x >= nb1;
     const int d = ((int) blockIdx.x - (second ? nb1 : 0)) * 4 + wave;
     const int t = second ? i - 1 : i;
-    if (d >= D || t < 0 || t >= T) return;
+    if (t < 0 || t >= T) return;
     const size_t row = (size_t) (g * D + d);
     const half_t * h1 = a.h1 + row0 * D, * h2 = a.h2 + row0 * D;
     float gi, gh = 0.0f, bi, bh;
     if (!second) {
+        half8 w[NBLK], h[NBLK];
+        if (t) { lstm_load<NBLK>(w, a.w_hh1 + row * D + (c << 3)); lstm_load<NBLK>(h, h1 + (size_t) (t - 1) * D + (c << 3)); }
         gi = a.gi1[(row0 + t) * 4 * D + row]; bi = a.b_ih1[row]; bh = a.b_hh1[row];
-        if (t) gh = lstm_dot(a.w_hh1 + row * D + (c << 3), h1 + (size_t) (t - 1) * D + (c << 3), nblk);
+        if (t) gh = lstm_dot<NBLK>(w, h);
     } else {
+        half8 wi[NBLK], hi[NBLK], wh[NBLK], hh[NBLK];
+        lstm_load<NBLK>(wi, a.w_ih2 + row * D + (c << 3)); lstm_load<NBLK>(hi, h1 + (size_t) t * D + (c << 3));
+        if (t) { lstm_load<NBLK>(wh, a.w_hh2 + row * D + (c << 3)); lstm_load<NBLK>(hh, h2 + (size_t) (t - 1) * D + (c << 3)); }
         bi = a.b_ih2[row]; bh = a.b_hh2[row];
-        gi = lstm_dot(a.w_ih2 + row * D + (c << 3), h1 + (size_t) t * D + (c << 3), nblk);          // W_ih2 . f16(h1_t)
-        if (t) gh = lstm_dot(a.w_hh2 + row * D + (c << 3), h2 + (size_t) (t - 1) * D + (c << 3), nblk);
+        gi = lstm_dot<NBLK>(wi, hi);                                // W_ih2 . f16(h1_t)
+        if (t) gh = lstm_dot<NBLK>(wh, hh);
     }
     const float pre = (gi + bi) + (gh + bh);                   // (gi + b_ih) + (gh + b_hh)
     const float act = g == 2 ? (float) tanh((double) pre) : 1.0f / (1.0f + (float) exp((double) (-pre)));
@@ -233,7 +245,14 @@ __global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs 
     }
 }
 void launch_lstm_pair_step(hipStream_t s, const LstmPairArgs & a) {
-    hipLaunchKernelGGL(lstm_pair_step_kernel, dim3(2 * ((a.D + 3) / 4), 1, a.cb.B), dim3(256), 0, s, a);
+    const dim3 grid(2 * (a.D / 4), 1, a.cb.B), block(256);
+    switch (a.D >> 7) {
+        case 1: hipLaunchKernelGGL((lstm_pair_step_kernel<1>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((lstm_pair_step_kernel<2>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((lstm_pair_step_kernel<4>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((lstm_pair_step_kernel<8>), grid, block, 0, s, a); break;
+        default: kernel_fail("bark-hip: the codec's LSTM width must be 128, 256, 512 or 1024 (got %d)", a.D);
+    }
 }
 
 __global__ void add_int_kernel(int * p, int v) { *p += v; }      // p[0]: step base of the replayed LSTM block

@@ -644,7 +644,6 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         const StageCfg s = stage_cfg(c, 1);
         if (p.n_coarse_codebooks != 2 || p.codebook_size != 1024 || p.sliding_window_size <= 0 || p.max_coarse_history < 0)
             throw std::runtime_error("coarse: unsupported parameters");
-        if (p.sliding_window_size & 1) throw std::runtime_error("coarse: lock-step batches need an even sliding_window_size (the slots share the codebook parity of a step)");
         if (s.lm_row0 + 2 * s.lm_rows > m.hp.n_out_vocab) throw std::runtime_error("coarse: vocabulary too small");
         const float stc_ratio = p.coarse_rate_hz / p.semantic_rate_hz * p.n_coarse_codebooks;
         const int max_semantic_history = (int) floorf(p.max_coarse_history / stc_ratio);
@@ -660,7 +659,10 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         std::vector<int> slot_utt;
         while (!queue.empty() || !slot_utt.empty()) {
             bool params_dirty = false;
-            while (!queue.empty() && (int) slot_utt.size() < S) {
+            // the slots of a lock step share the codebook parity of their step (slot 0's step selects the LM-head rows of everyone): with an odd
+            // sliding window the live utterances' step counts are odd in every second window, and a newcomer (step 0) has to wait for an even one
+            const bool parity_ok = slot_utt.empty() || (us[(size_t) slot_utt[0]].step_idx & 1) == 0;
+            while (parity_ok && !queue.empty() && (int) slot_utt.size() < S) {
                 const int slot = (int) slot_utt.size();
                 slot_utt.push_back(queue.front()); queue.pop_front();
                 Utt & u = us[(size_t) slot_utt.back()];

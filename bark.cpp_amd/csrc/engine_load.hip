@@ -313,7 +313,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         conv("decoder.model.0.conv.conv", cm.init);
         if (cm.init.cin != cm.hp.hidden_dim) throw std::runtime_error("codec: the first conv does not take hidden_dim channels");
         cm.D = cm.init.cout;
-        if (cm.D % 128 != 0 || cm.D > 1024) throw std::runtime_error("codec LSTM width must be a multiple of 128 and <= 1024");
+        if (cm.D != 128 && cm.D != 256 && cm.D != 512 && cm.D != 1024) throw std::runtime_error("codec LSTM width must be 128, 256, 512 or 1024");
         for (int l = 0; l < 2; l++) {
             const std::string s = std::to_string(l);
             place(codec_weight("decoder.model.1.lstm.weight_ih_l" + s, cm.D, 4 * cm.D), (const void **) &cm.lstm[l].w_ih);
