@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs 
     if (t < 0 || t >= T) return;
     const size_t row = (size_t) (g * D + d);
     const half_t * h1 = a.h1 + row0 * D, * h2 = a.h2 + row0 * D;
+    float * cs = (second ? a.c2 : a.c1) + (size_t) z * D;
+    const float cprev = t ? cs[d] : 0.0f;                          // requested with the operands, not behind the gates
     float gi, gh = 0.0f, bi, bh;
     if (!second) {
         half8 w[NBLK], h[NBLK];
@@ -235,8 +237,6 @@ __global__ __launch_bounds__(256) void lstm_pair_step_kernel(const LstmPairArgs 
     const float act = g == 2 ? (float) tanh((double) pre) : 1.0f / (1.0f + (float) exp((double) (-pre)));
     const float i_t = __shfl(act, 0, 64), f_t = __shfl(act, 16, 64), g_t = __shfl(act, 32, 64), o_t = __shfl(act, 48, 64);
     if (lane == 0) {
-        float * cs = (second ? a.c2 : a.c1) + (size_t) z * D;
-        const float cprev = t ? cs[d] : 0.0f;
         const float cn = f_t * cprev + i_t * g_t;
         const float hn = o_t * (float) tanh((double) cn);
         cs[d] = cn;
