@@ -30,7 +30,7 @@ stats fine_1_window python $R/tools/profile_fine.py
 FINE_WINDOWS=8 stats fine_8_windows python $R/tools/profile_fine.py
 stats lock_step python $R/tools/lock_step_timeline.py small 640
 for C in ${PMC_COUNTERS:-FETCH_SIZE WRITE_SIZE}; do   # PMC_COUNTERS="" skips the passes
-    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/prof_pmc_$C -- python $R/tools/profile_decode.py > $R/gpurun_out/prof_pmc_$C.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $R/gpurun_out/prof_pmc_$C -- python $R/tools/profile_decode.py f16 48 > $R/gpurun_out/prof_pmc_$C.log 2>&1
     DB=$(find $R/gpurun_out/prof_pmc_$C -name "*.db" | head -1); python $R/tools/rocpd_pmc.py $DB $R/gpurun_out/${N}_pmc_$C.json > /dev/null
 done
 [ -s $R/gpurun_out/${N}_pmc_FETCH_SIZE.json ] && [ -s $R/gpurun_out/${N}_pmc_WRITE_SIZE.json ] && python $R/tools/derive_pmc_decode_step.py $R/gpurun_out/${N}_pmc_FETCH_SIZE.json $R/gpurun_out/${N}_pmc_WRITE_SIZE.json $R/gpurun_out/${N}_pmc_decode_step.json > /dev/null
