@@ -530,12 +530,15 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         for (int i = 0; i < n; i++) {
             bark_context::BatchResult & r = c->batch_results[(size_t) i];
             Utt & u = us[(size_t) i];
+            // the captured graphs bake the sampling constants: an utterance with other parameters than its predecessor needs fresh ones (as bark_hip_set_params)
+            if (c->params.temp != u.rp.temp || c->params.fine_temp != u.rp.fine_temp || c->params.min_eos_p != u.rp.min_eos_p) engine_invalidate_graphs(c);
             c->params.temp = u.rp.temp; c->params.fine_temp = u.rp.fine_temp; c->params.min_eos_p = u.rp.min_eos_p; c->params.n_steps_text_encoder = u.rp.n_steps_text_encoder;
             std::swap(c->rng, u.rng);
-            try { r.ok = engine_generate(c, u.text.c_str()); } catch (...) { std::swap(c->rng, u.rng); c->params = saved; throw; }
+            try { r.ok = engine_generate(c, u.text.c_str()); } catch (...) { std::swap(c->rng, u.rng); c->params = saved; engine_invalidate_graphs(c); throw; }
             std::swap(c->rng, u.rng);
             if (r.ok) { r.semantic = c->semantic_tokens; r.coarse = c->coarse_tokens; r.fine = c->fine_tokens; r.audio = c->audio; good++; }
         }
+        if (c->params.temp != saved.temp || c->params.fine_temp != saved.fine_temp || c->params.min_eos_p != saved.min_eos_p) engine_invalidate_graphs(c);
         c->params = saved;
         return good;
     }
@@ -786,7 +789,12 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 const float ft = us[(size_t) todo[k0]].rp.fine_temp;
                 size_t k1 = k0;
                 while (k1 < todo.size() && k1 - k0 < (size_t) std::max(1, chunk_env) && us[(size_t) todo[k1]].rp.fine_temp == ft) k1++;
-                c->params.fine_temp = ft;
+                if (c->params.fine_temp != ft) {
+                    // the per-utterance fine loop replays one captured forward pass + pick per codebook, and a capture bakes the kind of pick and its
+                    // temperature: a chunk with another fine temperature needs fresh ones
+                    for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
+                    c->params.fine_temp = ft;
+                }
                 if (many) {
                     std::vector<const std::vector<int32_t> *> co;
                     std::vector<std::mt19937> rr;
@@ -804,8 +812,11 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 }
                 k0 = k1;
             }
-        } catch (...) { c->params.fine_temp = saved_fine_temp; throw; }
-        c->params.fine_temp = saved_fine_temp;
+        } catch (...) { c->params.fine_temp = saved_fine_temp; for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } throw; }
+        if (c->params.fine_temp != saved_fine_temp) {
+            c->params.fine_temp = saved_fine_temp;
+            for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
+        }
         c->stats.t_fine_us += now_us() - t;
         std::sort(todo.begin(), todo.end());
         for (int b : todo) {

@@ -188,3 +188,25 @@ def test_lock_step_time_line_hook(toy_model):
         assert all(r is not None and len(r["pcm"]) > 0 for r in res)
     finally:
         ctx.free()
+
+
+@pytest.mark.parametrize("kind", ["q4_0", "f32"])
+def test_ragged_job_on_quantised_and_f32_model_files(kind, toy_q4_model, toy_f32_model):
+    """Per-utterance parameters on the other weight formats: a q4_0 file runs the lock-step path on the per-pair VALU products, an f32 file the
+    sequential fallback of bark_hip_generate_batch_ex (one utterance in flight, the context's parameters switched per utterance) - each
+    utterance equals its own oracle run on the same file."""
+    from oracle.pyoracle import Oracle
+    import bench
+    pkg = _pkg()
+    path = toy_q4_model if kind == "q4_0" else toy_f32_model
+    orc = Oracle(path, n_threads=4)
+    ctx = pkg.BarkContext.load_model(path, pkg.default_params(), seed=3)
+    try:
+        ctx.reserve_batch(8)
+        texts = bench.synth_prompts(11)
+        reqs = [ctx.request_params(temp=0.7 if i % 4 == 1 else 0.0, fine_temp=0.5 if i % 4 == 1 else 0.0, min_eos_p=0.2,
+                                   n_steps_text_encoder=5 + 9 * (i % 7), seed=50 + i) for i in range(len(texts))]
+        res = ctx.generate_batch(texts, params=reqs)
+        _check_job(f"{kind} toy job", res, orc, texts, reqs)
+    finally:
+        ctx.free(); orc.close()
