@@ -625,7 +625,7 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
                 auto enqueue = [&] {
                     run_fine_forward(c, nn, cs);               // only logits [0, 1024) of each row are sampled (bark.cpp:2031)
                     if (greedy) launch_argmax_rows(c->stream, c->logits, cs, 1024, cs, pick_dst, 1, c->d_state);
-                    else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024, pick_dst, 1);
+                    else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024, pick_dst, 1, c->d_state);
                 };
                 if (c->use_graph && rel == 0) {
                     hipGraphExec_t & g = c->fine_graphs[nn];
@@ -761,7 +761,7 @@ std::vector<std::vector<int32_t>> engine_fine_many(bark_context * c, const std::
             int32_t * pick_dst = any_rel ? fb.picks : fb.tokens + (size_t) nn * R;
             run_fine_forward(c, nn, cs, &rb, Z);
             if (greedy) launch_argmax_rows(c->stream, fb.logits, cs, R, cs, pick_dst, 1, c->d_state);
-            else launch_sample_rows_multinomial(c->stream, fb.logits, cs, R, cs, p.fine_temp, fb.u + (size_t) (nn - nc) * R, pick_dst, 1);
+            else launch_sample_rows_multinomial(c->stream, fb.logits, cs, R, cs, p.fine_temp, fb.u + (size_t) (nn - nc) * R, pick_dst, 1, c->d_state);
             if (any_rel)
                 for (int z = 0; z < Z; z++)
                     HIP_OK(hipMemcpyAsync(fb.tokens + (size_t) nn * R + (size_t) z * 1024 + rels[(size_t) z], fb.picks + (size_t) z * 1024 + rels[(size_t) z],

@@ -201,8 +201,9 @@ struct SampleArgs {
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a);
 // fine: per-row greedy pick over the first n_cols of each row -> out[i*out_stride]
 // fine stage, fine_temp > 0: row r picks with the uniform draw u[r]
+// st (optional): near_tie counts the picks settled by the exact path (u within 1e-6 of a bin boundary)
 void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, float temp, const double * u,
-                                    int32_t * out, int out_stride);
+                                    int32_t * out, int out_stride, StepState * st = nullptr);
 void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
                         int out_stride, StepState * st);
 

@@ -202,6 +202,23 @@ void launch_ln_rows(hipStream_t s, const float * x, int N, int E, const float * 
 constexpr float kTieCut = -2.98023223876953125e-08f;     // -2^-25
 constexpr float kNearTie = -4.0e-7f;
 constexpr float kEosBand = 2.0e-3f;
+constexpr double kPickMargin = 1.0e-6;
+
+// the reference's multinomial pick, literally, by ONE thread: e[0..n) exponentials (float), u the sample's uniform draw
+DEVINL int multinomial_exact(const float * e, int n, double u, float * p_last) {
+    float fs = 0.0f;
+    for (int i = 0; i < n; i++) fs += e[i];                    // sequential float sum (bark.cpp:191-195)
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum += (double) (e[i] / fs);   // std::accumulate over the float probabilities
+    double run = 0.0;
+    int pick = n - 1;
+    for (int i = 0; i < n; i++) {
+        run += (double) (e[i] / fs) / sum;                     // normalise, partial_sum
+        if ((i == n - 1 ? 1.0 : run) >= u) { pick = i; break; }
+    }
+    if (p_last) *p_last = e[n - 1] / fs;
+    return pick;
+}
 
 // leading parameters: what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel in kernels.hip)
 __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __restrict__ logits0, StepState * st0, const int n, const int ld_logits, const SampleArgs a) {
@@ -340,17 +357,25 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
 // running sums (last one forced to 1.0) and returns lower_bound(sums, u) for ONE uniform double u in [0,1) drawn with
 // std::generate_canonical<double, 53> - the host draws those u from the context's std::mt19937 in the order the
 // reference would (one per sample) and uploads them, so a seed selects the same random stream as in the reference.
-// The running sums are formed per thread range + block scan instead of sequentially: a pick can differ from libstdc++
-// only if u falls within ~1e-16 of a boundary.
+// Fast path: float sum of the exponentials by a tree, running sums per thread range + block scan.  Against the reference's sequential
+// float sum / sequential double sums the cumulative probabilities move by at most ~1.3e-7 (two float roundings per term; the common
+// factor of the sum cancels in libstdc++'s renormalisation), so the pick is the reference's whenever u is further than kPickMargin =
+// 1e-6 from both ends of the picked bin.  Otherwise (about two picks in a million) the EXACT path runs: one thread walks the
+// exponentials out of LDS - sequential float sum (bark.cpp:191-195), p_i = e_i / sum, libstdc++'s sequential accumulate / normalise /
+// partial_sum in double, last running sum pinned to 1.0, lower_bound.  (Round 4 found the need: a fine-stage pick 1.7e-11 from a bin
+// boundary differed from the host path.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleArgs a) {
     __shared__ float red_f[16];
     __shared__ double red_d[16];
     __shared__ int red_i[16];
+    __shared__ int red_r[16];
     __shared__ int next_tok, next_pos;
+    __shared__ float e_all[12288];                             // exponentials in index order (exact path)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = blockIdx.x;
     if (a.slot_temp && !(a.slot_temp[slot] > 0.0f)) return;    // a greedy slot of a mixed batch: sample_greedy_kernel's
+    if (tid == 0) red_r[0] = 0;
     const float temp = a.slot_temp ? a.slot_temp[slot] : a.temp;
     const float min_eos_p = a.slot_min_eos_p ? a.slot_min_eos_p[slot] : a.min_eos_p;
     const float * logits = a.logits + (size_t) slot * a.ld_logits;
@@ -374,7 +399,10 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
     float fsum = 0.0f;
     #pragma unroll
-    for (int k = 0; k < CH; k++) { pv[k] = tid * CH + k < a.n ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int k = 0; k < CH; k++) {
+        pv[k] = tid * CH + k < a.n ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k];
+        if (tid * CH + k < a.n) e_all[tid * CH + k] = pv[k];
+    }
     for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
     __syncthreads();
     if (lane == 0) red_f[wave] = fsum;
@@ -399,29 +427,40 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
     double incl = dsum;
     for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
     double run = (wave_off + (incl - dsum)) / total;
-    int pick = INT32_MAX;
+    int pick = INT32_MAX, risky = 0;
     #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int i = tid * CH + k;
         if (i < a.n) {
+            const double prev = run;
             run += (double) pv[k] / total;
             const double cp = i == a.n - 1 ? 1.0 : run;                                    // libstdc++ pins the last running sum to 1.0
-            if (cp >= u && i < pick) pick = i;
+            if (cp >= u && i < pick) { pick = i; risky = (cp - u < kPickMargin || u - prev < kPickMargin) ? 1 : 0; }
         }
     }
+    // the smallest index wins; its thread knows how far u is from the ends of its bin
+    const int mine = pick;
     for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
     if (lane == 0) red_i[wave] = pick;
     if (tid == ((a.n - 1) / CH)) red_f[0] = eos_p;
     __syncthreads();
+    pick = red_i[0];
+    #pragma unroll
+    for (int i = 1; i < 16; i++) pick = min(pick, red_i[i]);
+    if (mine == pick && pick != INT32_MAX) red_r[0] = risky;                               // exactly one thread holds the winning index
+    __syncthreads();
     if (tid == 0) {
-        for (int i = 1; i < 16; i++) pick = min(pick, red_i[i]);
         int tok = pick;
-        float ep = 0.0f;
+        float ep = red_f[0];                                    // probability of the LAST logit (bark.cpp:217-218)
+        if (red_r[0] || pick == INT32_MAX) {                    // u next to a bin boundary: the reference's arithmetic, literally
+            tok = multinomial_exact(e_all, a.n, u, &ep);
+            st->near_tie += 1;
+        }
         if (a.mode == 0) {
-            ep = red_f[0];                                      // probability of the LAST logit (bark.cpp:217-218)
             if ((tok == a.eos_token || ep >= min_eos_p) && st->eos_step == INT32_MAX) st->eos_step = step;
             if (a.eos_trace) a.eos_trace[(size_t) slot * a.out_stride + step] = ep;
         } else {
+            ep = 0.0f;
             tok += a.token_base + ((step & 1) ? 1024 : 0);
         }
         a.out_tokens[(size_t) slot * a.out_stride + st->n_out] = tok;
@@ -444,9 +483,10 @@ __global__ __launch_bounds__(1024) void sample_multinomial_kernel(const SampleAr
 
 // fine stage: one wave per row, multinomial over the first n_cols logits of the row; u[row] is that sample's uniform draw
 __global__ __launch_bounds__(256) void sample_rows_multinomial_kernel(const float * logits, int ld, int n_rows, int n_cols, float temp,
-                                                                     const double * u, int32_t * out, int out_stride) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                                     const double * u, int32_t * out, int out_stride, StepState * st) {
+    __shared__ float es[4][1024];                               // the rows' exponentials in index order (exact path)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
     if (row >= n_rows) return;
     const float * l = logits + (size_t) row * ld;
     constexpr int CH = 16;                                      // lane owns ids [lane*16, lane*16+16): n_cols <= 1024
@@ -457,7 +497,10 @@ __global__ __launch_bounds__(256) void sample_rows_multinomial_kernel(const floa
     mx = wave_max(mx);
     float fsum = 0.0f;
     #pragma unroll
-    for (int k = 0; k < CH; k++) { pv[k] = lane * CH + k < n_cols ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k]; }
+    for (int k = 0; k < CH; k++) {
+        pv[k] = lane * CH + k < n_cols ? (float) exp((double) (pv[k] - mx)) : 0.0f; fsum += pv[k];
+        es[wave][lane * CH + k] = pv[k];
+    }
     for (int m = 1; m < 64; m <<= 1) fsum += __shfl_xor(fsum, m, 64);
     double dsum = 0.0;
     #pragma unroll
@@ -467,22 +510,34 @@ __global__ __launch_bounds__(256) void sample_rows_multinomial_kernel(const floa
     for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_up(incl, m, 64); if (lane >= m) incl += o; }
     double run = (incl - dsum) / total;
     const double uu = u[row];
-    int pick = INT32_MAX;
+    int pick = INT32_MAX, risky = 0;
     #pragma unroll
     for (int k = 0; k < CH; k++) {
         const int i = lane * CH + k;
         if (i < n_cols) {
+            const double prev = run;
             run += (double) pv[k] / total;
             const double cp = i == n_cols - 1 ? 1.0 : run;
-            if (cp >= uu && i < pick) pick = i;
+            if (cp >= uu && i < pick) { pick = i; risky = (cp - uu < kPickMargin || uu - prev < kPickMargin) ? 1 : 0; }
         }
     }
+    const int mine = pick;
     for (int m = 1; m < 64; m <<= 1) pick = min(pick, __shfl_xor(pick, m, 64));
+    // the lane that holds the winning index knows how far u is from the ends of its bin
+    const bool exact = __builtin_amdgcn_ballot_w64(pick == INT32_MAX || (mine == pick && risky)) != 0;
+    if (exact) {                                                // wave-uniform; the wave's LDS row was written by this wave only
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the ds_writes above have landed
+        if (lane == 0) {
+            pick = multinomial_exact(es[wave], n_cols, uu, nullptr);
+            if (st) atomicAdd(&st->near_tie, 1);
+        }
+    }
     if (lane == 0) out[(size_t) row * out_stride] = pick;
 }
 void launch_sample_rows_multinomial(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, float temp, const double * u,
-                                    int32_t * out, int out_stride) {
-    hipLaunchKernelGGL(sample_rows_multinomial_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, temp, u, out, out_stride);
+                                    int32_t * out, int out_stride, StepState * st) {
+    if (n_cols > 1024) kernel_fail("bark-hip: the per-row multinomial pick takes at most 1024 columns");
+    hipLaunchKernelGGL(sample_rows_multinomial_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, temp, u, out, out_stride, st);
 }
 
 void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {

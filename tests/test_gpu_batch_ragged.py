@@ -66,9 +66,9 @@ def test_randomised_lock_step_jobs_against_the_oracle(preset):
             texts, reqs = [], []
             for i in range(n):
                 texts.append(" ".join(rng.choice(words, size=int(rng.integers(1, 40)))))
-                sampled = rng.random() < 0.4
-                reqs.append(ctx.request_params(temp=float(rng.choice([0.7, 1.0])) if sampled else 0.0,
-                                               fine_temp=float(rng.choice([0.0, 0.5])) if sampled else 0.0,
+                # temperatures drawn independently: greedy / sampled semantic + coarse stages with a greedy / sampled fine stage in any combination
+                reqs.append(ctx.request_params(temp=float(rng.choice([0.7, 1.0])) if rng.random() < 0.4 else 0.0,
+                                               fine_temp=0.5 if rng.random() < 0.3 else 0.0,
                                                min_eos_p=float(rng.choice(eos_choices)), n_steps_text_encoder=int(rng.integers(1, 121)),
                                                seed=int(rng.integers(0, 2**31))))
             if it == 0:
@@ -204,7 +204,7 @@ def test_ragged_job_on_quantised_and_f32_model_files(kind, toy_q4_model, toy_f32
     try:
         ctx.reserve_batch(8)
         texts = bench.synth_prompts(11)
-        reqs = [ctx.request_params(temp=0.7 if i % 4 == 1 else 0.0, fine_temp=0.5 if i % 4 == 1 else 0.0, min_eos_p=0.2,
+        reqs = [ctx.request_params(temp=0.7 if i % 4 in (1, 3) else 0.0, fine_temp=0.5 if i % 4 in (1, 2) else 0.0, min_eos_p=0.2,
                                    n_steps_text_encoder=5 + 9 * (i % 7), seed=50 + i) for i in range(len(texts))]
         res = ctx.generate_batch(texts, params=reqs)
         _check_job(f"{kind} toy job", res, orc, texts, reqs)
