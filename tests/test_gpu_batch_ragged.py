@@ -210,3 +210,13 @@ def test_ragged_job_on_quantised_and_f32_model_files(kind, toy_q4_model, toy_f32
         _check_job(f"{kind} toy job", res, orc, texts, reqs)
     finally:
         ctx.free(); orc.close()
+
+
+def test_device_and_host_sampling_agree_on_many_sampled_utterances():
+    """tools/sampling_soak.py: 64 sampled utterances (temp 0.7 / 1.0, fine_temp 0.5, own seeds) as one lock-step job with the device multinomial
+    kernels against the same utterances with BARK_HIP_HOST_SAMPLING=1 (std::discrete_distribution on fetched logits): ~45 000 ids and
+    ~400 000 picks (padding rows of the fine windows included), all equal - the picks next to a bin boundary go through the exact path."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sampling_soak.py"), "toy", "64", "60"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert " 0 arrays differ" in r.stdout
