@@ -551,10 +551,14 @@ void launch_sample_greedy(hipStream_t s, const SampleArgs & a) {
     else hipLaunchKernelGGL(sample_greedy_kernel, dim3(a.nbatch), dim3(1024), 0, s, a.logits, a.st, a.n, a.ld_logits, a);
 }
 
+// fine stage, greedy: per-row pick of gpt_argmax_sample (bark.cpp:223-247) over the first n_cols logits.  Fast path as in sample_greedy_kernel: the
+// first index whose e_i is 1.0f wins unless another logit lies within kNearTie of the maximum; then (about one row in 10^6) the wave repeats the
+// reference's arithmetic literally - e_i in double precision, sequential float sum, p_i = e_i / sum, first strict maximum.
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, int ld, int n_rows, int n_cols, int32_t * out,
-                                                         int out_stride, StepState * st) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                         int out_stride, StepState * st, int force_exact) {
+    __shared__ float es[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
     if (row >= n_rows) return;
     const float * l = logits + (size_t) row * ld;
     float mx = -INFINITY;
@@ -567,14 +571,24 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float * logits, 
         if (d >= kNearTie) close++;
     }
     for (int m = 1; m < 64; m <<= 1) { best = min(best, __shfl_xor(best, m, 64)); close += __shfl_xor(close, m, 64); }
-    if (lane == 0) {
-        out[(size_t) row * out_stride] = best;
-        if (close > 1 && st) atomicAdd(&st->near_tie, 1);
+    if ((close > 1 || force_exact) && n_cols <= 1024) {        // wave-uniform
+        for (int i = lane; i < n_cols; i += 64) es[wave][i] = (float) exp((double) (l[i] / 0.7f - mx));
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS row
+        if (lane == 0) {
+            float fs = 0.0f;
+            for (int i = 0; i < n_cols; i++) fs += es[wave][i];                             // float sum in index order (bark.cpp:191-195)
+            float pbest = -1.0f; int ibest = 0;
+            for (int i = 0; i < n_cols; i++) { const float p = es[wave][i] / fs; if (p > pbest) { pbest = p; ibest = i; } }      // first strict maximum
+            best = ibest;
+            if (st) atomicAdd(&st->near_tie, 1);
+        }
     }
+    if (lane == 0) out[(size_t) row * out_stride] = best;
 }
 void launch_argmax_rows(hipStream_t s, const float * logits, int ld, int n_rows, int n_cols, int32_t * out, int out_stride,
                         StepState * st) {
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, out, out_stride, st);
+    static const int force_exact = getenv("BARK_HIP_EXACT_SAMPLING") ? atoi(getenv("BARK_HIP_EXACT_SAMPLING")) : 0;      // tests: every row through the exact path
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, s, logits, ld, n_rows, n_cols, out, out_stride, st, force_exact);
 }
 
 }  // namespace barkhip
