@@ -439,11 +439,11 @@ std::vector<int32_t> engine_semantic(bark_context * c, const std::vector<int32_t
         }
         const int n_keep = std::min(cur.eos_step, issued);
         out.resize((size_t) n_keep);
-        if (n_keep) HIP_OK(hipMemcpy(out.data(), c->d_out_tokens, (size_t) n_keep * 4, hipMemcpyDeviceToHost));
+        if (n_keep) copy_to_host(c, out.data(), c->d_out_tokens, (size_t) n_keep * 4);
         if (eos_trace) {
             const int n_tr = std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
             eos_trace->resize((size_t) n_tr);
-            if (n_tr) HIP_OK(hipMemcpy(eos_trace->data(), c->d_eos_trace, (size_t) n_tr * 4, hipMemcpyDeviceToHost));
+            if (n_tr) copy_to_host(c, eos_trace->data(), c->d_eos_trace, (size_t) n_tr * 4);
         }
         const int n_used = std::min(issued, cur.eos_step == INT32_MAX ? issued : cur.eos_step + 1);
         c->stats.n_sample_semantic += n_used;
@@ -542,7 +542,7 @@ std::vector<int32_t> engine_coarse(bark_context * c, const std::vector<int32_t> 
             for (int j = 1; j < steps_here; j++) progress(c, COARSE, 100 * (step_idx + j + 1) / n_steps);
             const StepState cur = get_state(c);
             std::vector<int32_t> got((size_t) steps_here);
-            HIP_OK(hipMemcpy(got.data(), c->d_out_tokens, (size_t) steps_here * 4, hipMemcpyDeviceToHost));
+            copy_to_host(c, got.data(), c->d_out_tokens, (size_t) steps_here * 4);
             out.insert(out.end(), got.begin(), got.end());
             cached = in;                                               // rows now in the cache: the prompt + every token fed back
             cached.insert(cached.end(), got.begin(), got.end() - 1);

@@ -574,7 +574,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             const int keep = std::min(st.eos_step, u.cap);
             auto & out = c->batch_results[(size_t) slot_utt[(size_t) slot]].semantic;
             out.resize((size_t) keep);
-            if (keep) HIP_OK(hipMemcpy(out.data(), bb.out_tokens + (size_t) slot * 2048, (size_t) keep * 4, hipMemcpyDeviceToHost));
+            if (keep) copy_to_host(c, out.data(), bb.out_tokens + (size_t) slot * 2048, (size_t) keep * 4);
             const int n_used = st.eos_step == INT32_MAX ? u.cap : std::min(u.cap, st.eos_step + 1);
             c->stats.n_sample_semantic += n_used;
             if (u.rp.temp > 0.0f) u.rng.discard(2ull * (unsigned long long) n_used);        // as consume_uniforms()
@@ -738,7 +738,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
                 std::vector<int32_t> got((size_t) here[(size_t) b]);
-                HIP_OK(hipMemcpy(got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4, hipMemcpyDeviceToHost));
+                copy_to_host(c, got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4);
                 u.coarse_out.insert(u.coarse_out.end(), got.begin(), got.end());
                 // rows now in the slot's cache: its prompt and every token fed back (steps past `here` wrote further rows, but those are
                 // never matched because the ids are not recorded)

@@ -36,6 +36,13 @@ template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
     return (T *) p;
 }
 
+// device -> host on the context's own (non-blocking) stream, complete on return: never the legacy stream, which refuses work while ANY blocking
+// stream of the process captures a graph (other contexts on other host threads do)
+inline void copy_to_host(bark_context * c, void * dst, const void * src, size_t bytes) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+
 // rows [row0, ...) of a weight matrix behind a QMat handle (block formats or f32)
 inline QMat q4_rows(const QMat & w, size_t row0, int K) {
     QMat r = w;

@@ -140,7 +140,7 @@ static void init_runtime(bark_context * ctxp) {
     }
     ctx->ps = dev_alloc<float>(ctx.get(), (size_t) ctx->max_H * P * 4);
     ctx->knew = dev_alloc<float>(ctx.get(), (size_t) ctx->max_E);
-    HIP_OK(hipMemset(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float)));
+    HIP_OK(hipMemsetAsync(ctx->ps, 0, (size_t) ctx->max_H * P * 4 * sizeof(float), ctx->stream));
     if (ctx->any_q4) {
         ctx->att32 = dev_alloc<float>(ctx.get(), NE);
         ctx->h32 = dev_alloc<float>(ctx.get(), NE * 4);
@@ -150,8 +150,8 @@ static void init_runtime(bark_context * ctxp) {
         ctx->xq.s = dev_alloc<float>(ctx.get(), NE * 4 / 32);
         ctx->xq.dT = dev_alloc<float>(ctx.get(), nT);
         ctx->xq.sT = dev_alloc<float>(ctx.get(), nT);
-        HIP_OK(hipMemset(ctx->xq.dT, 0, nT * sizeof(float)));
-        HIP_OK(hipMemset(ctx->xq.sT, 0, nT * sizeof(float)));
+        HIP_OK(hipMemsetAsync(ctx->xq.dT, 0, nT * sizeof(float), ctx->stream));
+        HIP_OK(hipMemsetAsync(ctx->xq.sT, 0, nT * sizeof(float), ctx->stream));
         if (ctx->any_w32) ctx->xn32 = dev_alloc<float>(ctx.get(), NE);
     }
     size_t n_logits = (size_t) 1024 * ctx->gpt[2].hp.n_out_vocab;
@@ -173,8 +173,12 @@ static void init_runtime(bark_context * ctxp) {
             lut[i] = __builtin_bit_cast(uint16_t, r);
         }
         ctx->d_gelu_lut = dev_alloc<uint16_t>(ctx.get(), 65536);
-        HIP_OK(hipMemcpy(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpyAsync(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));               // `lut` leaves scope
     }
+    // everything the load put on the legacy stream (weight uploads) or on this one is in place before the first kernel of the non-blocking stream
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    HIP_OK(hipDeviceSynchronize());
 }
 
 // bark_load_model_from_file (bark.cpp:1080-1163): parse the container, upload every tensor of the hot path.
@@ -196,7 +200,9 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         if (!strcmp(e, "1")) ctx->fast_gemm = 1;
         else if (strcmp(e, "0") && *e) throw std::runtime_error("BARK_HIP_FAST_GEMM accepts 0 or 1");
     }
-    HIP_OK(hipStreamCreate(&ctx->stream));
+    // non-blocking: the legacy stream neither waits for this one nor is refused while it captures a graph - contexts (clones) of one process run
+    // from several host threads, and a plain hipMemcpy of one thread must not collide with a capture of another (tools/staggered_jobs.py)
+    HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     init_kernel_attributes();
 
     ModelFile mf;
@@ -498,7 +504,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     ctx->device = src->device; ctx->use_graph = src->use_graph; ctx->fast_gemm = src->fast_gemm;
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
     ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4; ctx->any_w32 = src->any_w32;
-    HIP_OK(hipStreamCreate(&ctx->stream));
+    HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     init_runtime(ctx.get());
     ctx->description = src->description + " (clone)";
     return ctx.release();

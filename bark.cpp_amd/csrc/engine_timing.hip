@@ -150,7 +150,7 @@ int engine_trace_decode_step(bark_context * c, int which, int ctxlen, int replay
     HIP_OK(hipStreamSynchronize(c->stream));
     unsigned n = c->trace_per_replay * (unsigned) replays;
     n = std::min(n, std::min(c->trace_cap, (unsigned) std::max(0, cap_records)));
-    HIP_OK(hipMemcpy(out6, c->trace_rec, (size_t) n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    copy_to_host(c, out6, c->trace_rec, (size_t) n * 8 * sizeof(unsigned long long));
     (void) hipGraphExecDestroy(g);
     return (int) n;
 }
