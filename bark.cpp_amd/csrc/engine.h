@@ -141,6 +141,7 @@ struct bark_context {
     } fine_batch;
     struct BatchResult { std::vector<int32_t> semantic, coarse, fine; std::vector<float> audio; bool ok = false; };
     std::vector<BatchResult> batch_results;
+    bark_context * tail = nullptr;                      // clone that runs the fine passes / codec of a lock-step job beside its decode chain (engine_batch.hip: JobTail)
 
 #ifdef BARK_TRACE
     unsigned long long * trace_rec = nullptr; unsigned * trace_pos = nullptr; unsigned trace_cap = 0; int trace_kid = 0; unsigned trace_base = 0, trace_per_replay = 0;

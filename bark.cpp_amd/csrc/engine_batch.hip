@@ -7,8 +7,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 using namespace barkhip;
 using namespace barkhip::detail;
@@ -499,6 +503,168 @@ void set_slot_params(bark_context * c, int slot, const Utt & u) {
     c->h_slot_par[(size_t) c->batch.cap + slot] = u.rp.min_eos_p;
 }
 
+
+// The tail of a job: fine passes (bark.cpp:1961-2059) and codec (bark.cpp:2143-2167) of the utterances that have left the coarse stage.
+// With a second context (a clone: own non-blocking stream, scratch and graphs, the same weights) it runs on a helper thread WHILE the lock
+// steps of the remaining utterances go on: a lock step is a chain of ~100 small dependent kernels that leaves most of the chip idle, the fine
+// passes are wide matrix-core kernels (tools/staggered_jobs.py: two job streams a second apart deliver 14 % more than one).  Utterances
+// arrive when their last coarse window is done; the helper takes up to `chunk` of one fine temperature at a time (their windows side by side,
+// engine_fine_many), the codec runs over what has accumulated whenever nobody waits for a fine pass (at most 32 per pass).  Per-utterance
+// results do not depend on the grouping (every utterance is checked against its own oracle run, tests/test_gpu_batch_ragged.py).
+// inline_ctx: BARK_HIP_TAIL_STREAM=0 - the same steps on the job's own context after the coarse stage (the A/B arm, and the only form for
+// host-side sampling).  The progress callback stays on the calling thread (bark.h contract): the helper reports nothing.
+struct JobTail {
+    bark_context * c;                                            // the job's context: parameters, results
+    bark_context * t;                                            // the context the tail runs on (c itself: inline)
+    std::vector<Utt> & us;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<int> pending;                                     // utterances whose coarse ids are complete
+    bool closed = false, abandon = false;
+    std::exception_ptr err;
+    std::thread th;
+    std::vector<int> codec_wait;
+    int good = 0;
+    float saved_fine_temp = 0.0f;
+
+    JobTail(bark_context * job, std::vector<Utt> & utts, bool second_stream) : c(job), t(job), us(utts) {
+        if (second_stream) {
+            if (!c->tail) {
+                c->tail = engine_clone(c, 0);
+                // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever
+                // a CU frees up), optionally confined to a part of the chip (BARK_HIP_TAIL_CUS = n: a CU mask of the first n CUs)
+                const char * pe = getenv("BARK_HIP_TAIL_PRIORITY"), * ce = getenv("BARK_HIP_TAIL_CUS");
+                const int low = pe ? atoi(pe) : 1, cus = ce ? atoi(ce) : 0;
+                if (low || cus > 0) {
+                    HIP_OK(hipStreamSynchronize(c->tail->stream));
+                    HIP_OK(hipStreamDestroy(c->tail->stream)); c->tail->stream = nullptr;
+                    if (cus > 0) {
+                        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int i = 0; i < std::min(cus, 256); i++) mask[i >> 5] |= 1u << (i & 31);
+                        HIP_OK(hipExtStreamCreateWithCUMask(&c->tail->stream, 8, mask));
+                    } else {
+                        int least = 0, greatest = 0;
+                        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                        HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
+                    }
+                }
+            }
+            t = c->tail;
+            t->params = c->params;
+            t->params.progress_callback = nullptr; t->params.progress_callback_user_data = nullptr;
+            const int64_t t_load = t->stats.t_load_us;
+            t->stats = bark_hip_stats{}; t->stats.t_load_us = t_load;
+        }
+        saved_fine_temp = t->params.fine_temp;
+        if (t != c) th = std::thread([this] { run(); });
+    }
+    ~JobTail() {
+        { std::lock_guard<std::mutex> g(mu); closed = true; abandon = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void drop_fine_graphs() { for (auto & g : t->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
+    void push(const std::vector<int> & utts) {
+        if (utts.empty()) return;
+        { std::lock_guard<std::mutex> g(mu); for (int b : utts) pending.push_back(b); }
+        cv.notify_all();
+    }
+    // everything pushed so far is carried through; rethrows what the helper met
+    void finish() {
+        { std::lock_guard<std::mutex> g(mu); closed = true; }
+        cv.notify_all();
+        if (t != c) { if (th.joinable()) th.join(); }
+        else run();
+        if (err) std::rethrow_exception(err);
+        if (t != c) {
+            c->stats.n_sample_fine += t->stats.n_sample_fine; c->stats.n_near_tie += t->stats.n_near_tie;
+            c->stats.t_fine_us += t->stats.t_fine_us; c->stats.t_codec_us += t->stats.t_codec_us;
+            c->stats.n_frames += t->stats.n_frames; c->stats.n_semantic += t->stats.n_semantic; c->stats.n_samples += t->stats.n_samples;
+            c->stats.graph_replays += t->stats.graph_replays;
+        }
+    }
+    void fine_chunk(const std::vector<int> & take, bool many) {
+        const int64_t t0 = now_us();
+        const float ft = us[(size_t) take[0]].rp.fine_temp;
+        if (t->params.fine_temp != ft) {
+            // the per-utterance fine loop replays one captured forward pass + pick per codebook, and a capture bakes the kind of pick and its
+            // temperature: a chunk with another fine temperature needs fresh ones
+            drop_fine_graphs();
+            t->params.fine_temp = ft;
+        }
+        if (many) {
+            std::vector<const std::vector<int32_t> *> co;
+            std::vector<std::mt19937> rr;
+            for (int b : take) { co.push_back(&c->batch_results[(size_t) b].coarse); rr.push_back(us[(size_t) b].rng); }
+            std::vector<std::vector<int32_t>> fine = engine_fine_many(t, co, &rr);
+            for (size_t k = 0; k < take.size(); k++) { c->batch_results[(size_t) take[k]].fine = std::move(fine[k]); us[(size_t) take[k]].rng = rr[k]; }
+        } else {
+            for (int b : take) {
+                bark_context::BatchResult & r = c->batch_results[(size_t) b];
+                std::swap(t->rng, us[(size_t) b].rng);                                // the fine stage draws from the utterance's generator
+                try { r.fine = engine_fine(t, r.coarse); } catch (...) { std::swap(t->rng, us[(size_t) b].rng); throw; }
+                std::swap(t->rng, us[(size_t) b].rng);
+            }
+        }
+        t->stats.t_fine_us += now_us() - t0;
+    }
+    void codec_pass(size_t count) {
+        const int64_t t0 = now_us();
+        std::vector<std::vector<int32_t>> codes; std::vector<const int32_t *> cp; std::vector<int> Ts;
+        for (size_t k = 0; k < count; k++) {
+            const bark_context::BatchResult & r = c->batch_results[(size_t) codec_wait[k]];
+            const int T = (int) r.fine.size() / 8;
+            std::vector<int32_t> cd((size_t) 8 * T);
+            for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) cd[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];      // bark.cpp:2153-2159
+            codes.push_back(std::move(cd)); Ts.push_back(T);
+            t->stats.n_frames += T; t->stats.n_semantic += (int32_t) r.semantic.size();
+        }
+        for (auto & cd : codes) cp.push_back(cd.data());
+        std::vector<std::vector<float>> pcm = engine_codec_decode_many(t, cp, 8, Ts, -1, nullptr);
+        for (size_t k = 0; k < count; k++) {
+            bark_context::BatchResult & r = c->batch_results[(size_t) codec_wait[k]];
+            r.audio = std::move(pcm[k]);
+            t->stats.n_samples += (int32_t) r.audio.size();
+            r.ok = true; good++;
+        }
+        codec_wait.erase(codec_wait.begin(), codec_wait.begin() + (long) count);
+        t->stats.t_codec_us += now_us() - t0;
+    }
+    void run() {
+        try {
+            HIP_OK(hipSetDevice(t->device));
+            static const int chunk_env = getenv("BARK_HIP_FINE_BATCH") ? atoi(getenv("BARK_HIP_FINE_BATCH")) : 8;
+            const bool many = chunk_env > 1 && !t->gpt[2].q4 && !t->gpt[2].w32 && !t->host_sampling;
+            const size_t chunk = (size_t) std::max(1, chunk_env);
+            while (true) {
+                std::vector<int> take;
+                bool drained = false;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return closed || !pending.empty(); });
+                    if (abandon) break;
+                    if (!pending.empty()) {
+                        const float ft = us[(size_t) pending.front()].rp.fine_temp;
+                        for (auto it = pending.begin(); it != pending.end() && take.size() < chunk;) {
+                            if (us[(size_t) *it].rp.fine_temp == ft) { take.push_back(*it); it = pending.erase(it); } else ++it;
+                        }
+                    }
+                    drained = pending.empty();
+                    if (take.empty() && closed && codec_wait.empty()) break;
+                }
+                if (!take.empty()) {
+                    fine_chunk(take, many);
+                    std::sort(take.begin(), take.end());
+                    codec_wait.insert(codec_wait.end(), take.begin(), take.end());
+                    std::lock_guard<std::mutex> g(mu);
+                    drained = pending.empty();
+                }
+                while (codec_wait.size() >= 32 || (drained && !codec_wait.empty())) codec_pass(std::min<size_t>(32, codec_wait.size()));
+            }
+        } catch (...) { err = std::current_exception(); }
+        if (t->params.fine_temp != saved_fine_temp) { t->params.fine_temp = saved_fine_temp; drop_fine_graphs(); }
+    }
+};
+
 }  // namespace
 
 // A job of n utterances on the context's lock-step slots (bark.cpp:2125-2172 per utterance).  The stages run one after the other for the
@@ -640,6 +806,10 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
     }
     c->stats.t_semantic_us = now_us() - t;
 
+    // the job's tail on a second stream (JobTail): utterances are handed over as they leave the coarse stage
+    const bool tail_stream_env = !(getenv("BARK_HIP_TAIL_STREAM") && !strcmp(getenv("BARK_HIP_TAIL_STREAM"), "0"));      // read per job: tests flip it
+    JobTail tail(c, us, tail_stream_env && n > 1);
+
     // ---- coarse (bark.cpp:1745-1863): windows in lock step, slots refilled at window boundaries ------------------------------------------
     t = now_us();
     {
@@ -751,6 +921,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             }
             // retire the finished utterances (from the back: a move never touches a slot still to be looked at)
             bool moved = false;
+            std::vector<int> retired;
             for (int b = B - 1; b >= 0; b--) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (u.step_idx < u.n_steps) continue;
@@ -760,89 +931,23 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                     res.push_back(u.coarse_out[i] - p.semantic_vocab_size);
                     res.push_back(u.coarse_out[i + 1] - p.semantic_vocab_size - p.codebook_size);
                 }
+                if (!res.empty()) retired.push_back(slot_utt[(size_t) b]);
                 const int last = (int) slot_utt.size() - 1;
                 if (b != last) { move_slot(c, 1, last, b); slot_utt[(size_t) b] = slot_utt[(size_t) last]; moved = true; }
                 slot_utt.pop_back();
             }
             if (moved) upload_slot_params(c);
+            std::sort(retired.begin(), retired.end());
+            tail.push(retired);                                          // all of a window boundary at once: the helper groups them into passes
             progress(c, COARSE, total_steps ? (int) (100 * done_steps / total_steps) : 100);
         }
     }
     c->stats.t_coarse_us = now_us() - t;
 
-    // ---- fine (bark.cpp:1961-2059): the windows of up to `chunk` utterances side by side in every forward pass (engine_fine_many): the
-    // products then see thousands of rows (whole waves of tiles on every CU instead of 0.75 - 2.25 rounds), the attention runs per window.
-    // Utterances are grouped by their fine temperature.  Quantised / f32 model files keep the per-utterance loop.
-    int good = 0;
-    std::vector<int> live;                                           // utterances that reach the codec
-    std::vector<std::vector<int32_t>> codes;
-    {
-        static const int chunk_env = getenv("BARK_HIP_FINE_BATCH") ? atoi(getenv("BARK_HIP_FINE_BATCH")) : 8;
-        const bool many = chunk_env > 1 && !c->gpt[2].q4 && !c->gpt[2].w32 && !c->host_sampling;
-        std::vector<int> todo;
-        for (int b = 0; b < n; b++) if (!c->batch_results[(size_t) b].coarse.empty()) todo.push_back(b);
-        std::stable_sort(todo.begin(), todo.end(), [&](int a, int b2) { return us[(size_t) a].rp.fine_temp < us[(size_t) b2].rp.fine_temp; });
-        t = now_us();
-        const float saved_fine_temp = c->params.fine_temp;
-        try {
-            for (size_t k0 = 0; k0 < todo.size();) {
-                const float ft = us[(size_t) todo[k0]].rp.fine_temp;
-                size_t k1 = k0;
-                while (k1 < todo.size() && k1 - k0 < (size_t) std::max(1, chunk_env) && us[(size_t) todo[k1]].rp.fine_temp == ft) k1++;
-                if (c->params.fine_temp != ft) {
-                    // the per-utterance fine loop replays one captured forward pass + pick per codebook, and a capture bakes the kind of pick and its
-                    // temperature: a chunk with another fine temperature needs fresh ones
-                    for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
-                    c->params.fine_temp = ft;
-                }
-                if (many) {
-                    std::vector<const std::vector<int32_t> *> co;
-                    std::vector<std::mt19937> rr;
-                    for (size_t k = k0; k < k1; k++) { co.push_back(&c->batch_results[(size_t) todo[k]].coarse); rr.push_back(us[(size_t) todo[k]].rng); }
-                    std::vector<std::vector<int32_t>> fine = engine_fine_many(c, co, &rr);
-                    for (size_t k = k0; k < k1; k++) { c->batch_results[(size_t) todo[k]].fine = std::move(fine[k - k0]); us[(size_t) todo[k]].rng = rr[k - k0]; }
-                } else {
-                    for (size_t k = k0; k < k1; k++) {
-                        const int b = todo[k];
-                        bark_context::BatchResult & r = c->batch_results[(size_t) b];
-                        std::swap(c->rng, us[(size_t) b].rng);                        // the fine stage draws from the utterance's generator
-                        try { r.fine = engine_fine(c, r.coarse); } catch (...) { std::swap(c->rng, us[(size_t) b].rng); throw; }
-                        std::swap(c->rng, us[(size_t) b].rng);
-                    }
-                }
-                k0 = k1;
-            }
-        } catch (...) { c->params.fine_temp = saved_fine_temp; for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } throw; }
-        if (c->params.fine_temp != saved_fine_temp) {
-            c->params.fine_temp = saved_fine_temp;
-            for (auto & g : c->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }
-        }
-        c->stats.t_fine_us += now_us() - t;
-        std::sort(todo.begin(), todo.end());
-        for (int b : todo) {
-            bark_context::BatchResult & r = c->batch_results[(size_t) b];
-            const int T = (int) r.fine.size() / 8;
-            std::vector<int32_t> cd((size_t) 8 * T);
-            for (int ch = 0; ch < 8; ch++) for (int i = 0; i < T; i++) cd[(size_t) ch * T + i] = r.fine[(size_t) i * 8 + ch];      // bark.cpp:2153-2159
-            codes.push_back(std::move(cd)); live.push_back(b);
-            c->stats.n_frames += T; c->stats.n_semantic += (int32_t) r.semantic.size();
-        }
-    }
-    // ---- codec: the utterances of the job in passes of up to 32 (engine_codec.hip) -----------------------------------------------------------
-    for (size_t k0 = 0; k0 < live.size(); k0 += 32) {
-        const size_t k1 = std::min(live.size(), k0 + 32);
-        t = now_us();
-        std::vector<const int32_t *> cp; std::vector<int> Ts;
-        for (size_t k = k0; k < k1; k++) { cp.push_back(codes[k].data()); Ts.push_back((int) codes[k].size() / 8); }
-        std::vector<std::vector<float>> pcm = engine_codec_decode_many(c, cp, 8, Ts, -1, nullptr);
-        c->stats.t_codec_us += now_us() - t;
-        for (size_t k = k0; k < k1; k++) {
-            bark_context::BatchResult & r = c->batch_results[(size_t) live[k]];
-            r.audio = std::move(pcm[k - k0]);
-            c->stats.n_samples += (int32_t) r.audio.size();
-            r.ok = true; good++;
-        }
-    }
+    // ---- fine + codec: whatever the helper has not finished yet (everything, without a second stream) ------------------------------------
+    tail.finish();
+    if (tail.t != c) progress(c, FINE, 100);                         // the helper reports nothing (the callback belongs to the calling thread)
+    const int good = tail.good;
     c->stats.t_eval_us = now_us() - t0;
     return good;
 }

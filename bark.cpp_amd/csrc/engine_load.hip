@@ -76,6 +76,7 @@ float gelu_tanh_host(float x) {
 
 
 bark_context::~bark_context() {
+    delete tail;
     (void) hipSetDevice(device);
     for (auto & g : gpt) {
         for (auto & e : g.decode_graph) if (e) (void) hipGraphExecDestroy(e);

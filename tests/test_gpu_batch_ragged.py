@@ -104,6 +104,31 @@ def test_job_larger_than_the_slots_equals_the_job_on_enough_slots(toy_model):
             _exact(f"utterance {i} {k}", a[k], b[k])
 
 
+def test_job_tail_on_a_second_stream_equals_the_one_stream_job(toy_model, monkeypatch):
+    """The fine passes and the codec of utterances that have left the coarse stage run on a clone of the context beside the lock steps of the
+    others (engine_batch.hip: JobTail); BARK_HIP_TAIL_STREAM=0 keeps them behind the coarse stage on the job's own stream.  Same job (31 utterances
+    with their own caps and temperatures on 8 slots: utterances leave at every window boundary), both forms, equal bit for bit - and the stage
+    counters of the two-stream job still account for every utterance."""
+    import bench
+    pkg = _pkg()
+    texts = bench.synth_prompts(31)
+    outs, stats = [], []
+    for arm in ("0", "1"):
+        monkeypatch.setenv("BARK_HIP_TAIL_STREAM", arm)
+        ctx = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=40), 0)
+        ctx.reserve_batch(8)
+        reqs = [ctx.request_params(n_steps_text_encoder=5 + 11 * (i % 10), temp=0.7 if i % 3 == 0 else 0.0, fine_temp=0.5 if i % 4 == 1 else 0.0, seed=100 + i)
+                for i in range(len(texts))]
+        outs.append(ctx.generate_batch(texts, params=reqs))
+        stats.append(ctx.stats())
+        ctx.free()
+    for i, (a, b) in enumerate(zip(*outs)):
+        for k in ("semantic", "coarse", "fine", "pcm"):
+            _exact(f"utterance {i} {k}", a[k], b[k])
+    for k in ("n_sample_semantic", "n_sample_coarse", "n_sample_fine", "n_frames", "n_samples"):
+        assert stats[0][k] == stats[1][k] and stats[0][k] > 0, (k, stats[0][k], stats[1][k])
+
+
 @pytest.mark.slow
 def test_small_ragged_job_matches_committed_oracle_outputs(small_model):
     """bark-small shapes, 16 slots, the ragged form of BASELINE config 5 (bench.ragged_caps: step caps 64..256 by prompt length): every
