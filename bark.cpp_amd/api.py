@@ -75,7 +75,7 @@ EXPORTS = [
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_generate_batch_ex", "bark_hip_reserve_batch", "bark_hip_profile_lock_step", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
     "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe",
-    "bark_hip_batcher_create", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_admitted", "bark_hip_batcher_free",
+    "bark_hip_batcher_create", "bark_hip_batcher_create_ex", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_admitted", "bark_hip_batcher_free",
 ]
 
 
@@ -143,6 +143,8 @@ def load_library() -> C.CDLL:
     lib.bark_hip_time_fine_pass.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.bark_hip_batcher_create.restype = vp
     lib.bark_hip_batcher_create.argtypes = [vp, C.c_int, C.c_int]
+    lib.bark_hip_batcher_create_ex.restype = vp
+    lib.bark_hip_batcher_create_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.bark_hip_batcher_submit.restype = C.c_int64
     lib.bark_hip_batcher_submit.argtypes = [vp, C.c_char_p, C.c_uint32]
     lib.bark_hip_batcher_submit_ex.restype = C.c_int64
@@ -456,10 +458,10 @@ class Batcher:
     """bark_hip_batcher: thread-safe submit / wait in front of the context's lock-step batches (the context is owned by the batcher's
     worker thread while it lives)."""
 
-    def __init__(self, ctx: "BarkContext", max_batch: int = 32, max_wait_ms: int = 2):
+    def __init__(self, ctx: "BarkContext", max_batch: int = 32, max_wait_ms: int = 2, streams: int = 1):
         self._lib = ctx._lib
         self._ctx = ctx                                 # the worker thread runs on this context: it must outlive the batcher
-        self._b = self._lib.bark_hip_batcher_create(ctx._h, max_batch, max_wait_ms)
+        self._b = self._lib.bark_hip_batcher_create_ex(ctx._h, max_batch, max_wait_ms, streams)     # streams > 1: further workers on clones of ctx
         if not self._b:
             raise RuntimeError("bark_hip_batcher_create failed")
 

@@ -7,7 +7,7 @@
 // a counter starting at the server's --seed); its audio is what a fresh context loaded with that seed generates, whatever batch it joined.
 // Plain POSIX sockets, one thread per connection, Connection: close; no third-party code.
 //
-//   bark_batch_server -m model.bin [-a 127.0.0.1] [-p 1337] [-s seed] [--max-batch 32] [--max-wait-ms 5] [--temp t] [--fine-temp t]
+//   bark_batch_server -m model.bin [-a 127.0.0.1] [-p 1337] [-s seed] [--max-batch 32] [--max-wait-ms 5] [--streams 1] [--temp t] [--fine-temp t]
 #include "bark.h"
 #include "bark_mi355x.h"
 #include "http_util.h"
@@ -32,7 +32,7 @@ using barkhttp::json_string; using barkhttp::json_uint; using barkhttp::wav_f32;
 
 struct Options {
     std::string model, host = "127.0.0.1";
-    int port = 1337, max_batch = 32, max_wait_ms = 5;
+    int port = 1337, max_batch = 32, max_wait_ms = 5, streams = 1;
     uint32_t seed = 0;
     float temp = -1.0f, fine_temp = -1.0f;
 };
@@ -111,7 +111,7 @@ void serve(int fd, bark_hip_batcher * batcher, int sample_rate) {
 }
 
 void usage(const char * argv0) {
-    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 256; the context serves up to 64 at a time)] [--max-wait-ms n] [--temp t] [--fine-temp t]\n", argv0);
+    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 256; the context serves up to 64 at a time)] [--max-wait-ms n] [--streams n (1 .. 4 jobs in flight)] [--temp t] [--fine-temp t]\n", argv0);
 }
 
 }  // namespace
@@ -127,6 +127,7 @@ int main(int argc, char ** argv) {
         else if (a == "-s" || a == "--seed") o.seed = (uint32_t) strtoul(next("-s"), nullptr, 10);
         else if (a == "--max-batch") o.max_batch = atoi(next("--max-batch"));
         else if (a == "--max-wait-ms") o.max_wait_ms = atoi(next("--max-wait-ms"));
+        else if (a == "--streams") o.streams = atoi(next("--streams"));
         else if (a == "--temp") o.temp = (float) atof(next("--temp"));
         else if (a == "--fine-temp") o.fine_temp = (float) atof(next("--fine-temp"));
         else { usage(argv[0]); return a == "-h" || a == "--help" ? 0 : 1; }
@@ -138,7 +139,7 @@ int main(int argc, char ** argv) {
     if (o.fine_temp >= 0.0f) params.fine_temp = o.fine_temp;
     bark_context * ctx = bark_load_model(o.model.c_str(), params, o.seed);
     if (!ctx) { fprintf(stderr, "%s: could not load the model\n", argv[0]); return 1; }
-    bark_hip_batcher * batcher = bark_hip_batcher_create(ctx, o.max_batch, o.max_wait_ms);
+    bark_hip_batcher * batcher = bark_hip_batcher_create_ex(ctx, o.max_batch, o.max_wait_ms, o.streams);
     if (!batcher) { fprintf(stderr, "%s: could not create the request collector\n", argv[0]); bark_free(ctx); return 1; }
     next_seed = o.seed;
 
