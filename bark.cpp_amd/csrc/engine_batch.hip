@@ -549,6 +549,8 @@ struct JobTail {
                 }
             }
             t = c->tail;
+            // its captured fine passes bake the fine temperature (bark_hip_set_params on the job's context drops them too: engine_invalidate_graphs)
+            if (t->params.fine_temp != c->params.fine_temp) drop_fine_graphs_of(t);
             t->params = c->params;
             t->params.progress_callback = nullptr; t->params.progress_callback_user_data = nullptr;
             const int64_t t_load = t->stats.t_load_us;
@@ -562,7 +564,8 @@ struct JobTail {
         cv.notify_all();
         if (th.joinable()) th.join();
     }
-    void drop_fine_graphs() { for (auto & g : t->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
+    static void drop_fine_graphs_of(bark_context * x) { for (auto & g : x->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
+    void drop_fine_graphs() { drop_fine_graphs_of(t); }
     void push(const std::vector<int> & utts) {
         if (utts.empty()) return;
         { std::lock_guard<std::mutex> g(mu); for (int b : utts) pending.push_back(b); }

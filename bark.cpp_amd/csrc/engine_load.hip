@@ -100,6 +100,7 @@ bark_context::SharedWeights::~SharedWeights() {
 namespace barkhip {
 
 void engine_invalidate_graphs(bark_context * ctx) {
+    if (ctx->tail) engine_invalidate_graphs(ctx->tail);       // the clone that runs the tail of lock-step jobs replays graphs with the same constants
     for (auto & g : ctx->batch_graphs) if (g.second) (void) hipGraphExecDestroy(g.second);
     ctx->batch_graphs.clear();
     for (auto & g : ctx->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; }

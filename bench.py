@@ -6,8 +6,8 @@ synthetic weights / synthetic prompts (no checkpoints offline), n_steps_text_enc
 6 fine passes, 384 frames = 5.12 s of audio per prompt.
 
   N = 1 (BASELINE config 2): a "step" = one bark_generate_audio call (single prompt, hipGraph decode).  The line also carries
-        `config5_64_prompts`: the 64-prompt job of config 5 on this one GPU (lock-step batches of 32), i.e. the N = 1 point of the
-        multi-GPU curve.
+        `config5_64_prompts`: the 64-prompt job of config 5 on this one GPU (ONE lock-step job on 64 slots), i.e. the N = 1 point of the
+        multi-GPU curve, and `config5_ragged`, the same prompts with step caps 64 .. 256 by prompt length.
   N > 1 (BASELINE config 5): a "step" = the 64-prompt synthetic batch, sorted by length and split statically 64 / N per rank; every
         rank runs bark_hip_generate_batch (lock-step decode) on its shard - no collective inside an utterance - then the sample
         counts are all-gathered and the PCM is gathered on rank 0 (RCCL over xGMI; edge collectives only).  Total work is fixed, so
@@ -384,6 +384,25 @@ def main():
                                      "slots": min(64, len(prompts)), "step_caps": "64..256 by prompt length (bench.ragged_caps), mean %.0f" % (sum(caps) / len(caps)),
                                      "stage_ms": {k: str_["t_%s_us" % k] / 1e3 for k in ("semantic", "coarse", "fine", "codec")},
                                      "parity": "tests/test_gpu_batch_ragged.py (randomised ragged jobs against the oracle; 16 of these 64 utterances against committed oracle outputs)"}
+            # the request collector under load: 256 requests of the same shape at once from 16 host threads, jobs of up to 64, TWO job streams
+            # (bark_hip_batcher_create_ex: a second worker on a clone of the context - two decode chains share the chip)
+            try:
+                import threading
+                col = pkg.Batcher(bctx, max_batch=64, max_wait_ms=20, streams=2)
+                def client(k, n):
+                    for t in [col.submit(prompts[i % len(prompts)]) for i in range(k, n, 16)]:
+                        col.wait(t)
+                for n_req in (128, 256):                                 # first pass: warm-up (the clone, its graphs)
+                    th = [threading.Thread(target=client, args=(k, n_req)) for k in range(16)]
+                    tb = time.perf_counter()
+                    for t in th: t.start()
+                    for t in th: t.join()
+                    dtc = time.perf_counter() - tb
+                out["config5_request_collector"] = {"requests": 256, "job_streams": 2, "max_batch": 64, "requests_per_s": 256 / dtc, "wall_ms": dtc * 1e3,
+                                                    "note": "native request collector (batcher.hip) in front of the lock-step jobs; one job stream: profiles/r04_batcher_load.txt"}
+                col.free()
+            except Exception as e:      # noqa: BLE001
+                out["config5_request_collector"] = {"error": str(e)}
             bctx.free()
         except Exception as e:      # noqa: BLE001
             out["config5_64_prompts"] = {"error": str(e)}

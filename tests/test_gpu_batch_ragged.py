@@ -127,6 +127,26 @@ def test_job_tail_on_a_second_stream_equals_the_one_stream_job(toy_model, monkey
             _exact(f"utterance {i} {k}", a[k], b[k])
     for k in ("n_sample_semantic", "n_sample_coarse", "n_sample_fine", "n_frames", "n_samples"):
         assert stats[0][k] == stats[1][k] and stats[0][k] > 0, (k, stats[0][k], stats[1][k])
+    # the helper's clone replays captured fine passes that bake the pick and its temperature: after bark_hip_set_params on the job's context a job
+    # without per-utterance parameters must see the new ones there too (same seeds, fresh contexts as the reference)
+    monkeypatch.setenv("BARK_HIP_TAIL_STREAM", "1")
+    seeds = list(range(40, 46))
+    ctx = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=20), 0)
+    ctx.reserve_batch(8)
+    got = [ctx.generate_batch(texts[:6], seeds=seeds)]
+    ctx.set_params(pkg.default_params(temp=0.0, fine_temp=0.5, n_steps_text_encoder=20))
+    got.append(ctx.generate_batch(texts[:6], seeds=seeds))
+    ctx.set_params(pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=20))
+    got.append(ctx.generate_batch(texts[:6], seeds=seeds))
+    ctx.free()
+    for j, ft in enumerate((0.0, 0.5, 0.0)):
+        fresh = pkg.BarkContext.load_model(toy_model, pkg.default_params(temp=0.0, fine_temp=ft, n_steps_text_encoder=20), 0)
+        ref = fresh.generate_batch(texts[:6], seeds=seeds)
+        fresh.free()
+        for i, (a, b) in enumerate(zip(got[j], ref)):
+            for k in ("fine", "pcm"):
+                _exact(f"job {j} (fine_temp {ft}) utterance {i} {k}", a[k], b[k])
+    assert any(not np.array_equal(a["fine"], b["fine"]) for a, b in zip(got[0], got[1])), "the sampled fine stage should differ from the greedy one"
 
 
 @pytest.mark.slow
