@@ -527,8 +527,8 @@ struct JobTail {
     float saved_fine_temp = 0.0f;
 
     JobTail(bark_context * job, std::vector<Utt> & utts, bool second_stream) : c(job), t(job), us(utts) {
-        if (second_stream) {
-            if (!c->tail) {
+        if (second_stream && !c->tail) {
+            try {
                 c->tail = engine_clone(c, 0);
                 // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever
                 // a CU frees up), optionally confined to a part of the chip (BARK_HIP_TAIL_CUS = n: a CU mask of the first n CUs)
@@ -547,7 +547,15 @@ struct JobTail {
                         HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
                     }
                 }
+            } catch (const std::exception & e) {
+                // e.g. no memory for a second set of caches and scratch: the job keeps its tail on its own stream (said once)
+                static bool said = false;
+                if (!said) { fprintf(stderr, "bark-hip: no second stream for the tail of lock-step jobs (%s)\n", e.what()); said = true; }
+                delete c->tail; c->tail = nullptr;
+                second_stream = false;
             }
+        }
+        if (second_stream) {
             t = c->tail;
             // its captured fine passes bake the fine temperature (bark_hip_set_params on the job's context drops them too: engine_invalidate_graphs)
             if (t->params.fine_temp != c->params.fine_temp) drop_fine_graphs_of(t);
