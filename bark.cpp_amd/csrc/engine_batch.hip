@@ -746,12 +746,12 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         }
         std::vector<int> slot_utt;                                  // slot -> utterance, a compact range [0, active)
         std::vector<std::vector<int32_t>> prompts((size_t) n);
+        std::vector<int32_t> ids_all;                               // the slots' ids at a poll at which somebody retires: one copy for all of them
         auto retire = [&](int slot, const StepState & st) {
             Utt & u = us[(size_t) slot_utt[(size_t) slot]];
             const int keep = std::min(st.eos_step, u.cap);
             auto & out = c->batch_results[(size_t) slot_utt[(size_t) slot]].semantic;
-            out.resize((size_t) keep);
-            if (keep) copy_to_host(c, out.data(), bb.out_tokens + (size_t) slot * 2048, (size_t) keep * 4);
+            out.assign(ids_all.begin() + (long) slot * 2048, ids_all.begin() + (long) slot * 2048 + keep);
             const int n_used = st.eos_step == INT32_MAX ? u.cap : std::min(u.cap, st.eos_step + 1);
             c->stats.n_sample_semantic += n_used;
             if (u.rp.temp > 0.0f) u.rng.discard(2ull * (unsigned long long) n_used);        // as consume_uniforms()
@@ -801,7 +801,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             std::vector<StepState> st = get_slot_states(c, B);
             for (auto & v : st) if (v.fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
             // retire from the back so that a move never touches a slot that is still to be looked at
-            bool moved = false;
+            bool moved = false, any_done = false;
+            for (int b = 0; b < B; b++) any_done = any_done || !(st[(size_t) b].eos_step == INT32_MAX && us[(size_t) slot_utt[(size_t) b]].issued < us[(size_t) slot_utt[(size_t) b]].cap);
+            if (any_done) { ids_all.resize((size_t) B * 2048); copy_to_host(c, ids_all.data(), bb.out_tokens, ids_all.size() * 4); }
             for (int b = B - 1; b >= 0; b--) {
                 const Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].eos_step == INT32_MAX && u.issued < u.cap) continue;
@@ -892,6 +894,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 if ((int) ins[(size_t) b].size() + max_here - 1 > m.hp.block_size) throw std::runtime_error("coarse: a lock-step window exceeds the context of a slot (history + sliding window too long for a batch)");
             int lock_steps = max_here - 1;                               // batched steps after every slot has its first sample
             std::vector<int> pf_slots, pf_L, pf_step; std::vector<const std::vector<int32_t> *> pf_ids;
+            // states of the slots that continue with a decode step: uploaded without a host synchronisation per slot - the staging vector lives until
+            // get_slot_states() below has synchronised the stream (64 slots x 13 windows of 25 us round trips otherwise)
+            std::vector<StepState> stage_st((size_t) B);
             for (int b = 0; b < B; b++) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 const auto & in = ins[(size_t) b];
@@ -899,8 +904,9 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 c->stats.n_prefix_rows_reused += L;
                 if ((int) in.size() - L == 1) {
                     // the prompt is the cached sequence plus one token: a decode step (prefix reuse, see engine_coarse)
-                    StepState st1 = fresh_state(); st1.step = u.step_idx; st1.n_past = L; st1.cur_token = in[(size_t) L];
-                    set_slot_state(c, b, st1);
+                    StepState & st1 = stage_st[(size_t) b];
+                    st1 = fresh_state(); st1.step = u.step_idx; st1.n_past = L; st1.cur_token = in[(size_t) L];
+                    HIP_OK(hipMemcpyAsync(bb.state + b, &st1, sizeof(StepState), hipMemcpyHostToDevice, c->stream));
                     embed_slot(c, s, b);
                     if (!all_single) enqueue_batch_step(c, s, 1, slot_view(c, s, b));      // mixed window: this slot alone, eagerly
                 } else if (prefill_many && !m.q4 && !m.w32) {
@@ -914,12 +920,15 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             // a slot whose last window is shorter than the others' keeps stepping to the end of the window (its further ids are discarded;
             // window prompt + sliding_window_size rows fit the context by the check above, as every window is even the parity stays shared)
             for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
+            // the window's ids of all slots in ONE copy (rows of 2048 per slot, 512 KB at 64 slots), enqueued in front of the states' copy whose
+            // synchronisation covers both
+            std::vector<int32_t> ids_all((size_t) B * 2048);
+            HIP_OK(hipMemcpyAsync(ids_all.data(), bb.out_tokens, ids_all.size() * 4, hipMemcpyDeviceToHost, c->stream));
             const std::vector<StepState> st = get_slot_states(c, B);
             for (int b = 0; b < B; b++) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
-                std::vector<int32_t> got((size_t) here[(size_t) b]);
-                copy_to_host(c, got.data(), bb.out_tokens + (size_t) b * 2048, got.size() * 4);
+                const std::vector<int32_t> got(ids_all.begin() + (long) b * 2048, ids_all.begin() + (long) b * 2048 + here[(size_t) b]);
                 u.coarse_out.insert(u.coarse_out.end(), got.begin(), got.end());
                 // rows now in the slot's cache: its prompt and every token fed back (steps past `here` wrote further rows, but those are
                 // never matched because the ids are not recorded)
