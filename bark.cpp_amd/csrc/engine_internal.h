@@ -66,7 +66,12 @@ bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool 
 // seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
                      const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0, const SeqTab * seqtab = nullptr);
-void run_layers_decode(bark_context * c, GptModel & m);
+void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_head_nw = nullptr);
+// BARK_HIP_WPREFETCH (opt-in experiment, default 0): 1 / 2 = every decode kernel of a single-utterance step asks for the weight rows of the
+// kernel one / two places behind it (NextWeights, kernels.h); BARK_HIP_WPREFETCH_STRIDE (bytes between touched words, default 128),
+// BARK_HIP_WPREFETCH_EARLY=1 (ask before the own operands have arrived instead of after)
+int weight_prefetch_mode();
+NextWeights next_weights(const half_t * W, int rows, int K, int rows_per_wg);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);
 StepState get_state(bark_context * c);

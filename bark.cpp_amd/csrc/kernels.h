@@ -56,6 +56,12 @@ struct TraceSink { unsigned long long * rec = nullptr; unsigned * pos = nullptr;
 // of every activation, continue its cache (utterance slot `slot`) at position pos0; rows len .. seq - 1 are padding
 struct SeqTab { int slot, pos0, len, pad; };
 
+// Opt-in experiment (BARK_HIP_WPREFETCH, engine.hip: plan_weight_prefetch): a decode kernel asks for the weight rows a LATER kernel of the
+// step will stream, so that they wait in the XCD's L2 when that kernel starts.  Consumer workgroup j reads the wg_bytes at base + j wg_bytes
+// and runs on XCD j % 8 (round-robin dispatch), so the producer workgroups of XCD x touch the slices of the consumers j % 8 == x: one dword
+// per `stride` bytes, results discarded.  Results cannot change (loads only); default off until measured on the device.
+struct NextWeights { const void * base = nullptr; unsigned wg_bytes = 0, n_wg = 0, stride = 128; int early = 0; };
+
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_QKV16 = 4 };      // EPI_QKV16: tolerance route only (fast_kernels.hip)
 
 // One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
@@ -108,6 +114,7 @@ struct LinArgs {
     // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's - or, with seqtab, position seqtab[z].pos0 + n % seq of the
     // cache of slot seqtab[z].slot (rows at or beyond seqtab[z].len are padding and store nothing)
     const SeqTab * seqtab = nullptr;
+    NextWeights nw;                       // decode GEMVs (N == 1, f16 weights) only
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
@@ -148,6 +155,7 @@ struct AttnDecodeArgs {
     const float * ps = nullptr;           // [H][4][P] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     float * sc = nullptr;                  // lock-step batches: [nbatch][H][P] scores between attn_slots_scores_kernel and attn_slots_mix_kernel (nullptr: attn_fused_kernel)
+    NextWeights nw;                        // attn_ps_kernel only
     BARK_TRACE_FIELD
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);      // a.ps set: attn_ps_kernel; otherwise attn_fused_kernel (one workgroup per head and slot)

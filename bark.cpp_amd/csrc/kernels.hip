@@ -54,7 +54,8 @@ void kernel_fail(const char * fmt, ...) {
 // The operands the first loads need (weight / input pointers, row count, row window) are explicit leading kernel parameters: built
 // with -amdgpu-kernarg-preload-count the hardware delivers them in SGPRs at wave launch, so the weight stream is requested without
 // the ~0.2 us kernel-argument round trip the in-kernel time line shows in front of every kernel; the struct carries the rest.
-template <int NBLK>
+// NW (opt-in, BARK_HIP_WPREFETCH): the wave also touches the weight rows a later kernel of the step will stream (NextWeights, kernels.h)
+template <int NBLK, bool NW>
 __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W, const half_t * __restrict__ x_f16, const int M, const int parity_rows, const LinArgs a) {
     TRACE_T0();
     TRACE_T1(M);
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
     for (int i = 0; i < NBLK; i++) { wv[i] = ld_half8_w(wrow + (i << 7)); xv[i] = ld_half8(xrow + (i << 7)); }
     __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
+    [[maybe_unused]] unsigned nw_sink = 0;
+    if constexpr (NW) { if (a.nw.early) prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink); }
     float acc = 0.0f;
     #pragma unroll
     for (int i = 0; i < NBLK; i++) {
@@ -81,8 +84,10 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
         for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
     }
     TRACE_T2(acc);
+    if constexpr (NW) { if (!a.nw.early) prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink, acc); }      // own operands have landed: nothing of this wave queues behind the requests
     acc = wave_xor_add16(acc);
     if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
+    if constexpr (NW) prefetch_sink_hold(nw_sink);
     TRACE_END(a.tr);
 }
 
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
 // 4 H q-workgroups of this launch, 64 bytes per key each, requested together with the weights.
 // Leading parameters = what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel): every stream of this kernel -
 // weights, the f32 row, LayerNorm parameters, the K quads of the partial scores - is requested before the argument struct is read.
-template <int NBLK, bool LNB, bool PS>
+template <int NBLK, bool LNB, bool PS, bool NW>
 __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restrict__ W, const float * __restrict__ x_f32, const float * __restrict__ ln_g,
                                                          const float * __restrict__ ln_b, const float * __restrict__ kc, const StepState * __restrict__ st, const int M,
                                                          const int parity_rows, const int E, const int kpc, const LinArgs a) {
@@ -165,6 +170,8 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
     __builtin_amdgcn_sched_barrier(0);                        // everything above goes out on the preloaded arguments alone
     EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     if (PS || a.epi == EPI_QKV) pre.n_past = n_past_now;      // same value epilogue_prefetch reads through the struct (that load is dead now)
+    [[maybe_unused]] unsigned nw_sink = 0;
+    if constexpr (NW) { if (a.nw.early) prefetch_next_weights(a.nw, tid, 256, nw_sink); }
     // (a copy whose keys are not in the context yet runs to the end and stores nothing: leaving early would put the arrival of the
     // context length in front of the LayerNorm; the host launches only the copies the context bound needs)
     if (wave == 0) {
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
         for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
     }
     TRACE_T2(acc);
+    if constexpr (NW) { if (!a.nw.early) prefetch_next_weights(a.nw, tid, 256, nw_sink, acc); }
     acc = wave_xor_add16(acc);
     if (live && c == 0 && !copy) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (PS) {
@@ -218,15 +226,16 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
             if (tid + 256 < kpc && j + 256 < pre.n_past) a.ps[((size_t) hq * 4 + blk) * a.P + j + 256] = score_block_f4(kq[1], qb);
         }
     }
+    if constexpr (NW) prefetch_sink_hold(nw_sink);
 #ifdef BARK_TRACE
     trace_emit(a.tr, _tr0, _tr1, _tr2, trace_clock(), stamp_a, stamp_b);
 #endif
 }
 
-template <int NBLK>
+template <int NBLK, bool NW>
 static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
     if (!a.x_f32) {
-        hipLaunchKernelGGL((gemv_kernel<NBLK>), dim3((a.M + 3) / 4), dim3(64), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
+        hipLaunchKernelGGL((gemv_kernel<NBLK, NW>), dim3((a.M + 3) / 4), dim3(64), 0, s, a.W, a.x_f16, a.M, a.parity_rows, a);
         return;
     }
     if constexpr (NBLK <= 8) {
@@ -240,11 +249,11 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
             const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));      // a copy scores at most 512 keys (two per thread)
             const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;                 // 256, 384 or 512
             const dim3 gps(n_main + n_copy * n_q);
-            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
-            else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
+            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, true, NW>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
+            else        hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, true, NW>), gps, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, kpc, a);
         }
-        else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
-        else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
+        else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, true, false, NW>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
+        else             hipLaunchKernelGGL((gemv_ln_wg_kernel<NBLK, false, false, NW>), g16, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, kc, a.st, a.M, a.parity_rows, a.E, 0, a);
     } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
 }
 
@@ -781,14 +790,14 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     }
     if (a.N == 1) {
         switch (nblk) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
-            case 1:  launch_gemv_n<1>(s, a); break;
-            case 2:  launch_gemv_n<2>(s, a); break;
-            case 4:  launch_gemv_n<4>(s, a); break;
-            case 6:  launch_gemv_n<6>(s, a); break;
-            case 8:  launch_gemv_n<8>(s, a); break;
-            case 16: launch_gemv_n<16>(s, a); break;
-            case 24: launch_gemv_n<24>(s, a); break;
-            case 32: launch_gemv_n<32>(s, a); break;
+            case 1: a.nw.base ? launch_gemv_n<1, true>(s, a) : launch_gemv_n<1, false>(s, a); break;
+            case 2: a.nw.base ? launch_gemv_n<2, true>(s, a) : launch_gemv_n<2, false>(s, a); break;
+            case 4: a.nw.base ? launch_gemv_n<4, true>(s, a) : launch_gemv_n<4, false>(s, a); break;
+            case 6: a.nw.base ? launch_gemv_n<6, true>(s, a) : launch_gemv_n<6, false>(s, a); break;
+            case 8: a.nw.base ? launch_gemv_n<8, true>(s, a) : launch_gemv_n<8, false>(s, a); break;
+            case 16: a.nw.base ? launch_gemv_n<16, true>(s, a) : launch_gemv_n<16, false>(s, a); break;
+            case 24: a.nw.base ? launch_gemv_n<24, true>(s, a) : launch_gemv_n<24, false>(s, a); break;
+            case 32: a.nw.base ? launch_gemv_n<32, true>(s, a) : launch_gemv_n<32, false>(s, a); break;
             default: kernel_fail("bark-hip: unsupported K=%d in decode GEMV", a.K);
         }
         return;
