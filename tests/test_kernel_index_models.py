@@ -160,3 +160,61 @@ def test_attention_rank_order_keeps_a_head_on_one_xcd():
             assert 0 <= r % QT < QT
         share = max(1, n // 8)                                             # consecutive ranks one XCD holds
         assert len(owner) == H * Z and all(len(v) <= QT // share + 2 for v in owner.values())
+
+
+# ---- opt-in weight prefetch (NextWeights, kernels.h; prefetch_next_weights, device_utils.h; the plan in engine.hip) -------------------------
+def _prefetch_touches(G, n_threads, n_wg, wg_bytes, stride, skip_tid=0):
+    """prefetch_next_weights restated: producer workgroup i of a launch of G workgroups (XCD i % 8) walks the consumer slices j = x + 8 s of its
+    XCD, s = i / 8, i / 8 + np, ...; thread t touches byte offsets t stride, (t + n_threads) stride, ... of a slice.  Returns
+    {consumer j: (producer XCDs that touched it, sorted byte offsets)}."""
+    out = {}
+    for i in range(G):
+        x, np_ = i & 7, (G - (i & 7) + 7) >> 3
+        s = i >> 3
+        while x + 8 * s < n_wg:
+            j = x + 8 * s
+            xs, offs = out.setdefault(j, (set(), []))
+            xs.add(x)
+            for t in range(n_threads):
+                off = t * stride
+                while off < wg_bytes:
+                    offs.append(off)
+                    off += n_threads * stride
+            s += np_
+    return out
+
+
+def test_weight_prefetch_covers_every_consumer_slice_once_on_its_own_xcd():
+    """Every consumer workgroup's slice is touched exactly once per `stride` bytes, by producers of the consumer's own XCD (j % 8), for the
+    producer / consumer geometries of a bark-small and a bark-large decode step and a few awkward ones."""
+    E = 768
+    cases = []
+    for E in (768, 1024, 128):
+        qkv_main = 3 * E // 16
+        gemv4 = lambda M: (M + 3) // 4
+        ln16 = lambda M: (M + 15) // 16
+        attn_grid = 8 * 16 * ((E // 64 + 7) // 8)
+        producers = {"qkv": (qkv_main + 2 * (E // 16), 256), "attn": (attn_grid, 1024), "attn_late": (attn_grid, 1024 - 64), "proj": (gemv4(E), 64), "fc": (ln16(4 * E), 256),
+                     "mproj": (gemv4(E), 64), "head": (ln16(10048), 256)}
+        consumers = {"proj": (E // 4, 4 * E * 2), "fc": (4 * E // 16, 16 * E * 2), "mproj": (E // 4, 4 * 4 * E * 2), "qkv": (3 * E // 16, 16 * E * 2),
+                     "head": (10048 // 16, 16 * E * 2), "coarse_head_both_windows": (2048 // 16, 16 * E * 2)}
+        for pn, (G, nt) in producers.items():
+            for cn, (n_wg, wg_bytes) in consumers.items():
+                cases.append((G, nt, n_wg, wg_bytes))
+    cases += [(5, 64, 19, 1000), (192, 64, 3, 6144), (9, 256, 64, 128)]
+    seen = set()
+    for G, nt, n_wg, wg_bytes in cases:
+        for stride in (64, 128, 256):
+            key = (G, nt, n_wg, wg_bytes, stride)
+            if key in seen:
+                continue
+            seen.add(key)
+            got = _prefetch_touches(G, nt, n_wg, wg_bytes, stride)
+            # every slice whose XCD holds at least one producer is covered; with fewer than 8 producers the other XCDs' slices stay cold
+            for j in range(n_wg):
+                if (j & 7) >= G:
+                    assert j not in got
+                    continue
+                xs, offs = got[j]
+                assert xs == {j & 7}, (key, j, xs)
+                assert sorted(offs) == list(range(0, wg_bytes, stride)), (key, j)
