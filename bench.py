@@ -157,6 +157,54 @@ def cpu_baseline_leg(model_path: str, prompt: str, n_semantic: int) -> dict:
                                    "fine": ref["t_predict_fine_us"] / 1000.0 / max(1, ref["n_sample_fine"])}}
 
 
+EXPERIMENT_CHILD = r"""
+import sys, json, time, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from bark_amd_loader import load_package
+pkg = load_package()
+ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=%d), 0)
+texts = %r
+assert ctx.generate_audio(texts[0])
+h = hashlib.sha256()
+t0 = time.perf_counter(); audio = 0.0
+for t in texts[1:]:
+    assert ctx.generate_audio(t)
+    audio += ctx.stats()["n_samples"] / 24000.0
+    for a in (ctx.semantic_tokens(), ctx.coarse_tokens(), ctx.fine_tokens(), ctx.audio_data()):
+        h.update(np.ascontiguousarray(a).tobytes())
+dt = time.perf_counter() - t0
+st = ctx.stats()
+print("RESULT " + json.dumps({"rtf": audio / dt, "sha256_ids_and_pcm": h.hexdigest(), "decode_step_us": {str(c): round(ctx.time_decode_step(0, c, 400)[0], 2) for c in (300, 640)},
+                              "semantic_ms_per_token": st["t_semantic_us"] / 1000.0 / max(1, st["n_sample_semantic"])}))
+ctx.free()
+"""
+
+
+def experiments_leg(path: str, texts, n_semantic: int) -> dict:
+    """Opt-in switches that are off by default because they have not been measured yet, each in a process of its own (the switches are read
+    once per process) on the headline workload: RTF, decode-step time, and whether the ids and the PCM equal the default arm's bit for bit.
+    Reported BESIDE the headline, never instead of it.  BARK_HIP_WPREFETCH: DESIGN.md section 8 item 9."""
+    import subprocess
+    arms = {"default": {}, "wprefetch_1": {"BARK_HIP_WPREFETCH": "1"}, "wprefetch_2": {"BARK_HIP_WPREFETCH": "2"},
+            "wprefetch_2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"}}
+    out = {}
+    for name, env_add in arms.items():
+        env = dict(os.environ); env.update(env_add)
+        try:
+            p = subprocess.run([sys.executable, "-c", EXPERIMENT_CHILD % (ROOT, path, n_semantic, list(texts))], env=env, capture_output=True, text=True, timeout=180)
+            line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+            out[name] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": str(e)}
+    ref = out.get("default", {}).get("sha256_ids_and_pcm")
+    for name, r in out.items():
+        if "sha256_ids_and_pcm" in r:
+            r["bits_equal_to_the_default_arm"] = bool(ref) and r.pop("sha256_ids_and_pcm") == ref
+    out["note"] = "opt-in, default off; arms run as separate processes of the same build on the same prompts (first prompt untimed)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +218,7 @@ def main():
     ap.add_argument("--no-q4", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the bark-large leg (BASELINE config 3)")
     ap.add_argument("--no-fast", action="store_true", help="skip the tolerance-route leg (BARK_HIP_FAST_GEMM=1)")
+    ap.add_argument("--no-experiments", action="store_true", help="skip the A/B of the opt-in, not yet measured switches (separate processes)")
     ap.add_argument("--no-roofline-legs", action="store_true", help="skip the kernel timing legs (rocprofv3 passes: the statistics then hold the prompts' kernels only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the --n-prompts job split over the ranks (BASELINE config 5); weak = --n-prompts per rank")
@@ -501,6 +550,11 @@ def main():
             qctx.free()
         except Exception as e:      # noqa: BLE001
             out["q4_0"] = {"error": str(e)}
+    if not a.no_experiments:
+        try:
+            out["opt_in_experiments"] = experiments_leg(path, [prompts[k % len(prompts)] for k in range(3)], a.n_semantic)
+        except Exception as e:      # noqa: BLE001
+            out["opt_in_experiments"] = {"error": str(e)}
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(path, prompts[a.warmup % len(prompts)], a.n_semantic)
     print(json.dumps(out))
