@@ -192,7 +192,7 @@ def experiments_leg(path: str, texts, n_semantic: int) -> dict:
     for name, env_add in arms.items():
         env = dict(os.environ); env.update(env_add)
         try:
-            p = subprocess.run([sys.executable, "-c", EXPERIMENT_CHILD % (ROOT, path, n_semantic, list(texts))], env=env, capture_output=True, text=True, timeout=180)
+            p = subprocess.run([sys.executable, "-c", EXPERIMENT_CHILD % (ROOT, path, n_semantic, list(texts))], env=env, capture_output=True, text=True, timeout=60)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
             out[name] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
         except Exception as e:      # noqa: BLE001
