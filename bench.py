@@ -187,7 +187,9 @@ def experiments_leg(path: str, texts, n_semantic: int) -> dict:
     Reported BESIDE the headline, never instead of it.  BARK_HIP_WPREFETCH: DESIGN.md section 8 item 9."""
     import subprocess
     arms = {"default": {}, "wprefetch_1": {"BARK_HIP_WPREFETCH": "1"}, "wprefetch_2": {"BARK_HIP_WPREFETCH": "2"},
-            "wprefetch_2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"}}
+            "wprefetch_2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"},
+            "wprefetch_1_stride64": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_WPREFETCH_STRIDE": "64"},
+            "wprefetch_2_stride64": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_STRIDE": "64"}}
     out = {}
     for name, env_add in arms.items():
         env = dict(os.environ); env.update(env_add)
