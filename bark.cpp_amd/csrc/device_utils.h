@@ -214,15 +214,20 @@ DEVINL float4 buf_ld_f4(const BufRsrc & r, unsigned lane_bytes, unsigned scalar_
 // `after`: a value the requests must not be scheduled in front of (the asm names it as an operand): the wave's finished dot product when
 // the requests are to follow the arrival of its own operands.
 DEVINL void prefetch_next_weights(const NextWeights & nw, unsigned tid, unsigned n_threads, unsigned & sink, float after = 0.0f) {
+    if (!nw.base) return;
     const unsigned G = gridDim.x * gridDim.y * gridDim.z;
     const unsigned i = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned x = i & 7u, np = (G - x + 7u) >> 3;           // producers of this launch on XCD x
     const unsigned step = n_threads * nw.stride;
-    for (unsigned s = i >> 3; x + 8u * s < nw.n_wg; s += np) {
-        const char * p = static_cast<const char *>(nw.base) + (size_t) (x + 8u * s) * nw.wg_bytes;
-        #pragma unroll 1
-        for (unsigned off = tid * nw.stride; off < nw.wg_bytes; off += step)
-            asm volatile("global_load_dword %0, %1, off ; NWPF" : "+v"(sink) : "v"(p + off), "v"(after));
+    const unsigned per = 1u << nw.group_shift, n_groups = nw.n_wg >> nw.group_shift;
+    const size_t pitch = nw.slice_stride ? nw.slice_stride : nw.wg_bytes;
+    for (unsigned s = i >> 3; x + 8u * s < n_groups; s += np) {
+        for (unsigned sub = 0; sub < per; sub++) {
+            const char * p = static_cast<const char *>(nw.base) + (size_t) (((x + 8u * s) << nw.group_shift) + sub) * pitch;
+            #pragma unroll 1
+            for (unsigned off = tid * nw.stride; off < nw.wg_bytes; off += step)
+                asm volatile("global_load_dword %0, %1, off ; NWPF" : "+v"(sink) : "v"(p + off), "v"(after));
+        }
     }
 }
 DEVINL void prefetch_sink_hold(unsigned sink) { asm volatile("; NWPF hold %0" :: "v"(sink)); }

@@ -124,6 +124,18 @@ NextWeights next_weights(const half_t * W, int rows, int K, int rows_per_wg) {
     return nw;
 }
 
+NextWeights next_k_quads(const float * k_layer, int E, int P, int ng) {
+    static const int on = getenv("BARK_HIP_KPREFETCH") ? atoi(getenv("BARK_HIP_KPREFETCH")) : 0;
+    NextWeights nw;
+    // q workgroup w (16 rows of q = one C2 block of one head) and its copies run on XCD w % 8 when the main workgroups (3 E / 16) and the q
+    // workgroups (E / 16) both come in multiples of 8 (gemv_ln_wg_kernel<PS>); its four d-quad rows are rows 4 w .. 4 w + 3 of [H * 16][P] float4
+    if (!on || !weight_prefetch_mode() || !k_layer || P != 1024 || (E / 16) % 8 != 0 || (3 * E / 16) % 8 != 0) return nw;
+    const NextWeights tmpl = next_weights(reinterpret_cast<const half_t *>(k_layer), 16, 128, 16);      // stride / early as configured
+    nw.base = k_layer; nw.wg_bytes = (unsigned) (256 * std::max(1, std::min(ng, 4)) * 16); nw.n_wg = (unsigned) (E / 4); nw.slice_stride = (unsigned) (P * 16); nw.group_shift = 2;
+    nw.stride = tmpl.stride; nw.early = tmpl.early;
+    return nw;
+}
+
 // one token through all layers; position / token come from the device-resident StepState
 void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_head_nw) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
@@ -132,19 +144,20 @@ void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_he
     const int wpf = (!m.q4 && !m.w32 && E <= 1024) ? weight_prefetch_mode() : 0;
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
-        NextWeights nw_qkv, nw_attn, nw_proj, nw_fc, nw_mproj;
+        NextWeights nw_qkv, nw_attn, nw_proj, nw_fc, nw_mproj, nw_knext;
+        const bool ps = !(crosscheck_mask() & 4) && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
         if (wpf) {
             const bool last = l + 1 == m.hp.n_layer;
             const NextWeights w_proj = next_weights(L.proj_w, E, E, 4), w_fc = next_weights(L.fc_w, 4 * E, E, 16), w_mproj = next_weights(L.mproj_w, E, 4 * E, 4);
             const NextWeights w_next = last ? (lm_head_nw ? *lm_head_nw : NextWeights{}) : next_weights(m.layers[(size_t) l + 1].attn_w, 3 * E, E, 16);
             if (wpf == 1) { nw_attn = w_proj; nw_proj = w_fc; nw_fc = w_mproj; nw_mproj = w_next; }
             else          { nw_qkv = w_proj; nw_attn = w_fc; nw_proj = w_mproj; nw_fc = w_next; }
+            if (!last && ps) nw_knext = next_k_quads(layer_k(m, l + 1), E, P, c->decode_ng);        // rides with the next layer's QKV rows
         }
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.vt = layer_vt(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
-        const bool ps = !(crosscheck_mask() & 4) && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
         if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
         a.nw = nw_qkv;
         BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 4 * (E / 4));        // room for all four copies of the q workgroups
@@ -163,12 +176,12 @@ void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_he
         LinArgs f;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
-        f.nw = nw_fc;
+        f.nw = nw_fc; if (wpf == 2) f.nw2 = nw_knext;
         BARK_TRACE_SET(c, f, (f.M + 3) / 4);
         launch_linear(s, f);
         LinArgs o;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = c->h32; else o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
-        o.nw = nw_mproj;
+        o.nw = nw_mproj; if (wpf == 1) o.nw2 = nw_knext;
         BARK_TRACE_SET(c, o, (o.M + 3) / 4);
         launch_linear(s, o);
     }
@@ -183,7 +196,10 @@ void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, i
     a.x_f32 = xrow; a.ln_g = m.lnf_g; a.ln_b = m.lnf_b; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     a.parity_rows = parity_rows; a.st = c->d_state; a.out_div = out_div;
     // opt-in experiment: the head asks for the first layer's QKV rows of the NEXT step (the sampler between them is one workgroup)
-    if (!m.q4 && !m.w32 && m.hp.n_embd <= 1024 && weight_prefetch_mode()) a.nw = next_weights(m.layers[0].attn_w, 3 * m.hp.n_embd, m.hp.n_embd, 16);
+    if (!m.q4 && !m.w32 && m.hp.n_embd <= 1024 && weight_prefetch_mode()) {
+        a.nw = next_weights(m.layers[0].attn_w, 3 * m.hp.n_embd, m.hp.n_embd, 16);
+        if (!(crosscheck_mask() & 4) && m.vtcache) a.nw2 = next_k_quads(layer_k(m, 0), m.hp.n_embd, c->P, c->decode_ng);
+    }
     BARK_TRACE_SET(c, a, (a.M + 3) / 4);
     launch_linear(c->stream, a);
 }

@@ -72,6 +72,9 @@ void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_he
 // BARK_HIP_WPREFETCH_EARLY=1 (ask before the own operands have arrived instead of after)
 int weight_prefetch_mode();
 NextWeights next_weights(const half_t * W, int rows, int K, int rows_per_wg);
+// BARK_HIP_KPREFETCH=1 (with BARK_HIP_WPREFETCH): the kernel that asks for a layer's QKV rows also asks for the K quads the partial-score copies of
+// that QKV kernel will stream (the first 256 ng keys of every d-quad row of the layer's K cache)
+NextWeights next_k_quads(const float * k_layer, int E, int P, int ng);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);
 StepState get_state(bark_context * c);

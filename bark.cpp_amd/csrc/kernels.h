@@ -60,7 +60,9 @@ struct SeqTab { int slot, pos0, len, pad; };
 // step will stream, so that they wait in the XCD's L2 when that kernel starts.  Consumer workgroup j reads the wg_bytes at base + j wg_bytes
 // and runs on XCD j % 8 (round-robin dispatch), so the producer workgroups of XCD x touch the slices of the consumers j % 8 == x: one dword
 // per `stride` bytes, results discarded.  Results cannot change (loads only); default off until measured on the device.
-struct NextWeights { const void * base = nullptr; unsigned wg_bytes = 0, n_wg = 0, stride = 128; int early = 0; };
+// Strided form (the K quads the partial-score copies of the next QKV kernel stream, BARK_HIP_KPREFETCH): slice j starts at base + j slice_stride
+// (0: wg_bytes, slices back to back) and 2^group_shift consecutive slices belong to ONE consumer workgroup, i.e. slice j sits on XCD (j >> group_shift) % 8.
+struct NextWeights { const void * base = nullptr; unsigned wg_bytes = 0, n_wg = 0, stride = 128; int early = 0; unsigned slice_stride = 0, group_shift = 0; };
 
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_QKV16 = 4 };      // EPI_QKV16: tolerance route only (fast_kernels.hip)
 
@@ -114,7 +116,7 @@ struct LinArgs {
     // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's - or, with seqtab, position seqtab[z].pos0 + n % seq of the
     // cache of slot seqtab[z].slot (rows at or beyond seqtab[z].len are padding and store nothing)
     const SeqTab * seqtab = nullptr;
-    NextWeights nw;                       // decode GEMVs (N == 1, f16 weights) only
+    NextWeights nw, nw2;                  // decode GEMVs (N == 1, f16 weights) only
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);

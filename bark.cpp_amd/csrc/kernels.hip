@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
     __builtin_amdgcn_sched_barrier(0);                    // the streams above go out on the preloaded arguments alone; the struct is read behind them
     const EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     [[maybe_unused]] unsigned nw_sink = 0;
-    if constexpr (NW) { if (a.nw.early) prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink); }
+    if constexpr (NW) { if (a.nw.early | a.nw2.early) { prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink); prefetch_next_weights(a.nw2, threadIdx.x, 64, nw_sink); } }
     float acc = 0.0f;
     #pragma unroll
     for (int i = 0; i < NBLK; i++) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void gemv_kernel(const half_t * __restrict__ W,
         for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
     }
     TRACE_T2(acc);
-    if constexpr (NW) { if (!a.nw.early) prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink, acc); }      // own operands have landed: nothing of this wave queues behind the requests
+    if constexpr (NW) { if (!(a.nw.early | a.nw2.early)) { prefetch_next_weights(a.nw, threadIdx.x, 64, nw_sink, acc); prefetch_next_weights(a.nw2, threadIdx.x, 64, nw_sink, acc); } }      // own operands have landed: nothing of this wave queues behind the requests
     acc = wave_xor_add16(acc);
     if (live && c == 0) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (NW) prefetch_sink_hold(nw_sink);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
     EpiPre pre = epilogue_prefetch(a, 0, live ? m : 0, row_off);
     if (PS || a.epi == EPI_QKV) pre.n_past = n_past_now;      // same value epilogue_prefetch reads through the struct (that load is dead now)
     [[maybe_unused]] unsigned nw_sink = 0;
-    if constexpr (NW) { if (a.nw.early) prefetch_next_weights(a.nw, tid, 256, nw_sink); }
+    if constexpr (NW) { if (a.nw.early | a.nw2.early) { prefetch_next_weights(a.nw, tid, 256, nw_sink); prefetch_next_weights(a.nw2, tid, 256, nw_sink); } }
     // (a copy whose keys are not in the context yet runs to the end and stores nothing: leaving early would put the arrival of the
     // context length in front of the LayerNorm; the host launches only the copies the context bound needs)
     if (wave == 0) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gemv_ln_wg_kernel(const half_t * __restri
         for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
     }
     TRACE_T2(acc);
-    if constexpr (NW) { if (!a.nw.early) prefetch_next_weights(a.nw, tid, 256, nw_sink, acc); }
+    if constexpr (NW) { if (!(a.nw.early | a.nw2.early)) { prefetch_next_weights(a.nw, tid, 256, nw_sink, acc); prefetch_next_weights(a.nw2, tid, 256, nw_sink, acc); } }
     acc = wave_xor_add16(acc);
     if (live && c == 0 && !copy) linear_epilogue_pre(a, 0, m, acc, pre);
     if constexpr (PS) {
@@ -790,14 +790,14 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
     }
     if (a.N == 1) {
         switch (nblk) {           // n_embd in {128, 256, 512, 768, 1024} and 4x those
-            case 1: a.nw.base ? launch_gemv_n<1, true>(s, a) : launch_gemv_n<1, false>(s, a); break;
-            case 2: a.nw.base ? launch_gemv_n<2, true>(s, a) : launch_gemv_n<2, false>(s, a); break;
-            case 4: a.nw.base ? launch_gemv_n<4, true>(s, a) : launch_gemv_n<4, false>(s, a); break;
-            case 6: a.nw.base ? launch_gemv_n<6, true>(s, a) : launch_gemv_n<6, false>(s, a); break;
-            case 8: a.nw.base ? launch_gemv_n<8, true>(s, a) : launch_gemv_n<8, false>(s, a); break;
-            case 16: a.nw.base ? launch_gemv_n<16, true>(s, a) : launch_gemv_n<16, false>(s, a); break;
-            case 24: a.nw.base ? launch_gemv_n<24, true>(s, a) : launch_gemv_n<24, false>(s, a); break;
-            case 32: a.nw.base ? launch_gemv_n<32, true>(s, a) : launch_gemv_n<32, false>(s, a); break;
+            case 1: (a.nw.base || a.nw2.base) ? launch_gemv_n<1, true>(s, a) : launch_gemv_n<1, false>(s, a); break;
+            case 2: (a.nw.base || a.nw2.base) ? launch_gemv_n<2, true>(s, a) : launch_gemv_n<2, false>(s, a); break;
+            case 4: (a.nw.base || a.nw2.base) ? launch_gemv_n<4, true>(s, a) : launch_gemv_n<4, false>(s, a); break;
+            case 6: (a.nw.base || a.nw2.base) ? launch_gemv_n<6, true>(s, a) : launch_gemv_n<6, false>(s, a); break;
+            case 8: (a.nw.base || a.nw2.base) ? launch_gemv_n<8, true>(s, a) : launch_gemv_n<8, false>(s, a); break;
+            case 16: (a.nw.base || a.nw2.base) ? launch_gemv_n<16, true>(s, a) : launch_gemv_n<16, false>(s, a); break;
+            case 24: (a.nw.base || a.nw2.base) ? launch_gemv_n<24, true>(s, a) : launch_gemv_n<24, false>(s, a); break;
+            case 32: (a.nw.base || a.nw2.base) ? launch_gemv_n<32, true>(s, a) : launch_gemv_n<32, false>(s, a); break;
             default: kernel_fail("bark-hip: unsupported K=%d in decode GEMV", a.K);
         }
         return;

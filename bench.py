@@ -189,7 +189,9 @@ def experiments_leg(path: str, texts, n_semantic: int) -> dict:
     arms = {"default": {}, "wprefetch_1": {"BARK_HIP_WPREFETCH": "1"}, "wprefetch_2": {"BARK_HIP_WPREFETCH": "2"},
             "wprefetch_2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"},
             "wprefetch_1_stride64": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_WPREFETCH_STRIDE": "64"},
-            "wprefetch_2_stride64": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_STRIDE": "64"}}
+            "wprefetch_2_stride64": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_STRIDE": "64"},
+            "wprefetch_1_kquads": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_KPREFETCH": "1"},
+            "wprefetch_2_kquads": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_KPREFETCH": "1"}}
     out = {}
     for name, env_add in arms.items():
         env = dict(os.environ); env.update(env_add)

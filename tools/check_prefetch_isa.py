@@ -61,7 +61,10 @@ def check(path):
             later = [i for i in req_idx if i > hold and re.match(r"global_load_dword v%d," % reg, code[i])]
             if later:
                 print(f"FAIL {name}: a request into v{reg} behind its hold marker"); ok = False; continue
-            rest = [code[i] for i in range(first, hold) if "NWPF" not in code[i] and names_register(code[i], reg)]
+            # a `v_mov_b32 vR, 0` inside the region is the sink's own initial value re-materialised on a path that joins behind a request site
+            # (the two sites of a kernel are alternatives): a write nobody reads - any READER of vR would be listed here and fail the check
+            rest = [code[i] for i in range(first, hold) if "NWPF" not in code[i] and names_register(code[i], reg)
+                    and not re.match(r"v_mov_b32(_e32)? v%d, 0$" % reg, code[i].split(";")[0].strip())]
             if rest:
                 print(f"FAIL {name}: v{reg} (prefetch sink) is named between its first request and its hold marker by: {rest[:4]}"); ok = False; continue
             tail = [l for l in code[hold + 1:hold + 40]]
