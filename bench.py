@@ -314,6 +314,9 @@ def main():
                 "prompts_per_s": len(prompts) * a.steps / dt,
                 "per_rank_s_per_step": {"generate": [float(x[0]) for x in all_ranks], "gather": [float(x[1]) for x in all_ranks]},
                 "roofline": None, "note": "roofline / cpu_baseline are reported by the N = 1 run (single-GPU kernels are the same)",
+                "scaling_reference": "the N = 1 point of THIS workload is `config5_64_prompts.audio_s_per_s` of the N = 1 line (the 64-prompt job on one GPU), "
+                                     "not its `value`: the N = 1 line's `value` is BASELINE config 2 (one prompt at a time, latency mode), so value(N) / (N x value(1)) "
+                                     "compares two workloads",
             }
             print(json.dumps(out))
         ctx.free()
