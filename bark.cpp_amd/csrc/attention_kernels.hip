@@ -124,6 +124,125 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Opt-in experiment (BARK_HIP_SLOT_PS, unmeasured at the end of round 4): attn_fused_kernel for lock steps whose QKV product has already formed
+// the partial scores of the cached keys (gemv_ln_slots_ps_kernel, kernels.hip: ps [slot][H][4][P]).  The workgroup of a (head, slot[, value
+// half]) then reads 16 bytes of partial scores per key instead of the key's 256 bytes of K: 92 KB instead of 246 KB through its CU at 640
+// keys with two value halves - the K stream was what the kernel's time is made of.  Scores: ((c0 + c1) + (c2 + c3)) * 0.125 over the four
+// C2 blocks = score_chain's value bit for bit; the key the step appended itself is scored here from its K row in the cache (lanes 0..3 of
+// wave 3 form the four blocks, as attn_ps_kernel does).  Softmax (C4), mix (C5) and the tree are attn_fused_kernel's, statement for statement.
+// ------------------------------------------------------------------------------------------------
+template <int VS>
+__global__ __launch_bounds__(256) void attn_fused_ps_kernel(const AttnDecodeArgs a) {
+    __shared__ float es[1024];
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    __shared__ float part[16][64];
+    __shared__ float snew;
+    const int h = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const int E = a.H * 64;
+    const float * kc = a.kc + (size_t) slot * a.kv_slot_stride, * vc = a.vc + (size_t) slot * a.kv_slot_stride;
+    const float * __restrict__ psl = a.ps + ((size_t) slot * a.H + h) * 4 * P;          // block b of key j at b * P + j
+    const int chain = 4 * wave + (lane >> 4);
+    const int vhalf = VS == 2 ? (int) blockIdx.z : 0;
+    const bool mixer = VS == 1 || (lane & 15) < 8;
+    const int d4 = VS == 2 ? 8 * vhalf + (lane & 7) : (lane & 15);
+    const float4 * vp = reinterpret_cast<const float4 *>(vc + (size_t) h * P * 64) + (size_t) chain * 16 + d4;
+    // partial scores of keys tid + 256 g: the first group lies inside the buffer for every context (stale bits beyond the context are never used)
+    float pq[4][4];
+    #pragma unroll
+    for (int b = 0; b < 4; b++) pq[0][b] = psl[b * P + tid];
+    const int ctx = a.st[slot].n_past + 1;
+    #pragma unroll
+    for (int g = 1; g < 4; g++) {
+        if (ctx > 256 * g) {
+            #pragma unroll
+            for (int b = 0; b < 4; b++) pq[g][b] = psl[b * P + tid + 256 * g];
+        }
+    }
+    float4 vv[64];
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if ((g == 0 || ctx > 256 * g) && mixer) {
+            #pragma unroll
+            for (int i = 0; i < 16; i++) vv[16 * g + i] = vp[(size_t) (16 * g + i) * 256];
+        }
+    }
+    // the key this step appended (position ctx - 1): its K row is in the cache, its partial scores are not
+    if (wave == 3) {
+        const int b = lane & 3;
+        const float * __restrict__ qh = a.q + (size_t) slot * E + h * 64;
+        const float4 * kp = reinterpret_cast<const float4 *>(kc) + ((size_t) h * 16 + 4 * b) * P + (ctx - 1);
+        float4 kq[4];
+        float qb[16];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) kq[i] = kp[(size_t) i * P];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) qb[i] = qh[16 * b + i];
+        const float cb = score_block_f4(kq, qb);
+        const float c0 = readlane_f32(cb, 0), c1 = readlane_f32(cb, 1), c2 = readlane_f32(cb, 2), c3 = readlane_f32(cb, 3);
+        if (lane == 0) snew = ((c0 + c1) + (c2 + c3)) * 0.125f;  // 1/sqrt(64), bark.cpp:1318
+    }
+    float s[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            const float v = ((pq[g][0] + pq[g][1]) + (pq[g][2] + pq[g][3])) * 0.125f;
+            if (tid + 256 * g < ctx - 1) s[g] = v;
+        }
+    }
+    __syncthreads();                                             // snew
+    #pragma unroll
+    for (int g = 0; g < 4; g++) if (tid + 256 * g == ctx - 1) s[g] = snew;
+    float mx = wave_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    double lsum = 0.0;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = tid + 256 * i;
+        float e = 0.0f;
+        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        es[j] = e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red_d[wave] = lsum;
+    __syncthreads();
+    const double sum = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+    const float inv = (float) (1.0 / sum);
+    float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    #pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g == 0 || ctx > 256 * g) {
+            float pj[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) pj[i] = es[chain + 16 * (16 * g + i)] * inv;      // p = e * (float)(1/sum), as ggml_soft_max scales in place
+            #pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool ok = chain + 16 * (16 * g + i) < ctx;
+                const float4 v = vv[16 * g + i];
+                const float tx = fmaf(v.x, pj[i], acc.x), ty = fmaf(v.y, pj[i], acc.y), tz = fmaf(v.z, pj[i], acc.z), tw = fmaf(v.w, pj[i], acc.w);
+                acc.x = ok ? tx : acc.x; acc.y = ok ? ty : acc.y; acc.z = ok ? tz : acc.z; acc.w = ok ? tw : acc.w;
+            }
+        }
+    }
+    if (mixer) *reinterpret_cast<float4 *>(&part[chain][4 * d4]) = acc;
+    __syncthreads();
+    if (tid < 64 / VS) {
+        const int d = VS == 2 ? 32 * vhalf + tid : tid;
+        float p[16];
+        #pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = part[c][d];
+        #pragma unroll
+        for (int st = 1; st < 16; st <<= 1)
+            #pragma unroll
+            for (int c = 0; c < 16; c += 2 * st) p[c] = p[c] + p[c + st];
+        if (a.att32) a.att32[(size_t) slot * E + h * 64 + d] = p[0]; else a.att[(size_t) slot * E + h * 64 + d] = to_half(p[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decode attention on partial scores.  The QKV kernel of the step (gemv_ln_wg_kernel<PS>) has already formed, for every cached key,
 // the four 16-d block sums of C2; this kernel adds them ((c0 + c1) + (c2 + c3)) * 0.125, scores the ONE key the step appended
 // itself (from the fixed-address copy of its K row, so that those loads do not wait for the context length), and runs softmax + mix
@@ -366,6 +485,14 @@ __global__ __launch_bounds__(256) void attn_slots_mix_kernel(const AttnDecodeArg
 }
 
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
+    if (a.ps && a.nbatch > 1) {
+        // opt-in experiment (BARK_HIP_SLOT_PS): lock step at few slots, partial scores per slot from gemv_ln_slots_ps_kernel
+        if (a.P != 1024 || a.knew || a.vt) kernel_fail("bark-hip: the lock-step partial-score attention takes block_size 1024 and the slots' own caches");
+        static const int n_cu2 = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+        if (2 * a.H * a.nbatch <= n_cu2 && !(crosscheck_mask() & 32)) hipLaunchKernelGGL((attn_fused_ps_kernel<2>), dim3(a.H, a.nbatch, 2), dim3(256), 0, s, a);
+        else                                                            hipLaunchKernelGGL((attn_fused_ps_kernel<1>), dim3(a.H, a.nbatch), dim3(256), 0, s, a);
+        return;
+    }
     if (a.ps) {
         if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: partial-score decode attention needs one sequence and block_size 1024"); }
         if (!a.knew) kernel_fail("bark-hip: partial-score decode attention needs the fixed-address copy of the appended K row");

@@ -30,6 +30,14 @@ namespace {
 
 constexpr int kMaxSlots = 64;                            // lock-step slots of a context (KV caches of both causal models per slot: 151 MB at bark-small)
 
+// BARK_HIP_SLOT_PS=<n> (opt-in experiment, default 0, unmeasured at the end of round 4): lock steps over 2 .. n live slots (f16 files, block_size 1024)
+// run their QKV product per slot as the single-utterance step does - LayerNorm per workgroup, partial scores of the cached keys formed where q is
+// born (gemv_ln_slots_ps_kernel) - and the attention on those scores (attn_fused_ps_kernel) instead of streaming every pair's K through one CU
+int slot_ps_max() {
+    static const int v = [] { const char * e = getenv("BARK_HIP_SLOT_PS"); const int n = e ? atoi(e) : 0; return n >= 2 && n <= kMaxSlots ? n : 0; }();
+    return v;
+}
+
 void ensure_batch(bark_context * c, int B) {
     bark_context::Batch & bb = c->batch;
     if (bb.cap >= B) return;
@@ -54,6 +62,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
     bb.u = dev_alloc<double>(c, (size_t) B * 8192);
     bb.sc = dev_alloc<float>(c, (size_t) B * c->max_H * c->P);
+    if (slot_ps_max() > 0) bb.ps = dev_alloc<float>(c, (size_t) B * c->max_H * 4 * c->P);
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.slot_par = dev_alloc<float>(c, (size_t) 2 * B);               // [0, B): temperatures, [B, 2 B): min_eos_p
     c->h_slot_par.assign((size_t) 2 * B, 0.0f);
@@ -136,6 +145,8 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.ln_stats = nullptr;
         launch_linear_slots(st, a);
     };
+    // opt-in experiment: QKV per slot with partial scores + attention on them (see slot_ps_max)
+    const bool slot_ps = bb.ps && B >= 2 && B <= slot_ps_max() && !m.q4 && !m.w32 && P == 1024 && E <= 1024 && (E & 127) == 0;
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
@@ -144,12 +155,14 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
-        product(a, L.ln1_g, L.ln1_b);
+        if (slot_ps) { a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = nullptr; a.ps = bb.ps; launch_linear_slots_ps(st, a); }
+        else product(a, L.ln1_g, L.ln1_b);
         mark("ln1+qkv");
         AttnDecodeArgs at;
         at.q = bb.q; at.kc = kl; at.vc = vl; at.H = H; at.P = P; at.st = bb.state; at.att = bb.att;
         at.nbatch = B; at.kv_slot_stride = slot; at.att32 = m.q4 ? bb.att32 : nullptr;
         at.sc = bb.sc;
+        if (slot_ps) at.ps = bb.ps;
         launch_attn_decode(st, at);
         mark("attention");
         LinArgs p;

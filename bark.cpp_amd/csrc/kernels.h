@@ -123,6 +123,9 @@ void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
 void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel; x_f32 + ln_g: the LayerNorm of the rows fused (when linear_slots_fuses_ln(K))
 bool linear_slots_fuses_ln(int K);
+// opt-in experiment (BARK_HIP_SLOT_PS): the QKV product of a lock step at few slots per slot as in the single-utterance step, forming the partial scores
+// of the cached keys (a.ps: [nbatch][H][4][P]) that attn_fused_ps_kernel finishes; a.x_f32 [nbatch][K] + LayerNorm, batched EPI_QKV epilogue
+void launch_linear_slots_ps(hipStream_t s, const LinArgs & a);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {

@@ -257,6 +257,139 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
     } else { kernel_fail("bark-hip: LayerNorm-fused GEMV supports n_embd <= 1024"); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Opt-in experiment (BARK_HIP_SLOT_PS, unmeasured at the end of round 4): the QKV product of a lock step at FEW slots as gemv_ln_wg_kernel<PS>
+// with a slot dimension (blockIdx.y).  At 8 slots a lock step is a latency chain whose longest link is the attention: one workgroup per
+// (head, slot, value half) pulls the pair's whole K (164 KB at 640 keys) through one CU to form scores.  The single-utterance step does not:
+// the workgroup that produces 16 consecutive q values also forms that C2 block's partial score against every cached key, spread over the
+// q workgroups' copies.  This kernel does the same per slot: slot b's workgroups normalise ITS row, read the same weight rows (from the XCD's L2
+// after the first slot: ids congruent mod 8 share it, grid.x is a multiple of 8), write q / K / V of slot b through the batched epilogue and the
+// partial scores to ps + b * H * 4 * P; attn_fused_ps_kernel (attention_kernels.hip) finishes them.  Same arithmetic per element as
+// gemv_ln_wg_kernel (C6 LayerNorm, C1 chains, C2 blocks): bit-equal to the lock step's gemm_slots16_kernel + attn_fused_kernel route.
+// A copy whose keys lie beyond its slot's context leaves once the context length has arrived (the lock step's graph is captured for any context,
+// so copies for all 1024 keys are launched).
+// ------------------------------------------------------------------------------------------------
+template <int NBLK, bool LNB>
+__global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __restrict__ W, const float * __restrict__ X, const float * __restrict__ ln_g,
+                                                               const float * __restrict__ ln_b, const float * __restrict__ kc0, const StepState * __restrict__ st0, const int M,
+                                                               const int E, const int kpc, const LinArgs a) {
+    constexpr int K = NBLK * 128;
+    constexpr int EPT = K / 64;
+    __shared__ __attribute__((aligned(16))) half_t xs[K];
+    __shared__ float qs[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, rg = lane >> 4;
+    const int slot = blockIdx.y;
+    const float * __restrict__ x_f32 = X + (size_t) slot * K;
+    const StepState * __restrict__ st = st0 + slot;
+    const float * __restrict__ kc = kc0 + (size_t) slot * a.kv_slot_stride;
+    const int n_main = (M + 15) >> 4, n_q = E >> 4;
+    const bool copy = (int) blockIdx.x >= n_main;
+    const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
+    const int wg = copy ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
+    const int m = (wg * 4 + wave) * 4 + rg;
+    const bool live = m < M;
+    const half_t * wrow = W + (size_t) (live ? m : 0) * K + (c << 3);
+    float xv[EPT], gv[EPT], bv[EPT];
+    if (wave == 0) {
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) xv[i] = x_f32[lane + 64 * i];
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            gv[i] = ln_g[lane + 64 * i];
+            if constexpr (LNB) bv[i] = ln_b[lane + 64 * i]; else bv[i] = 0.0f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    half8 wv[NBLK];
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++) wv[b] = ld_half8_w(wrow + (b << 7));
+    float4 kq[2][4];
+    const int m0 = wg * 16;
+    const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
+    const int n_past = st->n_past;
+    __builtin_amdgcn_sched_barrier(0);
+    if (copy && rep * kpc >= n_past) return;                      // uniform per workgroup: none of this copy's keys is cached yet
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, 0);       // batched: bias, the slot's context length
+    if (wave == 0) {
+        // ggml_norm (+mul, +add) exactly as gemv_ln_wg_kernel: double sums in four partial chains per lane, Markstein division by the row length
+        double p1[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) p1[i & 3] += (double) xv[i];
+        const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        const float mean = (float) div_by_const<K>(s1);
+        double p2[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; p2[i & 3] += (double) (xv[i] * xv[i]); }
+        const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+        const float var = (float) div_by_const<K>(s2);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            float v = xv[i] * scale;
+            v = v * gv[i];
+            if constexpr (LNB) v = v + bv[i];
+            xs[lane + 64 * i] = to_half(v);
+        }
+    }
+    __syncthreads();
+    if (copy) {
+        const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // P == 1024
+        #pragma unroll
+        for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);
+        if (tid + 256 < kpc) {
+            #pragma unroll
+            for (int i = 0; i < 4; i++) kq[1][i] = buf_ld_f4(kr, (unsigned) tid * 16u + 4096u, (unsigned) i * 16384u);
+        }
+    }
+    float acc = 0.0f;
+    #pragma unroll
+    for (int b = 0; b < NBLK; b++) {
+        const half8 xh = *reinterpret_cast<const half8 *>(xs + ((b * 16 + c) << 3));
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0 && !copy) linear_epilogue_pre(a, slot, m, acc, pre);
+    // the copies cover the keys below (copies per q block) x kpc; a launch whose bound on the context was too small must not pass silently
+    if (blockIdx.x == 0 && tid == 0 && n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;
+    if (copy) {                                                  // uniform per workgroup
+        if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
+        __syncthreads();
+        float qb[16];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) qb[i] = qs[i];
+        float * __restrict__ psl = a.ps + (size_t) slot * (size_t) (E >> 6) * 4 * a.P + ((size_t) hq * 4 + blk) * a.P;
+        const int j = rep * kpc + tid;
+        if (j < n_past) psl[j] = score_block_f4(kq[0], qb);
+        if (tid + 256 < kpc && j + 256 < n_past) psl[j + 256] = score_block_f4(kq[1], qb);
+    }
+}
+
+template <int NBLK>
+static void launch_slots_ps_n(hipStream_t s, const LinArgs & a) {
+    if constexpr (NBLK <= 8) {
+        const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
+        // the lock step's graph serves every context: copies for all 1024 keys, two per q block of 512 keys each (as the single-utterance launch at ng = 4)
+        const int n_copy = 2, kpc = 512;
+        const dim3 grid(n_main + n_copy * n_q, a.nbatch), b256(256);
+        if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+        else        hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+    } else { kernel_fail("bark-hip: the per-slot partial-score QKV product supports n_embd <= 1024"); }
+}
+void launch_linear_slots_ps(hipStream_t s, const LinArgs & a) {
+    if (!a.batched || !a.x_f32 || !a.ln_g || !a.W || a.wq.qs || a.epi != EPI_QKV || !a.ps || a.P != 1024 || a.M != 3 * a.E || a.K != a.E || (a.E & 127) != 0 || a.knew || a.vt || a.parity_rows || !a.st)
+        kernel_fail("bark-hip: the per-slot partial-score QKV product takes f32 rows + LayerNorm, f16 weights, block_size 1024 and n_embd %% 128 == 0");
+    switch (a.K >> 7) {
+        case 1: launch_slots_ps_n<1>(s, a); break;
+        case 2: launch_slots_ps_n<2>(s, a); break;
+        case 4: launch_slots_ps_n<4>(s, a); break;
+        case 6: launch_slots_ps_n<6>(s, a); break;
+        case 8: launch_slots_ps_n<8>(s, a); break;
+        default: kernel_fail("bark-hip: unsupported K=%d in the per-slot partial-score QKV product", a.K);
+    }
+}
+
 // Batched decode GEMV (several utterances in lock step): grid.y walks the sequence slots, BPW slots per wave.
 // The weight rows of a workgroup column are read from HBM once (same XCD L2 for every grid.y: grid.x is a multiple
 // of 8) and each slot's dot product is the same C1 chain as in gemv_kernel, so results do not depend on the batch.

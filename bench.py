@@ -181,6 +181,58 @@ ctx.free()
 """
 
 
+EXPERIMENT_JOB_CHILD = r"""
+import sys, json, time, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from bark_amd_loader import load_package
+pkg = load_package()
+ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=%d), 0)
+slots, texts = %d, %r
+ctx.reserve_batch(slots)
+res = ctx.generate_batch(texts)                      # warm-up: graphs, allocations
+t0 = time.perf_counter()
+res = ctx.generate_batch(texts)
+dt = time.perf_counter() - t0
+h = hashlib.sha256()
+for r in res:
+    assert r is not None
+    for k in ("semantic", "coarse", "fine", "pcm"):
+        h.update(np.ascontiguousarray(r[k]).tobytes())
+st = ctx.stats()
+print("RESULT " + json.dumps({"slots": slots, "prompts": len(texts), "prompts_per_s": len(texts) / dt, "sha256_ids_and_pcm": h.hexdigest(),
+                              "stage_ms": {k: st["t_%%s_us" %% k] / 1e3 for k in ("semantic", "coarse", "fine", "codec")}}))
+ctx.free()
+"""
+
+
+def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
+    """Opt-in, not yet measured switches of the lock-step path, each arm a process of its own: a job of 3 x slots prompts on 8 / 16 slots (the
+    per-GPU share of config 5 at N = 8 / N = 4), prompts/s and bit-equality with the default arm of the same slot count.
+    BARK_HIP_SLOT_PS: per-slot QKV with partial scores + attention on them (engine_batch.hip: slot_ps_max)."""
+    import subprocess
+    out = {}
+    for slots in (8, 16):
+        texts = [prompts[i % len(prompts)] for i in range(3 * slots)]
+        ref = None
+        for name, env_add in (("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(slots)})):
+            env = dict(os.environ); env.update(env_add)
+            key = "%s_%d_slots" % (name, slots)
+            try:
+                p = subprocess.run([sys.executable, "-c", EXPERIMENT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts)], env=env, capture_output=True, text=True, timeout=90)
+                line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+                out[key] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+            except Exception as e:      # noqa: BLE001
+                out[key] = {"error": str(e)}
+            sha = out[key].pop("sha256_ids_and_pcm", None)
+            if name == "default":
+                ref = sha
+            elif sha is not None:
+                out[key]["bits_equal_to_the_default_arm"] = bool(ref) and sha == ref
+    out["note"] = "opt-in, default off; 3 x slots prompts as one job on a context with that many slots, second run timed"
+    return out
+
+
 def experiments_leg(path: str, texts, n_semantic: int) -> dict:
     """Opt-in switches that are off by default because they have not been measured yet, each in a process of its own (the switches are read
     once per process) on the headline workload: RTF, decode-step time, and whether the ids and the PCM equal the default arm's bit for bit.
@@ -560,6 +612,8 @@ def main():
     if not a.no_experiments:
         try:
             out["opt_in_experiments"] = experiments_leg(path, [prompts[k % len(prompts)] for k in range(3)], a.n_semantic)
+            if not a.no_batched:
+                out["opt_in_experiments"]["lock_step_jobs"] = job_experiments_leg(path, prompts, a.n_semantic)
         except Exception as e:      # noqa: BLE001
             out["opt_in_experiments"] = {"error": str(e)}
     if not a.no_cpu_baseline:
