@@ -38,6 +38,13 @@ int slot_ps_max() {
     return v;
 }
 
+// BARK_HIP_SLOT_GEMV=<n> (second opt-in experiment, default 0): lock steps over 2 .. n live slots run the FC product per slot on the VALU with the
+// LayerNorm in the workgroup (gemv_ln_slots_ps_kernel<PS = false>) instead of gemm_slots16_kernel<LNF> - a timing question only, same C1 / C6 bits
+int slot_gemv_max() {
+    static const int v = [] { const char * e = getenv("BARK_HIP_SLOT_GEMV"); const int n = e ? atoi(e) : 0; return n >= 2 && n <= kMaxSlots ? n : 0; }();
+    return v;
+}
+
 void ensure_batch(bark_context * c, int B) {
     bark_context::Batch & bb = c->batch;
     if (bb.cap >= B) return;
@@ -175,7 +182,8 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
-        product(f, L.ln2_g, L.ln2_b);
+        if (B >= 2 && B <= slot_gemv_max() && !m.q4 && !m.w32 && E <= 1024 && (E & 127) == 0) { f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_stats = nullptr; f.E = E; launch_linear_slots_ps(st, f); }
+        else product(f, L.ln2_g, L.ln2_b);
         mark("ln2+fc+gelu");
         LinArgs o;
         o.batched = 1; o.nbatch = B;

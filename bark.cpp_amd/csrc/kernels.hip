@@ -269,7 +269,9 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
 // A copy whose keys lie beyond its slot's context leaves once the context length has arrived (the lock step's graph is captured for any context,
 // so copies for all 1024 keys are launched).
 // ------------------------------------------------------------------------------------------------
-template <int NBLK, bool LNB>
+// PS = false (BARK_HIP_SLOT_GEMV, a second experiment): the same per-slot LayerNorm-fused product without copies and partial scores, for the FC
+// product of a lock step at few slots (any batched epilogue) - to be timed against gemm_slots16_kernel<LNF>.
+template <int NBLK, bool LNB, bool PS>
 __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __restrict__ W, const float * __restrict__ X, const float * __restrict__ ln_g,
                                                                const float * __restrict__ ln_b, const float * __restrict__ kc0, const StepState * __restrict__ st0, const int M,
                                                                const int E, const int kpc, const LinArgs a) {
@@ -283,9 +285,9 @@ __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __
     const float * __restrict__ x_f32 = X + (size_t) slot * K;
     const StepState * __restrict__ st = st0 + slot;
     const float * __restrict__ kc = kc0 + (size_t) slot * a.kv_slot_stride;
-    const int n_main = (M + 15) >> 4, n_q = E >> 4;
-    const bool copy = (int) blockIdx.x >= n_main;
-    const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
+    [[maybe_unused]] const int n_main = (M + 15) >> 4, n_q = PS ? E >> 4 : 1;
+    const bool copy = PS && (int) blockIdx.x >= n_main;
+    [[maybe_unused]] const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
     const int wg = copy ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
     const int m = (wg * 4 + wave) * 4 + rg;
     const bool live = m < M;
@@ -304,12 +306,13 @@ __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __
     half8 wv[NBLK];
     #pragma unroll
     for (int b = 0; b < NBLK; b++) wv[b] = ld_half8_w(wrow + (b << 7));
-    float4 kq[2][4];
-    const int m0 = wg * 16;
-    const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
-    const int n_past = st->n_past;
+    [[maybe_unused]] float4 kq[2][4];
+    [[maybe_unused]] const int m0 = wg * 16;
+    [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
+    [[maybe_unused]] int n_past = 0;
+    if constexpr (PS) n_past = st->n_past;
     __builtin_amdgcn_sched_barrier(0);
-    if (copy && rep * kpc >= n_past) return;                      // uniform per workgroup: none of this copy's keys is cached yet
+    if constexpr (PS) { if (copy && rep * kpc >= n_past) return; }      // uniform per workgroup: none of this copy's keys is cached yet
     const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, 0);       // batched: bias, the slot's context length
     if (wave == 0) {
         // ggml_norm (+mul, +add) exactly as gemv_ln_wg_kernel: double sums in four partial chains per lane, Markstein division by the row length
@@ -333,13 +336,15 @@ __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __
         }
     }
     __syncthreads();
-    if (copy) {
-        const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // P == 1024
-        #pragma unroll
-        for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);
-        if (tid + 256 < kpc) {
+    if constexpr (PS) {
+        if (copy) {
+            const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // P == 1024
             #pragma unroll
-            for (int i = 0; i < 4; i++) kq[1][i] = buf_ld_f4(kr, (unsigned) tid * 16u + 4096u, (unsigned) i * 16384u);
+            for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);
+            if (tid + 256 < kpc) {
+                #pragma unroll
+                for (int i = 0; i < 4; i++) kq[1][i] = buf_ld_f4(kr, (unsigned) tid * 16u + 4096u, (unsigned) i * 16384u);
+            }
         }
     }
     float acc = 0.0f;
@@ -351,18 +356,20 @@ __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __
     }
     acc = wave_xor_add16(acc);
     if (live && c == 0 && !copy) linear_epilogue_pre(a, slot, m, acc, pre);
-    // the copies cover the keys below (copies per q block) x kpc; a launch whose bound on the context was too small must not pass silently
-    if (blockIdx.x == 0 && tid == 0 && n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;
-    if (copy) {                                                  // uniform per workgroup
-        if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
-        __syncthreads();
-        float qb[16];
-        #pragma unroll
-        for (int i = 0; i < 16; i++) qb[i] = qs[i];
-        float * __restrict__ psl = a.ps + (size_t) slot * (size_t) (E >> 6) * 4 * a.P + ((size_t) hq * 4 + blk) * a.P;
-        const int j = rep * kpc + tid;
-        if (j < n_past) psl[j] = score_block_f4(kq[0], qb);
-        if (tid + 256 < kpc && j + 256 < n_past) psl[j + 256] = score_block_f4(kq[1], qb);
+    if constexpr (PS) {
+        // the copies cover the keys below (copies per q block) x kpc; a launch whose bound on the context was too small must not pass silently
+        if (blockIdx.x == 0 && tid == 0 && n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;
+        if (copy) {                                              // uniform per workgroup
+            if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
+            __syncthreads();
+            float qb[16];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) qb[i] = qs[i];
+            float * __restrict__ psl = a.ps + (size_t) slot * (size_t) (E >> 6) * 4 * a.P + ((size_t) hq * 4 + blk) * a.P;
+            const int j = rep * kpc + tid;
+            if (j < n_past) psl[j] = score_block_f4(kq[0], qb);
+            if (tid + 256 < kpc && j + 256 < n_past) psl[j + 256] = score_block_f4(kq[1], qb);
+        }
     }
 }
 
@@ -373,13 +380,21 @@ static void launch_slots_ps_n(hipStream_t s, const LinArgs & a) {
         // the lock step's graph serves every context: copies for all 1024 keys, two per q block of 512 keys each (as the single-utterance launch at ng = 4)
         const int n_copy = 2, kpc = 512;
         const dim3 grid(n_main + n_copy * n_q, a.nbatch), b256(256);
-        if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
-        else        hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+        if (!a.ps) {
+            const dim3 g0(n_main, a.nbatch);
+            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a);
+            else        hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a);
+        }
+        else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+        else             hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
     } else { kernel_fail("bark-hip: the per-slot partial-score QKV product supports n_embd <= 1024"); }
 }
 void launch_linear_slots_ps(hipStream_t s, const LinArgs & a) {
-    if (!a.batched || !a.x_f32 || !a.ln_g || !a.W || a.wq.qs || a.epi != EPI_QKV || !a.ps || a.P != 1024 || a.M != 3 * a.E || a.K != a.E || (a.E & 127) != 0 || a.knew || a.vt || a.parity_rows || !a.st)
-        kernel_fail("bark-hip: the per-slot partial-score QKV product takes f32 rows + LayerNorm, f16 weights, block_size 1024 and n_embd %% 128 == 0");
+    if (!a.batched || !a.x_f32 || !a.ln_g || !a.W || a.wq.qs || (a.K & 127) != 0 || a.knew || a.vt || a.parity_rows)
+        kernel_fail("bark-hip: the per-slot LayerNorm-fused product takes f32 rows + LayerNorm and f16 weights, K %% 128 == 0");
+    if (a.ps && (a.epi != EPI_QKV || a.P != 1024 || a.M != 3 * a.E || a.K != a.E || !a.st))
+        kernel_fail("bark-hip: the per-slot partial-score QKV product needs block_size 1024");
+    if (a.epi == EPI_QKV && !a.st) kernel_fail("bark-hip: a QKV product needs the slots' states");
     switch (a.K >> 7) {
         case 1: launch_slots_ps_n<1>(s, a); break;
         case 2: launch_slots_ps_n<2>(s, a); break;

@@ -209,13 +209,15 @@ ctx.free()
 def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
     """Opt-in, not yet measured switches of the lock-step path, each arm a process of its own: a job of 3 x slots prompts on 8 / 16 slots (the
     per-GPU share of config 5 at N = 8 / N = 4), prompts/s and bit-equality with the default arm of the same slot count.
-    BARK_HIP_SLOT_PS: per-slot QKV with partial scores + attention on them (engine_batch.hip: slot_ps_max)."""
+    BARK_HIP_SLOT_PS: per-slot QKV with partial scores + attention on them (engine_batch.hip: slot_ps_max); BARK_HIP_SLOT_GEMV: the FC product
+    per slot on the VALU as well (slot_gemv_max)."""
     import subprocess
     out = {}
     for slots in (8, 16):
         texts = [prompts[i % len(prompts)] for i in range(3 * slots)]
         ref = None
-        for name, env_add in (("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(slots)})):
+        for name, env_add in (("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(slots)}),
+                              ("slot_ps_and_gemv", {"BARK_HIP_SLOT_PS": str(slots), "BARK_HIP_SLOT_GEMV": str(slots)})):
             env = dict(os.environ); env.update(env_add)
             key = "%s_%d_slots" % (name, slots)
             try:
