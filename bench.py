@@ -188,11 +188,15 @@ import numpy as np
 from bark_amd_loader import load_package
 pkg = load_package()
 ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=%d), 0)
-slots, texts = %d, %r
+slots, texts, ragged = %d, %r, %d
 ctx.reserve_batch(slots)
-res = ctx.generate_batch(texts)                      # warm-up: graphs, allocations
+reqs = None
+if ragged:
+    import bench
+    reqs = [ctx.request_params(n_steps_text_encoder=c) for c in bench.ragged_caps(texts)]
+res = ctx.generate_batch(texts, params=reqs)         # warm-up: graphs, allocations
 t0 = time.perf_counter()
-res = ctx.generate_batch(texts)
+res = ctx.generate_batch(texts, params=reqs)
 dt = time.perf_counter() - t0
 h = hashlib.sha256()
 for r in res:
@@ -213,15 +217,19 @@ def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
     per slot on the VALU as well (slot_gemv_max)."""
     import subprocess
     out = {}
-    for slots in (8, 16):
-        texts = [prompts[i % len(prompts)] for i in range(3 * slots)]
+    for slots, ragged in ((8, 0), (16, 0), (64, 1)):
+        # 3 x slots equal prompts on 8 / 16 slots; on 64 slots the ragged form of config 5 (caps 64 .. 256 by prompt length: the live slot count falls
+        # through 16 .. 2 in the job's tail, where the experimental route takes over)
+        texts = list(prompts) if ragged else [prompts[i % len(prompts)] for i in range(3 * slots)]
         ref = None
-        for name, env_add in (("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(slots)}),
-                              ("slot_ps_and_gemv", {"BARK_HIP_SLOT_PS": str(slots), "BARK_HIP_SLOT_GEMV": str(slots)})):
+        arms = [("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(min(slots, 16))})]
+        if not ragged:
+            arms.append(("slot_ps_and_gemv", {"BARK_HIP_SLOT_PS": str(slots), "BARK_HIP_SLOT_GEMV": str(slots)}))
+        for name, env_add in arms:
             env = dict(os.environ); env.update(env_add)
-            key = "%s_%d_slots" % (name, slots)
+            key = "%s_%d_slots%s" % (name, slots, "_ragged" if ragged else "")
             try:
-                p = subprocess.run([sys.executable, "-c", EXPERIMENT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts)], env=env, capture_output=True, text=True, timeout=90)
+                p = subprocess.run([sys.executable, "-c", EXPERIMENT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts, ragged)], env=env, capture_output=True, text=True, timeout=90)
                 line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
                 out[key] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
             except Exception as e:      # noqa: BLE001
