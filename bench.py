@@ -210,7 +210,7 @@ ctx.free()
 """
 
 
-def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
+def job_experiments_leg(path: str, prompts, n_semantic: int, deadline: float = float("inf")) -> dict:
     """Opt-in, not yet measured switches of the lock-step path, each arm a process of its own: a job of 3 x slots prompts on 8 / 16 slots (the
     per-GPU share of config 5 at N = 8 / N = 4), prompts/s and bit-equality with the default arm of the same slot count.
     BARK_HIP_SLOT_PS: per-slot QKV with partial scores + attention on them (engine_batch.hip: slot_ps_max); BARK_HIP_SLOT_GEMV: the FC product
@@ -228,6 +228,9 @@ def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
         for name, env_add in arms:
             env = dict(os.environ); env.update(env_add)
             key = "%s_%d_slots%s" % (name, slots, "_ragged" if ragged else "")
+            if time.perf_counter() > deadline:
+                out[key] = {"skipped": "time budget of the experiment legs used up"}
+                continue
             try:
                 p = subprocess.run([sys.executable, "-c", EXPERIMENT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts, ragged)], env=env, capture_output=True, text=True, timeout=90)
                 line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
@@ -243,7 +246,7 @@ def job_experiments_leg(path: str, prompts, n_semantic: int) -> dict:
     return out
 
 
-def experiments_leg(path: str, texts, n_semantic: int) -> dict:
+def experiments_leg(path: str, texts, n_semantic: int, deadline: float = float("inf")) -> dict:
     """Opt-in switches that are off by default because they have not been measured yet, each in a process of its own (the switches are read
     once per process) on the headline workload: RTF, decode-step time, and whether the ids and the PCM equal the default arm's bit for bit.
     Reported BESIDE the headline, never instead of it.  BARK_HIP_WPREFETCH: DESIGN.md section 8 item 9."""
@@ -257,6 +260,9 @@ def experiments_leg(path: str, texts, n_semantic: int) -> dict:
     out = {}
     for name, env_add in arms.items():
         env = dict(os.environ); env.update(env_add)
+        if time.perf_counter() > deadline:
+            out[name] = {"skipped": "time budget of the experiment legs used up"}
+            continue
         try:
             p = subprocess.run([sys.executable, "-c", EXPERIMENT_CHILD % (ROOT, path, n_semantic, list(texts))], env=env, capture_output=True, text=True, timeout=60)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
@@ -621,9 +627,11 @@ def main():
             out["q4_0"] = {"error": str(e)}
     if not a.no_experiments:
         try:
-            out["opt_in_experiments"] = experiments_leg(path, [prompts[k % len(prompts)] for k in range(3)], a.n_semantic)
+            t_exp = time.perf_counter()                          # both legs together: arms are started for at most ~2.5 minutes
+            out["opt_in_experiments"] = experiments_leg(path, [prompts[k % len(prompts)] for k in range(3)], a.n_semantic, t_exp + 75.0)
             if not a.no_batched:
-                out["opt_in_experiments"]["lock_step_jobs"] = job_experiments_leg(path, prompts, a.n_semantic)
+                out["opt_in_experiments"]["lock_step_jobs"] = job_experiments_leg(path, prompts, a.n_semantic, t_exp + 150.0)
+            out["opt_in_experiments"]["wall_s"] = time.perf_counter() - t_exp
         except Exception as e:      # noqa: BLE001
             out["opt_in_experiments"] = {"error": str(e)}
     if not a.no_cpu_baseline:
