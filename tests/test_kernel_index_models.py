@@ -245,3 +245,86 @@ def test_k_quad_prefetch_matches_the_partial_score_copies():
                         assert xs == {w & 7}, (E, ng, G, w, xs)
                         assert sorted(offs) == list(range(row * P * 16, row * P * 16 + 256 * ng * 16, 128))
                 assert set(got) <= set(range(E // 4))
+
+
+# ---- opt-in lock-step route for few slots (BARK_HIP_SLOT_PS): gemv_ln_slots_ps_kernel (kernels.hip) -> attn_fused_ps_kernel (attention_kernels.hip) ----
+def _mul32(a, b):
+    return np.float32(np.float32(a) * np.float32(b))
+
+
+def _score_block(kq4, qb):
+    """score_block_f4 (device_utils.h): one fmaf chain over the block's four d-quads x four components"""
+    acc = np.float32(0.0)
+    for i in range(4):
+        for comp in range(4):
+            acc = fma32(kq4[i][comp], qb[4 * i + comp], acc)
+    return acc
+
+
+def test_slot_partial_scores_reach_the_attention_as_the_c2_score():
+    """The address arithmetic of the two kernels restated thread by thread on a small shape (2 slots with different contexts, 2 heads, block_size
+    1024, keys beyond 512 so that both copies of a q block work): what copy workgroup (rep, q block) thread t writes to ps, and what thread t of the
+    attention workgroup (head, slot) reads back and combines, must be C2's score ((c0 + c1) + (c2 + c3)) * 0.125 of key j for every cached key -
+    and the key the step appended must be scored from its K row at position ctx - 1."""
+    rng = np.random.default_rng(5)
+    H, P, B = 2, 1024, 2
+    E = 64 * H
+    n_q, n_main, kpc, n_copy = E // 16, 3 * E // 16, 512, 2
+    ctxs = [600, 37]                                           # n_past + 1 per slot
+    stride = H * 16 * P * 4                                    # floats per slot of one layer's K cache [H][16][P][4]
+    kc = rng.standard_normal(B * stride).astype(np.float32)
+    q = rng.standard_normal((B, E)).astype(np.float32)
+    ps = np.full(B * H * 4 * P, np.nan, np.float32)
+    # --- producer: gemv_ln_slots_ps_kernel<PS = true>, the copies (blockIdx.x >= n_main), grid (n_main + n_copy n_q, B) ---
+    for slot in range(B):
+        n_past = ctxs[slot] - 1
+        for bx in range(n_main, n_main + n_copy * n_q):
+            rep, wg = (bx - n_main) // n_q, (bx - n_main) % n_q
+            if rep * kpc >= n_past:
+                continue                                       # the early exit
+            m0 = wg * 16
+            hq, blk = m0 >> 6, (m0 >> 4) & 3
+            qb = [q[slot][m0 + i] for i in range(16)]          # qs[wave * 4 + rg] = q row m0 + 4 wave + rg
+            base_f4 = slot * stride // 4 + (hq * 16 + 4 * blk) * 1024 + rep * kpc          # buf_rsrc base in float4 units
+            for tid in range(256):
+                for half in range(2):
+                    if half == 1 and not (tid + 256 < kpc):
+                        continue
+                    j = rep * kpc + tid + 256 * half
+                    if j >= n_past:
+                        continue
+                    kq = []
+                    for i in range(4):                         # buf_ld_f4(kr, tid * 16 (+ 4096), i * 16384): byte offsets
+                        byte = base_f4 * 16 + tid * 16 + 4096 * half + i * 16384
+                        kq.append(kc[byte // 4: byte // 4 + 4])
+                    ps[slot * (E >> 6) * 4 * P + (hq * 4 + blk) * P + j] = _score_block(kq, qb)
+    # --- consumer: attn_fused_ps_kernel, workgroup (h, slot), thread tid owns keys tid + 256 g ---
+    for slot in range(B):
+        ctx = ctxs[slot]
+        for h in range(H):
+            psl = (slot * H + h) * 4 * P
+            got = {}
+            for tid in range(256):
+                for g in range(4):
+                    if not (g == 0 or ctx > 256 * g):
+                        continue
+                    if tid + 256 * g < ctx - 1:
+                        p4 = [ps[psl + b * P + tid + 256 * g] for b in range(4)]
+                        got[tid + 256 * g] = _mul32(add32(add32(p4[0], p4[1]), add32(p4[2], p4[3])), 0.125)
+            # the appended key: lanes 0..3 of wave 3 form the blocks from the K row at ctx - 1
+            cb = []
+            for b in range(4):
+                kq = [kc[slot * stride + ((h * 16 + 4 * b + i) * P + (ctx - 1)) * 4: slot * stride + ((h * 16 + 4 * b + i) * P + (ctx - 1)) * 4 + 4] for i in range(4)]
+                cb.append(_score_block(kq, [q[slot][h * 64 + 16 * b + i] for i in range(16)]))
+            got[ctx - 1] = _mul32(add32(add32(cb[0], cb[1]), add32(cb[2], cb[3])), 0.125)
+            # reference: C2 on the K layout [H][16][P][4] (kc_index: ((h 16 + d / 4) P + pos) 4 + d % 4)
+            assert sorted(got) == list(range(ctx))
+            for j in range(ctx):
+                c = []
+                for b in range(4):
+                    acc = np.float32(0.0)
+                    for d in range(16 * b, 16 * b + 16):
+                        acc = fma32(kc[slot * stride + ((h * 16 + d // 4) * P + j) * 4 + d % 4], q[slot][h * 64 + d], acc)
+                    c.append(acc)
+                ref = _mul32(add32(add32(c[0], c[1]), add32(c[2], c[3])), 0.125)
+                assert got[j].tobytes() == ref.tobytes(), (slot, h, j)
