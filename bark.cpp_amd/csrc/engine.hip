@@ -286,7 +286,8 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
     // j + parity_rows / 16 share an XCD when parity_rows is a multiple of 128)
     NextWeights head_nw;
     if (weight_prefetch_mode() && !m.q4 && !m.w32 && (s.parity_rows % 128) == 0)
-        head_nw = next_weights(m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd, s.parity_rows ? s.lm_rows + s.parity_rows : s.lm_rows, m.hp.n_embd, 16);
+        head_nw = next_weights(m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd, std::min(s.parity_rows ? s.lm_rows + s.parity_rows : s.lm_rows, m.hp.n_out_vocab - s.lm_row0),
+                               m.hp.n_embd, 16);                   // never beyond the matrix
     run_layers_decode(c, m, &head_nw);
     // greedy decode step: the LM head divides by 0.7 itself (2512 waves instead of one workgroup doing 10 048 divisions)
     const bool prescale = sample && s.temp == 0.0f;
