@@ -204,8 +204,16 @@ for r in res:
     for k in ("semantic", "coarse", "fine", "pcm"):
         h.update(np.ascontiguousarray(r[k]).tobytes())
 st = ctx.stats()
-print("RESULT " + json.dumps({"slots": slots, "prompts": len(texts), "prompts_per_s": len(texts) / dt, "sha256_ids_and_pcm": h.hexdigest(),
-                              "stage_ms": {k: st["t_%%s_us" %% k] / 1e3 for k in ("semantic", "coarse", "fine", "codec")}}))
+out = {"slots": slots, "prompts": len(texts), "prompts_per_s": len(texts) / dt, "sha256_ids_and_pcm": h.hexdigest(),
+       "stage_ms": {k: st["t_%%s_us" %% k] / 1e3 for k in ("semantic", "coarse", "fine", "codec")}}
+if not ragged:
+    # where a lock step of the coarse model at context 640 spends its time under this arm: microseconds per launch site summed over the layers
+    # (kernel + the gap in front, eager launches), and the graph-replayed step
+    sites = {}
+    for r in ctx.profile_lock_step(1, slots, 640, 10):
+        sites[r["site"]] = round(sites.get(r["site"], 0.0) + r["us"], 1)
+    out["lock_step_us_by_site"] = sites
+print("RESULT " + json.dumps(out))
 ctx.free()
 """
 
