@@ -39,7 +39,8 @@ int slot_ps_max() {
 }
 
 // BARK_HIP_SLOT_GEMV=<n> (second opt-in experiment, default 0): lock steps over 2 .. n live slots run the FC product per slot on the VALU with the
-// LayerNorm in the workgroup (gemv_ln_slots_ps_kernel<PS = false>) instead of gemm_slots16_kernel<LNF> - a timing question only, same C1 / C6 bits
+// LayerNorm in the workgroup (gemv_ln_slots_ps_kernel<PS = false>) instead of gemm_slots16_kernel<LNF>, and the two out-projections as the
+// single-utterance GEMV with a slot dimension (gemv_slots_kernel) instead of gemv_batch_kernel - a timing question only, same C1 / C6 bits
 int slot_gemv_max() {
     static const int v = [] { const char * e = getenv("BARK_HIP_SLOT_GEMV"); const int n = e ? atoi(e) : 0; return n >= 2 && n <= kMaxSlots ? n : 0; }();
     return v;
@@ -175,7 +176,8 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
-        product(p, nullptr, nullptr);
+        const bool slot_gemv = B >= 2 && B <= slot_gemv_max() && !m.q4 && !m.w32;
+        if (slot_gemv) launch_linear_slots_gemv(st, p); else product(p, nullptr, nullptr);
         mark("proj");
         if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
@@ -188,7 +190,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         LinArgs o;
         o.batched = 1; o.nbatch = B;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
-        product(o, nullptr, nullptr);
+        if (slot_gemv) launch_linear_slots_gemv(st, o); else product(o, nullptr, nullptr);
         mark("mlp_proj");
     }
     if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);

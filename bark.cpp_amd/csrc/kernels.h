@@ -126,6 +126,8 @@ bool linear_slots_fuses_ln(int K);
 // opt-in experiment (BARK_HIP_SLOT_PS): the QKV product of a lock step at few slots per slot as in the single-utterance step, forming the partial scores
 // of the cached keys (a.ps: [nbatch][H][4][P]) that attn_fused_ps_kernel finishes; a.x_f32 [nbatch][K] + LayerNorm, batched EPI_QKV epilogue
 void launch_linear_slots_ps(hipStream_t s, const LinArgs & a);
+// BARK_HIP_SLOT_GEMV: the out-projections of a few-slot lock step as the single-utterance GEMV with a slot dimension (a.x_f16 [nbatch][K])
+void launch_linear_slots_gemv(hipStream_t s, const LinArgs & a);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {

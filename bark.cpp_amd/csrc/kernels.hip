@@ -373,6 +373,54 @@ __global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __
     }
 }
 
+// The plain decode GEMV (gemv_kernel: one wave = 4 output rows, every chunk of the row requested up front) with a slot dimension - the out-projections of
+// a lock step at few slots under BARK_HIP_SLOT_GEMV, to be timed against gemv_batch_kernel (two slots per wave share the weight loads).  Slot b reads
+// its f16 row X + b K and finishes through the batched epilogue; the weight rows come out of the XCD's L2 after the first slot (grid.x is a multiple of 8
+// for every bark shape).  Same C1 chains.
+template <int NBLK>
+__global__ __launch_bounds__(64) void gemv_slots_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int slot = blockIdx.y;
+    const bool live = m < M;
+    constexpr int K = NBLK * 128;
+    const half_t * wrow = W + (size_t) (live ? m : 0) * K + (c << 3);
+    const half_t * xrow = X + (size_t) slot * K + (c << 3);
+    half8 wv[NBLK], xv[NBLK];
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) { wv[i] = ld_half8_w(wrow + (i << 7)); xv[i] = ld_half8(xrow + (i << 7)); }
+    __builtin_amdgcn_sched_barrier(0);
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, 0);
+    float acc = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, slot, m, acc, pre);
+}
+template <int NBLK>
+static void launch_gemv_slots_n(hipStream_t s, const LinArgs & a) {
+    hipLaunchKernelGGL((gemv_slots_kernel<NBLK>), dim3((a.M + 3) / 4, a.nbatch), dim3(64), 0, s, a.W, a.x_f16, a.M, a);
+}
+void launch_linear_slots_gemv(hipStream_t s, const LinArgs & a) {
+    if (!a.batched || !a.x_f16 || a.x_f32 || !a.W || a.wq.qs || (a.K & 127) != 0 || a.K > 4096 || a.parity_rows || a.epi == EPI_QKV)
+        kernel_fail("bark-hip: the per-slot plain GEMV takes f16 rows, f16 weights and a residual / GELU / logits epilogue");
+    switch (a.K >> 7) {
+        case 1:  launch_gemv_slots_n<1>(s, a); break;
+        case 2:  launch_gemv_slots_n<2>(s, a); break;
+        case 4:  launch_gemv_slots_n<4>(s, a); break;
+        case 6:  launch_gemv_slots_n<6>(s, a); break;
+        case 8:  launch_gemv_slots_n<8>(s, a); break;
+        case 16: launch_gemv_slots_n<16>(s, a); break;
+        case 24: launch_gemv_slots_n<24>(s, a); break;
+        case 32: launch_gemv_slots_n<32>(s, a); break;
+        default: kernel_fail("bark-hip: unsupported K=%d in the per-slot plain GEMV", a.K);
+    }
+}
+
 template <int NBLK>
 static void launch_slots_ps_n(hipStream_t s, const LinArgs & a) {
     if constexpr (NBLK <= 8) {
