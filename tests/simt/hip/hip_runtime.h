@@ -1,0 +1,115 @@
+// A stand-in for <hip/hip_runtime.h> that lets the VALU kernels of bark.cpp_amd/csrc run on the HOST, thread for thread (tests/test_simt_emulation.py):
+// test infrastructure only - nothing of the product includes it.  One workgroup at a time, one std::thread per work-item; `__shared__` variables are
+// function-local statics (shared by the work-items of the running workgroup), __syncthreads() is a barrier that leaving work-items drop out of, and
+// the wave-wide operations the kernels use (DPP row permutations, readlane, shuffles) are rendezvous of the 64 work-items of a wave.  Floating point:
+// fmaf is the hardware FMA (-mfma), f32 <-> f16 conversions are IEEE round-to-nearest-even as on the device, -ffp-contract=off as in the product.
+#pragma once
+#include <algorithm>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x = 1, y = 1, z = 1; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct uint3_sim { unsigned x, y, z; };
+inline thread_local uint3_sim threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
+
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+
+// ---- host-API surface the launch functions of the kernel files touch (never executed here) --------------------------------------------------
+typedef struct sim_stream * hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+struct hipDeviceProp_t { int multiProcessorCount = 256; };
+inline hipError_t hipGetDevice(int * d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t * p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+#define hipLaunchKernelGGL(...) ((void) 0)
+
+// ---- the running workgroup ----------------------------------------------------------------------------------------------------------------------
+namespace sim {
+struct Wave {
+    std::barrier<> bar;
+    uint64_t slot[64];
+    explicit Wave(int n) : bar(n) {}
+};
+struct Group {
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<Wave>> waves;
+    explicit Group(int n) : bar(n) { for (int w = 0; w < (n + 63) / 64; w++) waves.emplace_back(new Wave(std::min(64, n - 64 * w))); }
+};
+inline thread_local Group * group = nullptr;
+inline thread_local int lane_id = 0;
+inline Wave & wave() { return *group->waves[threadIdx.x >> 6]; }
+// every work-item of the wave deposits `v`, then reads the deposit of work-item `from`
+inline uint64_t exchange(uint64_t v, int from) {
+    Wave & w = wave();
+    w.slot[lane_id] = v;
+    w.bar.arrive_and_wait();
+    const uint64_t r = w.slot[from & 63];
+    w.bar.arrive_and_wait();
+    return r;
+}
+inline int dpp_source(int lane, int ctrl) {
+    const int row = lane & ~15, i = lane & 15;
+    if (ctrl >= 0 && ctrl <= 0xFF) return (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);       // quad_perm
+    if (ctrl == 0x140) return row + (15 - i);                                                       // row_mirror
+    if (ctrl == 0x141) return row + (i & 8) + (7 - (i & 7));                                        // row_half_mirror
+    fprintf(stderr, "sim: unsupported DPP control 0x%x\n", ctrl); abort();
+}
+// One workgroup after the other, one thread per work-item (blocks of up to 1024 work-items, 1-D blocks as all kernels here use).
+template <typename F> void launch(dim3 grid, int block, F && body) {
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+        Group g(block);
+        std::vector<std::thread> th;
+        for (int t = 0; t < block; t++) th.emplace_back([&, t] {
+            group = &g; lane_id = t & 63;
+            threadIdx = {(unsigned) t, 0, 0}; blockIdx = {bx, by, bz}; blockDim = {(unsigned) block, 1, 1}; gridDim = {grid.x, grid.y, grid.z};
+            body();
+            // a work-item that is done no longer takes part in barriers and rendezvous (early returns are uniform per wave / workgroup in these kernels)
+            g.waves[(size_t) (t >> 6)]->bar.arrive_and_drop();
+            g.bar.arrive_and_drop();
+        });
+        for (auto & x : th) x.join();
+    }
+}
+}  // namespace sim
+
+inline void __syncthreads() { sim::group->bar.arrive_and_wait(); }
+inline int sim_update_dpp(int, int src, int ctrl, int, int, bool) { return (int) (uint32_t) sim::exchange((uint32_t) src, sim::dpp_source(sim::lane_id, ctrl)); }
+inline int sim_readlane(int v, int lane) { return (int) (uint32_t) sim::exchange((uint32_t) v, lane); }
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) sim_update_dpp(old, src, ctrl, rm, bm, bc)
+#define __builtin_amdgcn_readlane(v, lane) sim_readlane(v, lane)
+#define __builtin_amdgcn_readfirstlane(v) sim_readlane(v, 0)
+#define __builtin_amdgcn_sched_barrier(x) ((void) 0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void) 0)
+inline float __shfl_xor(float v, int mask, int = 64) { uint32_t u; memcpy(&u, &v, 4); u = (uint32_t) sim::exchange(u, sim::lane_id ^ mask); memcpy(&v, &u, 4); return v; }
+
+// v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x1_4b_f32: the kernels that use them are compiled but not run by the emulation tests
+typedef float sim_floatx16 __attribute__((ext_vector_type(16)));
+inline sim_floatx16 sim_mfma_unsupported(sim_floatx16 acc) { fprintf(stderr, "sim: matrix-core kernels are not emulated\n"); abort(); return acc; }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, x, y, z) sim_mfma_unsupported(acc)
+#define __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, x, y, z) sim_mfma_unsupported(acc)

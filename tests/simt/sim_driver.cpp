@@ -1,0 +1,95 @@
+// Host-side execution of the opt-in few-slot lock-step kernels next to the kernels they must equal, work-item for work-item (see hip/hip_runtime.h in this
+// directory and tests/test_simt_emulation.py, which builds this file against patched copies of the kernel sources).  Test infrastructure only.
+#include "kernels_sim.hip"
+#include "attention_kernels_sim.hip"
+
+namespace barkhip {
+// the other kernel files' entry points kernels.hip refers to: never reached here
+void init_quant_attributes() {}
+void init_fast_attributes() {}
+void launch_linear_q(hipStream_t, const LinArgs &) { kernel_fail("sim: quantised products are not emulated"); }
+void launch_linear_w32(hipStream_t, const LinArgs &) { kernel_fail("sim: f32 products are not emulated"); }
+void launch_linear_fast(hipStream_t, const LinArgs &) { kernel_fail("sim: matrix-core products are not emulated"); }
+}
+
+using namespace barkhip;
+
+namespace {
+template <int NBLK> void qkv_slots(const LinArgs & a, int B) {
+    const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
+    sim::launch(dim3(n_main + 2 * n_q, B), 256, [&] { gemv_ln_slots_ps_kernel<NBLK, true, true>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 512, a); });
+}
+template <int NBLK> void qkv_single(const LinArgs & a) {
+    const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
+    sim::launch(dim3(n_main + 2 * n_q), 256, [&] { gemv_ln_wg_kernel<NBLK, true, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, 512, a); });
+}
+template <int NBLK> void fc_slots(const LinArgs & a, int B) {
+    sim::launch(dim3((a.M + 15) / 16, B), 256, [&] { gemv_ln_slots_ps_kernel<NBLK, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a); });
+}
+template <int NBLK> void fc_single(const LinArgs & a) {
+    sim::launch(dim3((a.M + 15) / 16), 256, [&] { gemv_ln_wg_kernel<NBLK, true, false, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, 0, a); });
+}
+template <int NBLK> void proj_slots(const LinArgs & a, int B) {
+    sim::launch(dim3((a.M + 3) / 4, B), 64, [&] { gemv_slots_kernel<NBLK>(a.W, a.x_f16, a.M, a); });
+}
+template <int NBLK> void proj_single(const LinArgs & a) {
+    sim::launch(dim3((a.M + 3) / 4), 64, [&] { gemv_kernel<NBLK, false>(a.W, a.x_f16, a.M, 0, a); });
+}
+#define BY_NBLK(F, K, ...) switch ((K) >> 7) { case 1: F<1>(__VA_ARGS__); break; case 2: F<2>(__VA_ARGS__); break; case 4: F<4>(__VA_ARGS__); break; case 8: F<8>(__VA_ARGS__); break; default: return -1; }
+}  // namespace
+
+extern "C" {
+
+// QKV of one layer for B slots.  route 0: the experimental kernel with a slot dimension; route 1: the single-utterance kernel, slot after slot.
+// x [B][E] f32, W [3E][E] f16, kc / vc [B][stride] f32 (K [H][16][P][4], V [H][P][64]), q [B][E], ps [B][H][4][P], st [B]
+int sim_qkv(int route, const void * W, const float * x, const float * ln_g, const float * ln_b, const float * bias, float * kc, float * vc, float * q, float * ps,
+            StepState * st, int E, int B, long stride) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = 3 * E; a.K = E; a.N = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.bias = bias; a.epi = EPI_QKV; a.E = E; a.P = 1024; a.pos0 = 0;
+    if (route == 0) {
+        a.batched = 1; a.nbatch = B; a.kv_slot_stride = (size_t) stride; a.x_f32 = x; a.q = q; a.kc = kc; a.vc = vc; a.st = st; a.ps = ps;
+        BY_NBLK(qkv_slots, E, a, B)
+    } else {
+        for (int b = 0; b < B; b++) {
+            a.x_f32 = x + (size_t) b * E; a.q = q + (size_t) b * E; a.kc = kc + (size_t) b * stride; a.vc = vc + (size_t) b * stride; a.st = st + b;
+            a.ps = ps + (size_t) b * (E / 64) * 4 * 1024; a.ng = 4;
+            BY_NBLK(qkv_single, E, a)
+        }
+    }
+    return 0;
+}
+
+// decode attention of B slots at their own context lengths.  route 0: attn_fused_ps_kernel on the partial scores; route 1: attn_fused_kernel (the default lock step)
+int sim_attention(int route, int vs, const float * q, const float * kc, const float * vc, const float * ps, const StepState * st, void * att, int H, int B, long stride) {
+    AttnDecodeArgs a;
+    a.q = q; a.kc = kc; a.vc = vc; a.H = H; a.P = 1024; a.st = st; a.att = (half_t *) att; a.nbatch = B; a.kv_slot_stride = (size_t) stride;
+    if (route == 0) {
+        a.ps = ps;
+        if (vs == 2) sim::launch(dim3(H, B, 2), 256, [&] { attn_fused_ps_kernel<2>(a); }); else sim::launch(dim3(H, B), 256, [&] { attn_fused_ps_kernel<1>(a); });
+    } else {
+        if (vs == 2) sim::launch(dim3(H, B, 2), 256, [&] { attn_fused_kernel<2>(a); }); else sim::launch(dim3(H, B), 256, [&] { attn_fused_kernel<1>(a); });
+    }
+    return 0;
+}
+
+// LayerNorm + FC + GELU table for B slots: out [B][M] f16.  route 0: the per-slot kernel without copies; route 1: the single-utterance kernel per slot
+int sim_fc(int route, const void * W, const float * x, const float * ln_g, const float * ln_b, const float * bias, const uint16_t * lut, void * out, int E, int M, int B) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = M; a.K = E; a.N = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.bias = bias; a.epi = EPI_GELU; a.lut = lut; a.E = E;
+    if (route == 0) { a.batched = 1; a.nbatch = B; a.x_f32 = x; a.out_h = (half_t *) out; BY_NBLK(fc_slots, E, a, B) }
+    else for (int b = 0; b < B; b++) { a.x_f32 = x + (size_t) b * E; a.out_h = (half_t *) out + (size_t) b * M; BY_NBLK(fc_single, E, a) }
+    return 0;
+}
+
+// out-projection + residual for B slots: res [B][M] f32 updated in place, xh [B][K] f16.  route 0: gemv_slots_kernel; route 1: gemv_kernel per slot
+int sim_proj(int route, const void * W, const void * xh, const float * bias, float * res, int K, int M, int B) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = M; a.K = K; a.N = 1; a.bias = bias; a.epi = EPI_RESID;
+    if (route == 0) { a.batched = 1; a.nbatch = B; a.x_f16 = (const half_t *) xh; a.res = res; BY_NBLK(proj_slots, K, a, B) }
+    else for (int b = 0; b < B; b++) { a.x_f16 = (const half_t *) xh + (size_t) b * K; a.res = res + (size_t) b * M; BY_NBLK(proj_single, K, a) }
+    return 0;
+}
+
+int sim_state_size() { return (int) sizeof(StepState); }
+
+}  // extern "C"
