@@ -122,3 +122,61 @@ def test_slot_kernels_equal_the_kernels_they_replace(sim, E, ctxs):
             assert sim.sim_proj(route, _p(Wp), _p(xh), _p(bp), _p(r), K, E, B) == 0
             res.append(r)
         assert res[0].tobytes() == res[1].tobytes() and (res[0] != x).all()
+
+
+def test_decode_kernels_run_on_the_host_equal_the_oracle(sim):
+    """The same emulation against the ORACLE's own functions (oracle/bark_oracle.cpp: layer_norm_row, gemm_w, attention - the C6 / R1 / C1 / C2 / C4 / C5
+    statements): the LayerNorm-fused QKV kernel of a decode step (gemv_ln_wg_kernel<PS>: q, the appended K and V rows), the lock step's attention
+    (attn_fused_kernel) and the plain out-projection (gemv_kernel) as the product's source computes them, work-item for work-item on the host - a parity check
+    of the kernel SOURCE that needs no GPU (the -m gpu tests check the compiled kernels on the device)."""
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = C.CDLL(pyoracle.LIB_PATH)
+    orc.orc_test_wdot.restype = C.c_float
+    orc.orc_test_wdot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    orc.orc_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    orc.orc_test_layer_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    E, ctxs = 128, [9, 411]
+    B, H, P = len(ctxs), E // 64, 1024
+    stride = H * 16 * P * 4
+    W = (rng.standard_normal((3 * E, E)) * 0.08).astype(np.float16)
+    x = rng.standard_normal((B, E)).astype(np.float32)
+    g, b_ln = (1 + 0.1 * rng.standard_normal(E)).astype(np.float32), (0.1 * rng.standard_normal(E)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(3 * E)).astype(np.float32)
+    kc = rng.standard_normal(B * stride).astype(np.float32)
+    vc = rng.standard_normal(B * stride).astype(np.float32)
+    q = np.zeros((B, E), np.float32)
+    ps = np.zeros(B * H * 4 * P, np.float32)
+    st = _states(ctxs)
+    assert sim.sim_qkv(1, _p(W), _p(x), _p(g), _p(b_ln), _p(bias), _p(kc), _p(vc), _p(q), _p(ps), _p(st), E, B, C.c_long(stride)) == 0
+    K4 = kc.reshape(B, H, 16, P, 4)                        # [slot][head][d / 4][position][d % 4]
+    V4 = vc.reshape(B, H, P, 64)
+    for s, c in enumerate(ctxs):
+        y = np.zeros(E, np.float32)
+        orc.orc_test_layer_norm(_p(x[s]), _p(y), E, _p(g), _p(b_ln))
+        yh = y.astype(np.float16).astype(np.float32)        # R1: the activation entering a weight product is rounded to f16
+        want = np.array([np.float32(orc.orc_test_wdot(_p(W[m]), _p(yh), E)) + bias[m] for m in range(3 * E)], np.float32)
+        assert q[s].tobytes() == want[:E].tobytes(), f"slot {s}: q differs from the oracle"
+        k_row = K4[s, :, :, c - 1, :].reshape(H, 64)        # the appended row, head by head
+        v_row = V4[s, :, c - 1, :]
+        assert k_row.reshape(-1).tobytes() == want[E:2 * E].tobytes() and v_row.reshape(-1).tobytes() == want[2 * E:].tobytes(), f"slot {s}: appended K / V rows"
+    att = np.zeros((B, E), np.float16)
+    assert sim.sim_attention(1, 1, _p(q), _p(kc), _p(vc), _p(ps), _p(_states(ctxs)), _p(att), H, B, C.c_long(stride)) == 0
+    for s, c in enumerate(ctxs):
+        for h in range(H):
+            kh = np.ascontiguousarray(K4[s, h, :, :c, :].transpose(1, 0, 2).reshape(c, 64))
+            vh = np.ascontiguousarray(V4[s, h, :c, :])
+            qh = np.ascontiguousarray(q[s, 64 * h:64 * h + 64])
+            o = np.zeros(64, np.float32)
+            orc.orc_test_attention(_p(qh), _p(kh), _p(vh), 1, c, c - 1, 1, _p(o))
+            assert att[s, 64 * h:64 * h + 64].tobytes() == o.astype(np.float16).tobytes(), f"slot {s} head {h}: attention row differs from the oracle"
+    # plain out-projection + residual (gemv_kernel): C1 dot of the f16 row, bias, residual added last
+    Wp = (rng.standard_normal((E, E)) * 0.05).astype(np.float16)
+    bp = (0.1 * rng.standard_normal(E)).astype(np.float32)
+    r = x.copy()
+    assert sim.sim_proj(1, _p(Wp), _p(att), _p(bp), _p(r), E, E, B) == 0
+    for s in range(B):
+        a32 = att[s].astype(np.float32)
+        want = np.array([(np.float32(orc.orc_test_wdot(_p(Wp[m]), _p(a32), E)) + bp[m]) + x[s, m] for m in range(E)], np.float32)
+        assert r[s].tobytes() == want.tobytes(), f"slot {s}: out-projection + residual differs from the oracle"
