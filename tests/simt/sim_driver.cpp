@@ -35,6 +35,9 @@ template <int NBLK> void proj_slots(const LinArgs & a, int B) {
 template <int NBLK> void proj_single(const LinArgs & a) {
     sim::launch(dim3((a.M + 3) / 4), 64, [&] { gemv_kernel<NBLK, false>(a.W, a.x_f16, a.M, 0, a); });
 }
+template <int NBLK> void qkv_slots16(const LinArgs & a, int B) {
+    sim::launch(dim3((a.M + 15) / 16, (B + 15) / 16), 256, [&] { gemm_slots16_kernel<NBLK, true>(a.W, a.x_f16, a.M, 0, a); });
+}
 #define BY_NBLK(F, K, ...) switch ((K) >> 7) { case 1: F<1>(__VA_ARGS__); break; case 2: F<2>(__VA_ARGS__); break; case 4: F<4>(__VA_ARGS__); break; case 8: F<8>(__VA_ARGS__); break; default: return -1; }
 }  // namespace
 
@@ -46,9 +49,11 @@ int sim_qkv(int route, const void * W, const float * x, const float * ln_g, cons
             StepState * st, int E, int B, long stride) {
     LinArgs a;
     a.W = (const half_t *) W; a.M = 3 * E; a.K = E; a.N = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.bias = bias; a.epi = EPI_QKV; a.E = E; a.P = 1024; a.pos0 = 0;
-    if (route == 0) {
-        a.batched = 1; a.nbatch = B; a.kv_slot_stride = (size_t) stride; a.x_f32 = x; a.q = q; a.kc = kc; a.vc = vc; a.st = st; a.ps = ps;
-        BY_NBLK(qkv_slots, E, a, B)
+    if (route == 0 || route == 2) {
+        a.batched = 1; a.nbatch = B; a.kv_slot_stride = (size_t) stride; a.x_f32 = x; a.q = q; a.kc = kc; a.vc = vc; a.st = st;
+        if (route == 0) { a.ps = ps; BY_NBLK(qkv_slots, E, a, B) }
+        else switch (E >> 7) {                                                                 // the default lock step: matrix cores, LayerNorm fused (n_embd % 256 == 0)
+            case 2: qkv_slots16<2>(a, B); break; case 4: qkv_slots16<4>(a, B); break; case 8: qkv_slots16<8>(a, B); break; default: return -1; }
     } else {
         for (int b = 0; b < B; b++) {
             a.x_f32 = x + (size_t) b * E; a.q = q + (size_t) b * E; a.kc = kc + (size_t) b * stride; a.vc = vc + (size_t) b * stride; a.st = st + b;
@@ -87,6 +92,15 @@ int sim_proj(int route, const void * W, const void * xh, const float * bias, flo
     a.W = (const half_t *) W; a.M = M; a.K = K; a.N = 1; a.bias = bias; a.epi = EPI_RESID;
     if (route == 0) { a.batched = 1; a.nbatch = B; a.x_f16 = (const half_t *) xh; a.res = res; BY_NBLK(proj_slots, K, a, B) }
     else for (int b = 0; b < B; b++) { a.x_f16 = (const half_t *) xh + (size_t) b * K; a.res = res + (size_t) b * M; BY_NBLK(proj_single, K, a) }
+    return 0;
+}
+
+// N rows through the prefill product (gemm_kernel: persistent workgroups, C1 chains on v_mfma_f32_32x32x2_f32): out [N][M] f32 = x [N][K] f16 x W [M][K] f16 + bias
+int sim_gemm(const void * W, const void * xh, const float * bias, float * out, int N, int K, int M, int grid) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = M; a.K = K; a.N = N; a.x_f16 = (const half_t *) xh; a.bias = bias; a.epi = EPI_LOGITS; a.out = out; a.ld_out = M;
+    const int ncol = (M + 63) / 64, nrow = (N + 63) / 64;
+    sim::launch(dim3(std::min(grid, ncol * nrow)), 512, [&] { gemm_kernel(a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol)); });
     return 0;
 }
 

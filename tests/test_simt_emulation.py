@@ -87,6 +87,12 @@ def test_slot_kernels_equal_the_kernels_they_replace(sim, E, ctxs):
         out.append((q, kc, vc, ps))
     for name, a0, a1 in zip(("q", "K cache", "V cache", "partial scores"), out[0], out[1]):
         assert a0.tobytes() == a1.tobytes(), f"QKV per slot: {name} differs from the single-utterance kernel"
+    if E % 256 == 0:
+        # ... and the DEFAULT lock-step product they replace: gemm_slots16_kernel<LNF> (16 x 16 tiles on v_mfma_f32_16x16x1_4b_f32, LayerNorm in the kernel)
+        kc, vc, q16 = kc0.copy(), vc0.copy(), np.zeros((B, E), np.float32)
+        assert sim.sim_qkv(2, _p(W), _p(x), _p(g), _p(b_ln), _p(bias), _p(kc), _p(vc), _p(q16), _p(np.zeros(1, np.float32)), _p(_states(ctxs)), E, B, C.c_long(stride)) == 0
+        for name, a0, a1 in zip(("q", "K cache", "V cache"), (q16, kc, vc), out[0][:3]):
+            assert a0.tobytes() == a1.tobytes(), f"the matrix-core lock-step product: {name} differs from the per-slot kernel"
     q, kc, vc, ps = out[0]
     assert (kc != kc0).sum() == B * E and (vc != vc0).sum() == B * E          # exactly one appended row per slot
     for s, c in enumerate(ctxs):                           # every cached key of every (head, block) scored, nothing beyond
@@ -180,3 +186,24 @@ def test_decode_kernels_run_on_the_host_equal_the_oracle(sim):
         a32 = att[s].astype(np.float32)
         want = np.array([(np.float32(orc.orc_test_wdot(_p(Wp[m]), _p(a32), E)) + bp[m]) + x[s, m] for m in range(E)], np.float32)
         assert r[s].tobytes() == want.tobytes(), f"slot {s}: out-projection + residual differs from the oracle"
+
+
+def test_prefill_product_run_on_the_host_equals_the_oracle(sim):
+    """gemm_kernel (the prompt passes of the causal models: persistent workgroups, operands staged through LDS, C1 chains on v_mfma_f32_32x32x2_f32 emulated as
+    the k-ordered fmaf chains the device probes established) against the oracle's gemm_w, element by element - ragged N and M, several tiles per workgroup."""
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = C.CDLL(pyoracle.LIB_PATH)
+    orc.orc_test_wdot.restype = C.c_float
+    orc.orc_test_wdot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(21)
+    N, K, M = 70, 256, 132
+    W = (rng.standard_normal((M, K)) * 0.06).astype(np.float16)
+    xh = rng.standard_normal((N, K)).astype(np.float16)
+    bias = (0.1 * rng.standard_normal(M)).astype(np.float32)
+    out = np.zeros((N, M), np.float32)
+    assert sim.sim_gemm(_p(W), _p(xh), _p(bias), _p(out), N, K, M, 4) == 0          # 6 tiles on 4 persistent workgroups
+    for n in range(0, N, 7):
+        x32 = xh[n].astype(np.float32)
+        want = np.array([np.float32(orc.orc_test_wdot(_p(W[m]), _p(x32), K)) + bias[m] for m in range(M)], np.float32)
+        assert out[n].tobytes() == want.tobytes(), f"row {n} of the prefill product differs from the oracle"
