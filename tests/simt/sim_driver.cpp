@@ -77,6 +77,29 @@ int sim_attention(int route, int vs, const float * q, const float * kc, const fl
     return 0;
 }
 
+// The single-utterance decode step's own pair: gemv_ln_wg_kernel<PS> (with the fixed-address copy of the appended K row and the K-layout copy of V) and
+// attn_ps_kernel on its partial scores.  One sequence: x [E], caches of one layer, vt = V in the K layout [H][16][P][4]; att [E] f16
+int sim_decode_attention(const void * W, const float * x, const float * ln_g, const float * ln_b, const float * bias, float * kc, float * vc, float * vt, float * q, float * ps,
+                         float * knew, StepState * st, void * att, int E, int ng) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = 3 * E; a.K = E; a.N = 1; a.ln_g = ln_g; a.ln_b = ln_b; a.bias = bias; a.epi = EPI_QKV; a.E = E; a.P = 1024; a.pos0 = 0;
+    a.x_f32 = x; a.q = q; a.kc = kc; a.vc = vc; a.vt = vt; a.st = st; a.ps = ps; a.knew = knew; a.ng = ng;
+    // copies as launch_gemv_n sizes them (kernels.hip)
+    const int n_main = (a.M + 15) / 16, n_q = E / 16, keys = 256 * std::max(1, std::min(ng, 4));
+    const int fit = std::max(1, std::min(2, (256 - n_main) / n_q));
+    const int n_copy = std::max((keys + 511) / 512, std::min(fit, keys / 256));
+    const int kpc = ((keys + n_copy - 1) / n_copy + 127) / 128 * 128;
+    switch (E >> 7) {
+        case 1: sim::launch(dim3(n_main + n_copy * n_q), 256, [&] { gemv_ln_wg_kernel<1, true, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, kpc, a); }); break;
+        case 2: sim::launch(dim3(n_main + n_copy * n_q), 256, [&] { gemv_ln_wg_kernel<2, true, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, kpc, a); }); break;
+        default: return -1;
+    }
+    AttnDecodeArgs at;
+    at.q = q; at.kc = kc; at.vc = vc; at.H = E / 64; at.P = 1024; at.st = st; at.att = (half_t *) att; at.ps = ps; at.knew = knew; at.ng = ng; at.vt = vt;
+    sim::launch(dim3(8 * 16 * ((at.H + 7) / 8)), 1024, [&] { attn_ps_kernel<false>(at.ps, at.vt, at.st, at.knew, at.q, at.H, std::max(1, std::min(ng, 4)), at); });
+    return st->fault ? -2 : 0;
+}
+
 // LayerNorm + FC + GELU table for B slots: out [B][M] f16.  route 0: the per-slot kernel without copies; route 1: the single-utterance kernel per slot
 int sim_fc(int route, const void * W, const float * x, const float * ln_g, const float * ln_b, const float * bias, const uint16_t * lut, void * out, int E, int M, int B) {
     LinArgs a;

@@ -207,3 +207,40 @@ def test_prefill_product_run_on_the_host_equals_the_oracle(sim):
         x32 = xh[n].astype(np.float32)
         want = np.array([np.float32(orc.orc_test_wdot(_p(W[m]), _p(x32), K)) + bias[m] for m in range(M)], np.float32)
         assert out[n].tobytes() == want.tobytes(), f"row {n} of the prefill product differs from the oracle"
+
+
+@pytest.mark.parametrize("ctx", [1, 2, 300, 641])
+def test_single_utterance_decode_attention_run_on_the_host_equals_the_oracle(sim, ctx):
+    """The default decode attention of one utterance: the QKV kernel's partial scores (copies of the q workgroups sized for the launch's context bound),
+    the fixed-address copy of the appended K row, V in the K layout, and attn_ps_kernel (one 1024-thread workgroup per head and value quad) - against the
+    oracle's attention over the cache this very step extends."""
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = C.CDLL(pyoracle.LIB_PATH)
+    orc.orc_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(ctx)
+    E, P = 128, 1024
+    H = E // 64
+    n = H * 16 * P * 4
+    W = (rng.standard_normal((3 * E, E)) * 0.08).astype(np.float16)
+    x = rng.standard_normal(E).astype(np.float32)
+    g, b_ln = (1 + 0.1 * rng.standard_normal(E)).astype(np.float32), (0.1 * rng.standard_normal(E)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(3 * E)).astype(np.float32)
+    kc = rng.standard_normal(n).astype(np.float32)
+    v_rows = rng.standard_normal((H, P, 64)).astype(np.float32)           # V [H][P][64] and its copy in the K layout [H][16][P][4]
+    vc = v_rows.reshape(-1).copy()
+    vt = np.ascontiguousarray(v_rows.reshape(H, P, 16, 4).transpose(0, 2, 1, 3)).reshape(-1).copy()
+    q, ps, knew = np.zeros(E, np.float32), np.zeros(H * 4 * P, np.float32), np.zeros(E, np.float32)
+    att = np.zeros(E, np.float16)
+    st = _states([ctx])
+    ng = (ctx + 255) // 256                                               # the graph variant the stage loop would pick
+    assert sim.sim_decode_attention(_p(W), _p(x), _p(g), _p(b_ln), _p(bias), _p(kc), _p(vc), _p(vt), _p(q), _p(ps), _p(knew), _p(st), _p(att), E, ng) == 0
+    K4, V4 = kc.reshape(H, 16, P, 4), vc.reshape(H, P, 64)
+    assert np.array_equal(vt.reshape(H, 16, P, 4)[:, :, ctx - 1, :].reshape(H, 64), V4[:, ctx - 1, :])        # the appended V row reached both layouts
+    assert np.array_equal(knew.reshape(H, 64), K4[:, :, ctx - 1, :].reshape(H, 64))
+    for h in range(H):
+        kh = np.ascontiguousarray(K4[h, :, :ctx, :].transpose(1, 0, 2).reshape(ctx, 64))
+        vh = np.ascontiguousarray(V4[h, :ctx, :])
+        o = np.zeros(64, np.float32)
+        orc.orc_test_attention(_p(np.ascontiguousarray(q[64 * h:64 * h + 64])), _p(kh), _p(vh), 1, ctx, ctx - 1, 1, _p(o))
+        assert att[64 * h:64 * h + 64].tobytes() == o.astype(np.float16).tobytes(), f"head {h}: attn_ps_kernel differs from the oracle at context {ctx}"
