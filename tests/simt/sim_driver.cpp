@@ -2,14 +2,13 @@
 // directory and tests/test_simt_emulation.py, which builds this file against patched copies of the kernel sources).  Test infrastructure only.
 #include "kernels_sim.hip"
 #include "attention_kernels_sim.hip"
+#include "fast_kernels_sim.hip"
 
 namespace barkhip {
 // the other kernel files' entry points kernels.hip refers to: never reached here
 void init_quant_attributes() {}
-void init_fast_attributes() {}
 void launch_linear_q(hipStream_t, const LinArgs &) { kernel_fail("sim: quantised products are not emulated"); }
 void launch_linear_w32(hipStream_t, const LinArgs &) { kernel_fail("sim: f32 products are not emulated"); }
-void launch_linear_fast(hipStream_t, const LinArgs &) { kernel_fail("sim: matrix-core products are not emulated"); }
 }
 
 using namespace barkhip;
@@ -124,6 +123,17 @@ int sim_gemm(const void * W, const void * xh, const float * bias, float * out, i
     a.W = (const half_t *) W; a.M = M; a.K = K; a.N = N; a.x_f16 = (const half_t *) xh; a.bias = bias; a.epi = EPI_LOGITS; a.out = out; a.ld_out = M;
     const int ncol = (M + 63) / 64, nrow = (N + 63) / 64;
     sim::launch(dim3(std::min(grid, ncol * nrow)), 512, [&] { gemm_kernel(a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol)); });
+    return 0;
+}
+
+// N rows through the fine model's product (gemm_f16_tile_kernel: canonical order C1m, the f16 matrix cores' own accumulation): out [N][M] f32.  tile: 128 or 64
+int sim_gemm_f16(const void * W, const void * xh, const float * bias, float * out, int N, int K, int M, int tile) {
+    LinArgs a;
+    a.W = (const half_t *) W; a.M = M; a.K = K; a.N = N; a.x_f16 = (const half_t *) xh; a.bias = bias; a.epi = EPI_LOGITS; a.out = out; a.ld_out = M;
+    const int ncol = (M + tile - 1) / tile, nrow = (N + tile - 1) / tile, pw = xcd_panel_width(ncol * nrow, ncol);
+    if (tile == 128) sim::launch(dim3(ncol * nrow), 512, [&] { gemm_f16_tile_kernel<128, 128, 3, 4>(a, ncol, nrow, pw); });
+    else if (tile == 64) sim::launch(dim3(ncol * nrow), 256, [&] { gemm_f16_tile_kernel<64, 64, 3, 2>(a, ncol, nrow, pw); });
+    else return -1;
     return 0;
 }
 

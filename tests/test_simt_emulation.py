@@ -43,7 +43,7 @@ def sim(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("simt"))
     for name in ("kernels.h", "quant_formats.h", "device_utils.h"):
         open(os.path.join(d, name), "w").write(_patch(open(os.path.join(CSRC, name)).read()))
-    for name in ("kernels.hip", "attention_kernels.hip"):
+    for name in ("kernels.hip", "attention_kernels.hip", "fast_kernels.hip"):
         open(os.path.join(d, name.replace(".hip", "_sim.hip")), "w").write(_patch(open(os.path.join(CSRC, name)).read()))
     so = os.path.join(d, "libsim.so")
     cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-mfma", "-mf16c", "-mavx2", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", "-Wno-everything",
@@ -244,3 +244,25 @@ def test_single_utterance_decode_attention_run_on_the_host_equals_the_oracle(sim
         o = np.zeros(64, np.float32)
         orc.orc_test_attention(_p(np.ascontiguousarray(q[64 * h:64 * h + 64])), _p(kh), _p(vh), 1, ctx, ctx - 1, 1, _p(o))
         assert att[64 * h:64 * h + 64].tobytes() == o.astype(np.float16).tobytes(), f"head {h}: attn_ps_kernel differs from the oracle at context {ctx}"
+
+
+@pytest.mark.parametrize("tile,N,K,M", [(128, 130, 192, 140), (64, 70, 448, 64)])
+def test_fine_model_product_run_on_the_host_equals_the_oracle(sim, tile, N, K, M):
+    """gemm_f16_tile_kernel (the fine model's weight products: 128 x 128 / 64 x 64 tiles, operands through LDS, three register sets in flight, guarded tail of the
+    K loop) with v_mfma_f32_32x32x16_f16 emulated by the oracle's restatement of that instruction, against the oracle's own C1m product (gemm_mfma): the
+    kernel walks K in the canonical order - ascending groups of 8 per accumulator - whatever the pipeline does around it."""
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = C.CDLL(pyoracle.LIB_PATH)
+    orc.orc_test_mfma_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(K)
+    W = (rng.standard_normal((M, K)) * 0.06).astype(np.float16)
+    xh = rng.standard_normal((N, K)).astype(np.float16)
+    bias = (0.1 * rng.standard_normal(M)).astype(np.float32)
+    out = np.zeros((N, M), np.float32)
+    assert sim.sim_gemm_f16(_p(W), _p(xh), _p(bias), _p(out), N, K, M, tile) == 0
+    want = np.zeros((N, M), np.float32)
+    x32 = xh.astype(np.float32)
+    orc.orc_test_mfma_gemm(_p(W), _p(x32), M, N, K, _p(want))
+    want = (want + bias[None, :]).astype(np.float32)
+    assert out.tobytes() == want.tobytes(), "the f16 tile product differs from the oracle's C1m product"
