@@ -266,3 +266,56 @@ def test_fine_model_product_run_on_the_host_equals_the_oracle(sim, tile, N, K, M
     orc.orc_test_mfma_gemm(_p(W), _p(x32), M, N, K, _p(want))
     want = (want + bias[None, :]).astype(np.float32)
     assert out.tobytes() == want.tobytes(), "the f16 tile product differs from the oracle's C1m product"
+
+
+def _attention_reference(orc, q, kc, vc, H, N, ctx, n_past, causal):
+    P = 1024
+    K4, V4 = kc.reshape(H, 16, P, 4), vc.reshape(H, P, 64)
+    want = np.zeros((N, H * 64), np.float16)
+    for h in range(H):
+        kh = np.ascontiguousarray(K4[h, :, :ctx, :].transpose(1, 0, 2).reshape(ctx, 64))
+        vh = np.ascontiguousarray(V4[h, :ctx, :])
+        qh = np.ascontiguousarray(q[:, 64 * h:64 * h + 64])
+        o = np.zeros((N, 64), np.float32)
+        orc.orc_test_attention(_p(qh), _p(kh), _p(vh), N, ctx, n_past, causal, _p(o))
+        want[:, 64 * h:64 * h + 64] = o.astype(np.float16)
+    return want
+
+
+def _orc_attention():
+    from oracle import pyoracle
+    pyoracle.build()
+    orc = C.CDLL(pyoracle.LIB_PATH)
+    orc.orc_test_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return orc
+
+
+@pytest.mark.parametrize("N,n_past", [(70, 5), (33, 0), (1, 40)])
+def test_prefill_attention_run_on_the_host_equals_the_oracle(sim, N, n_past):
+    """attn_rows_kernel (causal prompt passes: 32-query tiles, the score tile in LDS, C2 / C4 / C5 on v_mfma_f32_32x32x2_f32) against the oracle's attention."""
+    orc = _orc_attention()
+    rng = np.random.default_rng(N)
+    H, P = 2, 1024
+    ctx = n_past + N
+    kc = rng.standard_normal(H * 16 * P * 4).astype(np.float32)
+    vc = rng.standard_normal(H * P * 64).astype(np.float32)
+    q = rng.standard_normal((N, H * 64)).astype(np.float32)
+    att = np.zeros((N, H * 64), np.float16)
+    assert sim.sim_attention_rows(0, _p(q), _p(kc), _p(vc), _p(att), H, N, n_past, 1) == 0
+    assert att.tobytes() == _attention_reference(orc, q, kc, vc, H, N, ctx, n_past, 1).tobytes()
+
+
+def test_fine_window_attention_run_on_the_host_equals_the_oracle(sim):
+    """attn_window_kernel (the fine model's whole-window attention with the scores in registers: transposed score tiles with permuted key rows, every wave owns
+    two C5 chains) and attn_rows_kernel on the same window, both against the oracle - one head, 1024 x 1024."""
+    orc = _orc_attention()
+    rng = np.random.default_rng(77)
+    H, P, N = 1, 1024, 1024
+    kc = rng.standard_normal(H * 16 * P * 4).astype(np.float32)
+    vc = rng.standard_normal(H * P * 64).astype(np.float32)
+    q = rng.standard_normal((N, H * 64)).astype(np.float32)
+    want = _attention_reference(orc, q, kc, vc, H, N, N, 0, 0)
+    for kernel in (1, 0):
+        att = np.zeros((N, H * 64), np.float16)
+        assert sim.sim_attention_rows(kernel, _p(q), _p(kc), _p(vc), _p(att), H, N, 0, 0) == 0
+        assert att.tobytes() == want.tobytes(), ("attn_window_kernel" if kernel else "attn_rows_kernel") + " differs from the oracle on a whole window"
