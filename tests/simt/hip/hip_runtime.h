@@ -1,11 +1,11 @@
-// A stand-in for <hip/hip_runtime.h> that lets the VALU kernels of bark.cpp_amd/csrc run on the HOST, thread for thread (tests/test_simt_emulation.py):
-// test infrastructure only - nothing of the product includes it.  One workgroup at a time, one std::thread per work-item; `__shared__` variables are
+// A stand-in for <hip/hip_runtime.h> that lets the kernels of bark.cpp_amd/csrc run on the HOST, work-item for work-item (tests/test_simt_emulation.py):
+// test infrastructure only - nothing of the product includes it.  One workgroup at a time, one fiber per work-item; `__shared__` variables are
 // function-local statics (shared by the work-items of the running workgroup), __syncthreads() is a barrier that leaving work-items drop out of, and
-// the wave-wide operations the kernels use (DPP row permutations, readlane, shuffles) are rendezvous of the 64 work-items of a wave.  Floating point:
+// the wave-wide operations the kernels use (DPP row permutations, readlane, shuffles, matrix-core instructions) are rendezvous of the 64 work-items of a wave.  Floating point:
 // fmaf is the hardware FMA (-mfma), f32 <-> f16 conversions are IEEE round-to-nearest-even as on the device, -ffp-contract=off as in the product.
 #pragma once
 #include <algorithm>
-#include <barrier>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -51,28 +51,55 @@ constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 #define hipLaunchKernelGGL(...) ((void) 0)
 
-// ---- the running workgroup ----------------------------------------------------------------------------------------------------------------------
+// ---- the running workgroup: one FIBER per work-item on the calling host thread --------------------------------------------------------------
+// Work-items are cooperative fibers (own stacks, a twenty-instruction context switch): a work-item runs until it reaches a barrier or a wave-wide
+// rendezvous, where the scheduler moves on to the next one; a phase completes when every work-item that has not left yet has arrived.  Nothing runs in
+// parallel, so `__shared__` statics need no protection inside a launch; launches from several host threads (a job's tail on its second stream) are
+// serialised by one mutex.  A sweep in which nobody can move is a deadlock of the kernel under test and aborts with a message.
+extern "C" void sim_switch(void ** save_sp, void * load_sp);
+asm(".text\n.globl sim_switch\n.type sim_switch,@function\nsim_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size sim_switch, .-sim_switch\n");
 namespace sim {
-struct Wave {
-    std::barrier<> bar;
-    uint64_t slot[64];
-    explicit Wave(int n) : bar(n) {}
-};
+struct Bar { int expected = 0, arrived = 0; unsigned phase = 0; };
+struct Fiber { void * sp = nullptr; int state = 0; Bar * on = nullptr; unsigned wait_phase = 0; unsigned tid = 0; };      // state: 0 runnable, 1 waiting, 2 done
+struct Wave { Bar bar; uint64_t slot[64]; };
 struct Group {
-    std::barrier<> bar;
-    std::vector<std::unique_ptr<Wave>> waves;
-    explicit Group(int n) : bar(n) { for (int w = 0; w < (n + 63) / 64; w++) waves.emplace_back(new Wave(std::min(64, n - 64 * w))); }
+    Bar bar; Wave waves[16]; Fiber fibers[1024]; int n = 0;
+    void * sched_sp = nullptr; int cur = -1;
+    const std::function<void()> * body = nullptr;
+    uint3_sim bidx{0, 0, 0}, bdim{1, 1, 1}, gdim{1, 1, 1};
 };
 inline thread_local Group * group = nullptr;
 inline thread_local int lane_id = 0;
-inline Wave & wave() { return *group->waves[threadIdx.x >> 6]; }
+inline Wave & wave() { return group->waves[threadIdx.x >> 6]; }
+inline void yield_to_scheduler() { Group * g = group; sim_switch(&g->fibers[g->cur].sp, g->sched_sp); }
+inline void leave(Bar & b) { if (--b.expected > 0 && b.arrived == b.expected) { b.arrived = 0; b.phase++; } }
+inline void wait(Bar & b) {
+    if (++b.arrived == b.expected) { b.arrived = 0; b.phase++; return; }        // the last one to arrive goes straight on
+    Fiber & f = group->fibers[group->cur];
+    f.on = &b; f.wait_phase = b.phase; f.state = 1;
+    yield_to_scheduler();
+}
+inline void fiber_entry() {
+    Group * g = group;
+    (*g->body)();
+    Fiber & f = g->fibers[g->cur];
+    // a work-item that is done no longer takes part in barriers and rendezvous (early returns are uniform per wave / workgroup in these kernels)
+    leave(g->waves[f.tid >> 6].bar); leave(g->bar);
+    f.state = 2;
+    yield_to_scheduler();
+    abort();                                                   // never resumed
+}
 // every work-item of the wave deposits `v`, then reads the deposit of work-item `from`
 inline uint64_t exchange(uint64_t v, int from) {
     Wave & w = wave();
     w.slot[lane_id] = v;
-    w.bar.arrive_and_wait();
+    wait(w.bar);
     const uint64_t r = w.slot[from & 63];
-    w.bar.arrive_and_wait();
+    wait(w.bar);
     return r;
 }
 inline int dpp_source(int lane, int ctrl) {
@@ -82,25 +109,49 @@ inline int dpp_source(int lane, int ctrl) {
     if (ctrl == 0x141) return row + (i & 8) + (7 - (i & 7));                                        // row_half_mirror
     fprintf(stderr, "sim: unsupported DPP control 0x%x\n", ctrl); abort();
 }
-// One workgroup after the other, one thread per work-item (blocks of up to 1024 work-items, 1-D blocks as all kernels here use).
-template <typename F> void launch(dim3 grid, int block, F && body) {
+inline std::mutex & launch_mutex() { static std::mutex m; return m; }
+constexpr size_t kStack = 256 * 1024;
+inline char * stacks() { static char * p = static_cast<char *>(aligned_alloc(4096, 1024 * kStack)); return p; }
+// One workgroup after the other (blocks of up to 1024 work-items, 1-D blocks as all kernels here use).
+template <typename F> void launch(dim3 grid, int block, F && body_in) {
+    std::lock_guard<std::mutex> lock(launch_mutex());
+    static Group * g = new Group();                           // under the mutex: one workgroup at a time in the whole process
+    const std::function<void()> body = body_in;
+    if (block < 1 || block > 1024) { fprintf(stderr, "sim: block of %d work-items\n", block); abort(); }
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
-        Group g(block);
-        std::vector<std::thread> th;
-        for (int t = 0; t < block; t++) th.emplace_back([&, t] {
-            group = &g; lane_id = t & 63;
-            threadIdx = {(unsigned) t, 0, 0}; blockIdx = {bx, by, bz}; blockDim = {(unsigned) block, 1, 1}; gridDim = {grid.x, grid.y, grid.z};
-            body();
-            // a work-item that is done no longer takes part in barriers and rendezvous (early returns are uniform per wave / workgroup in these kernels)
-            g.waves[(size_t) (t >> 6)]->bar.arrive_and_drop();
-            g.bar.arrive_and_drop();
-        });
-        for (auto & x : th) x.join();
+        g->n = block; g->body = &body; g->bar = Bar(); g->bar.expected = block;
+        for (int w = 0; w < 16; w++) { g->waves[w].bar = Bar(); g->waves[w].bar.expected = std::max(0, std::min(64, block - 64 * w)); }
+        for (int t = 0; t < block; t++) {
+            Fiber & f = g->fibers[t];
+            f = Fiber(); f.tid = (unsigned) t;
+            void ** top = reinterpret_cast<void **>(stacks() + (size_t) (t + 1) * kStack);       // 16-byte aligned
+            top[-2] = reinterpret_cast<void *>(&fiber_entry);                                    // the `ret` of the first switch lands there with rsp = 8 mod 16
+            for (int i = 3; i <= 8; i++) top[-i] = nullptr;                                       // rbp, rbx, r12 .. r15
+            f.sp = top - 8;
+        }
+        Group * outer = group;
+        group = g;
+        int done = 0;
+        while (done < block) {
+            bool moved = false;
+            for (int t = 0; t < block; t++) {
+                Fiber & f = g->fibers[t];
+                if (f.state == 1 && f.on->phase != f.wait_phase) f.state = 0;
+                if (f.state != 0) continue;
+                g->cur = t; lane_id = t & 63;
+                threadIdx = {(unsigned) t, 0, 0}; blockIdx = {bx, by, bz}; blockDim = {(unsigned) block, 1, 1}; gridDim = {grid.x, grid.y, grid.z};
+                sim_switch(&g->sched_sp, f.sp);
+                moved = true;
+                if (f.state == 2) done++;
+            }
+            if (!moved) { fprintf(stderr, "sim: deadlock in workgroup (%u, %u, %u): no work-item can move\n", bx, by, bz); abort(); }
+        }
+        group = outer;
     }
 }
 }  // namespace sim
 
-inline void __syncthreads() { sim::group->bar.arrive_and_wait(); }
+inline void __syncthreads() { sim::wait(sim::group->bar); }
 inline int sim_update_dpp(int, int src, int ctrl, int, int, bool) { return (int) (uint32_t) sim::exchange((uint32_t) src, sim::dpp_source(sim::lane_id, ctrl)); }
 inline int sim_readlane(int v, int lane) { return (int) (uint32_t) sim::exchange((uint32_t) v, lane); }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) sim_update_dpp(old, src, ctrl, rm, bm, bc)
@@ -120,9 +171,9 @@ inline void gather2(float a, float b, float (&A)[64], float (&B)[64]) {
     Wave & w = wave();
     uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
     w.slot[lane_id] = ((uint64_t) ua << 32) | ub;
-    w.bar.arrive_and_wait();
+    wait(w.bar);
     for (int l = 0; l < 64; l++) { const uint32_t x = (uint32_t) (w.slot[l] >> 32), y = (uint32_t) w.slot[l]; memcpy(&A[l], &x, 4); memcpy(&B[l], &y, 4); }
-    w.bar.arrive_and_wait();
+    wait(w.bar);
 }
 }
 // v_mfma_f32_32x32x2_f32: lane l holds A[l % 32][l / 32] and B[l / 32][l % 32]; D register r of lane l = element ((r & 3) + 8 (r >> 2) + 4 (l / 32), l % 32)
@@ -160,7 +211,7 @@ inline sim_floatx16 sim_mfma_32x32x16_f16(sim_half8 a, sim_half8 b, sim_floatx16
     static Side side[16];                                     // one per wave of the running workgroup (at most 1024 work-items)
     Side & sd = side[threadIdx.x >> 6];
     memcpy(sd.a[sim::lane_id], &a, 16); memcpy(sd.b[sim::lane_id], &b, 16);
-    w.bar.arrive_and_wait();
+    sim::wait(w.bar);
     const int half = sim::lane_id >> 5, col = sim::lane_id & 31;
     for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -169,7 +220,7 @@ inline sim_floatx16 sim_mfma_32x32x16_f16(sim_half8 a, sim_half8 b, sim_floatx16
         v = mfma_emu::group8(sd.a[32 + row], sd.b[32 + col], 8, v);   // k = 8 .. 15: lanes 32 .. 63
         acc[r] = v;
     }
-    w.bar.arrive_and_wait();
+    sim::wait(w.bar);
     return acc;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, x, y, z) sim_mfma_32x32x16_f16(a, b, acc)
@@ -177,9 +228,9 @@ inline unsigned long long sim_ballot(bool p) {
     unsigned long long m = 0;
     sim::Wave & w = sim::wave();
     w.slot[sim::lane_id] = p ? 1 : 0;
-    w.bar.arrive_and_wait();
+    sim::wait(w.bar);
     for (int l = 0; l < 64; l++) m |= (unsigned long long) (w.slot[l] & 1) << l;
-    w.bar.arrive_and_wait();
+    sim::wait(w.bar);
     return m;
 }
 #define __builtin_amdgcn_ballot_w64(p) sim_ballot(p)
