@@ -5,6 +5,7 @@
 // fmaf is the hardware FMA (-mfma), f32 <-> f16 conversions are IEEE round-to-nearest-even as on the device, -ffp-contract=off as in the product.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <cmath>
 #include <cstdint>
@@ -34,22 +35,92 @@ struct int4 { int x, y, z, w; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
+inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+inline float2 make_float2(float a, float b) { return float2{a, b}; }
+inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 
+// atomics: one work-item runs at a time
+inline int atomicAdd(int * p, int v) { const int o = *p; *p = o + v; return o; }
+inline unsigned atomicAdd(unsigned * p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+inline float atomicAdd(float * p, float v) { const float o = *p; *p = o + v; return o; }
+inline unsigned atomicMax(unsigned * p, unsigned v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+inline int atomicMax(int * p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 
-// ---- host-API surface the launch functions of the kernel files touch (never executed here) --------------------------------------------------
-typedef struct sim_stream * hipStream_t;
+// ---- the host API the engine uses: memory is host memory, a stream executes at once unless it is capturing, a graph is the list of what was captured ----
+struct sim_stream { std::vector<std::function<void()>> * capture = nullptr; };
+typedef sim_stream * hipStream_t;
+typedef std::vector<std::function<void()>> sim_graph;
+typedef sim_graph * hipGraph_t;
+typedef sim_graph * hipGraphExec_t;
+struct sim_event { std::chrono::steady_clock::time_point t; };
+typedef sim_event * hipEvent_t;
 typedef int hipError_t;
-constexpr hipError_t hipSuccess = 0;
-struct hipDeviceProp_t { int multiProcessorCount = 256; };
-inline hipError_t hipGetDevice(int * d) { *d = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t * p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+constexpr hipError_t hipSuccess = 0, hipErrorInvalidValue = 1;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+constexpr unsigned hipStreamNonBlocking = 1, hipHostMallocDefault = 0;
+struct hipDeviceProp_t { char name[256] = "host emulation (tests/simt)"; char gcnArchName[256] = "gfx950:emulated"; int multiProcessorCount = 256; size_t totalGlobalMem = (size_t) 1 << 40; };
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
+inline const char * hipGetErrorString(hipError_t) { return "emulated HIP runtime"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int * n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDevice(int * d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t * p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
-#define hipLaunchKernelGGL(...) ((void) 0)
+inline hipError_t hipDeviceGetStreamPriorityRange(int * least, int * greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+namespace sim {
+// every allocation is registered, so that a request (the weight-prefetch experiment) can be checked against what is actually allocated
+inline std::mutex & alloc_mutex() { static std::mutex m; return m; }
+inline std::vector<std::pair<const char *, size_t>> & allocs() { static std::vector<std::pair<const char *, size_t>> v; return v; }
+inline bool inside_an_allocation(const void * p, size_t n) {
+    std::lock_guard<std::mutex> g(alloc_mutex());
+    for (auto & a : allocs()) if ((const char *) p >= a.first && (const char *) p + n <= a.first + a.second) return true;
+    return false;
+}
+inline long & prefetch_requests() { static long n = 0; return n; }      // weight-prefetch requests seen (and checked) so far
+inline void enqueue(hipStream_t s, std::function<void()> f) { if (s && s->capture) s->capture->push_back(std::move(f)); else f(); }
+}
+inline hipError_t hipMalloc(void ** p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) / 256 * 256);
+    if (!*p) return hipErrorInvalidValue;
+    memset(*p, 0xA5, n);                                      // device memory starts with arbitrary contents
+    std::lock_guard<std::mutex> g(sim::alloc_mutex()); sim::allocs().emplace_back((const char *) *p, n);
+    return hipSuccess;
+}
+template <typename T> hipError_t hipMalloc(T ** p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n); }
+inline hipError_t hipFree(void * p) {
+    if (!p) return hipSuccess;
+    { std::lock_guard<std::mutex> g(sim::alloc_mutex()); auto & v = sim::allocs(); for (size_t i = 0; i < v.size(); i++) if (v[i].first == p) { v.erase(v.begin() + (long) i); break; } }
+    free(p); return hipSuccess;
+}
+template <typename T> hipError_t hipHostMalloc(T ** p, size_t n, unsigned = 0) { *p = static_cast<T *>(malloc(n)); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipHostFree(void * p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void * d, const void * s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void * d, const void * s, size_t n, hipMemcpyKind, hipStream_t st) { sim::enqueue(st, [=] { memmove(d, s, n); }); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void * d, int v, size_t n, hipStream_t st) { sim::enqueue(st, [=] { memset(d, v, n); }); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t * s, unsigned) { *s = new sim_stream(); return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t * s, unsigned, int) { *s = new sim_stream(); return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t * s, unsigned, const unsigned *) { *s = new sim_stream(); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) { if (!s || s->capture) return hipErrorInvalidValue; s->capture = new sim_graph(); return hipSuccess; }
+inline hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t * g) { if (!s || !s->capture) { *g = nullptr; return hipErrorInvalidValue; } *g = s->capture; s->capture = nullptr; return hipSuccess; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t * e, hipGraph_t g, void *, void *, size_t) { *e = new sim_graph(*g); return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s) { for (auto & f : *e) sim::enqueue(s, f); return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t * e) { *e = new sim_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float * ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 
 // ---- the running workgroup: one FIBER per work-item on the calling host thread --------------------------------------------------------------
 // Work-items are cooperative fibers (own stacks, a twenty-instruction context switch): a work-item runs until it reaches a barrier or a wave-wide
@@ -57,7 +128,7 @@ inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSucces
 // parallel, so `__shared__` statics need no protection inside a launch; launches from several host threads (a job's tail on its second stream) are
 // serialised by one mutex.  A sweep in which nobody can move is a deadlock of the kernel under test and aborts with a message.
 extern "C" void sim_switch(void ** save_sp, void * load_sp);
-asm(".text\n.globl sim_switch\n.type sim_switch,@function\nsim_switch:\n"
+asm(".text\n.weak sim_switch\n.type sim_switch,@function\nsim_switch:\n"
     "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
     "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
     "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
@@ -162,6 +233,36 @@ inline int sim_readlane(int v, int lane) { return (int) (uint32_t) sim::exchange
 inline float __shfl_xor(float v, int mask, int = 64) { uint32_t u; memcpy(&u, &v, 4); u = (uint32_t) sim::exchange(u, sim::lane_id ^ mask); memcpy(&v, &u, 4); return v; }
 inline double __shfl_xor(double v, int mask, int = 64) { uint64_t u; memcpy(&u, &v, 8); u = sim::exchange(u, sim::lane_id ^ mask); memcpy(&v, &u, 8); return v; }
 inline int __shfl_xor(int v, int mask, int = 64) { return (int) (uint32_t) sim::exchange((uint32_t) v, sim::lane_id ^ mask); }
+inline float __shfl(float v, int lane, int = 64) { uint32_t u; memcpy(&u, &v, 4); u = (uint32_t) sim::exchange(u, lane); memcpy(&v, &u, 4); return v; }
+inline int __shfl(int v, int lane, int = 64) { return (int) (uint32_t) sim::exchange((uint32_t) v, lane); }
+// __shfl_up: lanes below `delta` keep their own value
+inline double __shfl_up(double v, unsigned delta, int = 64) { uint64_t u; memcpy(&u, &v, 8); const int from = sim::lane_id >= (int) delta ? sim::lane_id - (int) delta : sim::lane_id; u = sim::exchange(u, from); memcpy(&v, &u, 8); return v; }
+inline float __shfl_up(float v, unsigned delta, int = 64) { uint32_t u; memcpy(&u, &v, 4); const int from = sim::lane_id >= (int) delta ? sim::lane_id - (int) delta : sim::lane_id; u = (uint32_t) sim::exchange(u, from); memcpy(&v, &u, 4); return v; }
+inline int __shfl_up(int v, unsigned delta, int = 64) { const int from = sim::lane_id >= (int) delta ? sim::lane_id - (int) delta : sim::lane_id; return (int) (uint32_t) sim::exchange((uint32_t) v, from); }
+// v_dot4_i32_i8: four signed byte products added to c (no clamp)
+inline int sim_sdot4(int a, int b, int c) { for (int i = 0; i < 4; i++) c += (int) (int8_t) (a >> (8 * i)) * (int) (int8_t) (b >> (8 * i)); return c; }
+#define __builtin_amdgcn_sdot4(a, b, c, clamp) sim_sdot4(a, b, c)
+// v_mfma_i32_32x32x32_i8: lane l holds the 16 levels k = 16 (l / 32) .. + 15 of A row / B column l % 32; D as for the 32 x 32 f32 forms; exact integer sums
+typedef int sim_intx4 __attribute__((ext_vector_type(4)));
+typedef int sim_intx16 __attribute__((ext_vector_type(16)));
+inline sim_intx16 sim_mfma_i32_32x32x32_i8(sim_intx4 a, sim_intx4 b, sim_intx16 acc) {
+    struct Side { int8_t a[64][16], b[64][16]; };
+    static Side side[16];
+    sim::Wave & w = sim::wave();
+    Side & sd = side[threadIdx.x >> 6];
+    memcpy(sd.a[sim::lane_id], &a, 16); memcpy(sd.b[sim::lane_id], &b, 16);
+    sim::wait(w.bar);
+    const int half = sim::lane_id >> 5, col = sim::lane_id & 31;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        int v = acc[r];
+        for (int hk = 0; hk < 2; hk++) for (int k = 0; k < 16; k++) v += (int) sd.a[32 * hk + row][k] * (int) sd.b[32 * hk + col][k];
+        acc[r] = v;
+    }
+    sim::wait(w.bar);
+    return acc;
+}
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, x, y, z) sim_mfma_i32_32x32x32_i8(a, b, acc)
 
 // The f32 matrix-core instructions as wave-wide rendezvous, with the arithmetic the device probes established (tools/probes/mfma*_probe.hip,
 // profiles/r02_mfma16x16x4_probe.txt, r03_mfma_*_probe.txt): every output element is one fmaf chain over k in ascending order.
@@ -237,3 +338,7 @@ inline unsigned long long sim_ballot(bool p) {
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, x, y, z) sim_mfma_32x32x2(a, b, acc)
 #define __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, x, y, z) sim_mfma_16x16x1_4b(a, b, acc)
+
+// a launch: executed at once, or recorded while the stream captures (arguments by value, as a kernel node keeps them)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    sim::enqueue(stream, [=]() { sim::launch(dim3(grid), (int) dim3(block).x, [&]() { kernel(__VA_ARGS__); }); })
