@@ -268,36 +268,42 @@ inline sim_intx16 sim_mfma_i32_32x32x32_i8(sim_intx4 a, sim_intx4 b, sim_intx16 
 // profiles/r02_mfma16x16x4_probe.txt, r03_mfma_*_probe.txt): every output element is one fmaf chain over k in ascending order.
 typedef float sim_floatx16 __attribute__((ext_vector_type(16)));
 namespace sim {
-inline void gather2(float a, float b, float (&A)[64], float (&B)[64]) {
+// deposit this work-item's two f32 operands; after the rendezvous every work-item reads the deposits it needs (a in the high, b in the low word)
+inline void deposit2(float a, float b) {
     Wave & w = wave();
     uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
     w.slot[lane_id] = ((uint64_t) ua << 32) | ub;
     wait(w.bar);
-    for (int l = 0; l < 64; l++) { const uint32_t x = (uint32_t) (w.slot[l] >> 32), y = (uint32_t) w.slot[l]; memcpy(&A[l], &x, 4); memcpy(&B[l], &y, 4); }
-    wait(w.bar);
 }
+inline float dep_a(const Wave & w, int l) { const uint32_t x = (uint32_t) (w.slot[l] >> 32); float f; memcpy(&f, &x, 4); return f; }
+inline float dep_b(const Wave & w, int l) { const uint32_t x = (uint32_t) w.slot[l]; float f; memcpy(&f, &x, 4); return f; }
 }
 // v_mfma_f32_32x32x2_f32: lane l holds A[l % 32][l / 32] and B[l / 32][l % 32]; D register r of lane l = element ((r & 3) + 8 (r >> 2) + 4 (l / 32), l % 32)
 inline sim_floatx16 sim_mfma_32x32x2(float a, float b, sim_floatx16 acc) {
-    float A[64], B[64];
-    sim::gather2(a, b, A, B);
+    sim::deposit2(a, b);
+    const sim::Wave & w = sim::wave();
     const int half = sim::lane_id >> 5, col = sim::lane_id & 31;
+    const float b0 = sim::dep_b(w, col), b1 = sim::dep_b(w, 32 + col);
     for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[r];
-        v = fmaf(A[row], B[col], v);
-        v = fmaf(A[32 + row], B[32 + col], v);
+        v = fmaf(sim::dep_a(w, row), b0, v);
+        v = fmaf(sim::dep_a(w, 32 + row), b1, v);
         acc[r] = v;
     }
+    sim::wait(sim::wave().bar);
     return acc;
 }
 // v_mfma_f32_16x16x1_4b_f32: four independent 16 x 16 x 1 blocks; lane 16 g + r holds A_g[r] and B_g[r]; D register 4 b + v of lane 16 g + j = element (4 g + v, j) of block b
 inline sim_floatx16 sim_mfma_16x16x1_4b(float a, float b, sim_floatx16 acc) {
-    float A[64], B[64];
-    sim::gather2(a, b, A, B);
+    sim::deposit2(a, b);
+    const sim::Wave & w = sim::wave();
     const int g = sim::lane_id >> 4, j = sim::lane_id & 15;
-    for (int blk = 0; blk < 4; blk++)
-        for (int v = 0; v < 4; v++) acc[4 * blk + v] = fmaf(A[16 * blk + 4 * g + v], B[16 * blk + j], acc[4 * blk + v]);
+    for (int blk = 0; blk < 4; blk++) {
+        const float bj = sim::dep_b(w, 16 * blk + j);
+        for (int v = 0; v < 4; v++) acc[4 * blk + v] = fmaf(sim::dep_a(w, 16 * blk + 4 * g + v), bj, acc[4 * blk + v]);
+    }
+    sim::wait(sim::wave().bar);
     return acc;
 }
 // v_mfma_f32_32x32x16_f16: lane l holds the 8 halves k = 8 (l / 32) .. + 7 of A row / B column l % 32; D as for 32x32x2.  The arithmetic is the oracle's
