@@ -1,0 +1,53 @@
+"""The -m gpu parity tests, run on a CPU: tests/simt/build_engine.py compiles the WHOLE engine (bark.cpp_amd/csrc: host control flow, graph capture and
+replay, stage loops, every kernel) for the host against the stand-in for the HIP runtime of tests/simt (work-items as fibers, matrix-core instructions as
+wave-wide rendezvous with the arithmetic the device probes established), and BARK_HIP_LIBRARY points the Python binding at the result.  A selection of the
+GPU suite then runs unchanged in a process of its own - the product's source against the oracle, bit for bit, without a GPU.  Test infrastructure: the product
+is libbark.so and has no CPU path ("Parity without a GPU")."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+# toy-model tests that take seconds each under emulation: tokenizer and hyper-parameters through the C ABI, prompt passes and decode steps of the semantic
+# and the coarse model (ragged prompt lengths: every tile shape of the prefill product and attention), fine forward passes (the C1m tile product and the
+# whole-window attention), the codec at several lengths (RVQ, the matrix-core convolutions, the LSTM wave front), loader refusals
+SELECTION = ("test_library_describes_a_gfx950_device or test_hparams or test_tokenizer or test_semantic_eval_prefill_and_decode or test_coarse_eval_prefill_and_decode "
+             "or test_coarse_prefill_ragged_lengths or test_fine_eval or test_codec_decode or refused or fails_cleanly")
+# minutes each under emulation (BARK_SIM_FULL=1): the five block formats (v_dot4 decode, i8 matrix cores for rows), graph replay against eager launches,
+# the matrix-core product against the one-row-per-wave kernel.  All of them passed on the emulated engine when this file was written.
+SLOW_SELECTION = "test_other_block_formats_toy or test_q4_0_logits_toy or test_graph_and_eager_agree or test_mfma_gemm_matches_row_kernel"
+
+
+@pytest.fixture(scope="module")
+def sim_engine(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm's clang is not installed")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "simt"))
+    import build_engine
+    return build_engine.build(str(tmp_path_factory.mktemp("sim_engine")))
+
+
+def _pytest_on(sim_engine, files, k, workers=4, timeout=1500, env_add=None):
+    env = dict(os.environ); env["BARK_HIP_LIBRARY"] = sim_engine
+    env.update(env_add or {})
+    cmd = [sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-n", str(workers), "-k", k]
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpu_parity_tests_pass_on_the_host_emulated_engine(sim_engine):
+    r = _pytest_on(sim_engine, ["tests/test_gpu_parity.py", "tests/test_gpu_loader.py"], SELECTION)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in tail and "failed" not in tail, tail
+    assert int(tail.split(" passed")[0].split()[-1]) >= 30, tail
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("BARK_SIM_FULL") != "1", reason="minutes of emulation: set BARK_SIM_FULL=1")
+def test_slower_gpu_parity_tests_pass_on_the_host_emulated_engine(sim_engine):
+    r = _pytest_on(sim_engine, ["tests/test_gpu_parity.py"], SLOW_SELECTION, workers=8, timeout=3000)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
