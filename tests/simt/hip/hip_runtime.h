@@ -85,6 +85,8 @@ inline bool inside_an_allocation(const void * p, size_t n) {
     return false;
 }
 inline long & prefetch_requests() { static long n = 0; return n; }      // weight-prefetch requests seen (and checked) so far
+struct PrefetchReport { ~PrefetchReport() { if (getenv("BARK_SIM_VERBOSE")) fprintf(stderr, "sim: %ld prefetch requests, every one inside an allocation\n", prefetch_requests()); } };
+inline PrefetchReport prefetch_report;
 inline void enqueue(hipStream_t s, std::function<void()> f) { if (s && s->capture) s->capture->push_back(std::move(f)); else f(); }
 }
 inline hipError_t hipMalloc(void ** p, size_t n) {

@@ -51,3 +51,35 @@ def test_gpu_parity_tests_pass_on_the_host_emulated_engine(sim_engine):
 def test_slower_gpu_parity_tests_pass_on_the_host_emulated_engine(sim_engine):
     r = _pytest_on(sim_engine, ["tests/test_gpu_parity.py"], SLOW_SELECTION, workers=8, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+_PREFETCH_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from bark_amd_loader import load_package
+from oracle.pyoracle import Oracle
+pkg = load_package()
+n = 16
+ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=n), 0)
+orc = Oracle(%r, n_threads=4)
+p = orc.params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=n)
+prompt = orc.tokenize("hello world , the water is cold today and the river runs fast !")
+so = orc.semantic(prompt, p)
+assert np.array_equal(ctx.semantic(prompt), so), "semantic tokens"
+assert np.array_equal(ctx.coarse(so), orc.coarse(so, p)), "coarse tokens"
+print("PREFETCH_SIM_OK")
+ctx.free(); orc.close()
+"""
+
+
+@pytest.mark.parametrize("arm", [{"BARK_HIP_WPREFETCH": "1", "BARK_HIP_KPREFETCH": "1"}, {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1", "BARK_HIP_WPREFETCH_STRIDE": "64"}])
+def test_weight_prefetch_requests_stay_inside_the_allocations(sim_engine, toy_model, arm):
+    """The unmeasured weight-prefetch experiment (BARK_HIP_WPREFETCH) on the emulated engine: every request of every decode
+    kernel of a semantic and a coarse stage (hipGraph-replayed steps, the coarse head's parity windows, the K quads of the next QKV kernel) is checked
+    against the registered allocations - a request outside aborts the process - and the stages' tokens equal the oracle's."""
+    env = dict(os.environ, BARK_HIP_LIBRARY=sim_engine, BARK_SIM_VERBOSE="1"); env.update(arm)
+    r = subprocess.run([sys.executable, "-c", _PREFETCH_CHILD % (ROOT, toy_model, toy_model)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PREFETCH_SIM_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    line = [l for l in r.stderr.splitlines() if l.startswith("sim: ") and "prefetch requests" in l]
+    assert line and int(line[0].split()[1]) > 100000, r.stderr[-500:]
