@@ -83,3 +83,41 @@ def test_weight_prefetch_requests_stay_inside_the_allocations(sim_engine, toy_mo
     assert r.returncode == 0 and "PREFETCH_SIM_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     line = [l for l in r.stderr.splitlines() if l.startswith("sim: ") and "prefetch requests" in l]
     assert line and int(line[0].split()[1]) > 100000, r.stderr[-500:]
+
+
+_SLOT_JOB_CHILD = r"""
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import bench
+from bark_amd_loader import load_package
+pkg = load_package()
+ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=12), 0)
+ctx.reserve_batch(8)
+texts = bench.synth_prompts(4, seed=3)
+reqs = [ctx.request_params(n_steps_text_encoder=3 + (5 * i) %% 12, temp=0.7 if i %% 4 == 1 else 0.0, seed=50 + i) for i in range(4)]
+h = hashlib.sha256()
+for r in ctx.generate_batch(texts, params=reqs):
+    for k in ("semantic", "coarse", "fine", "pcm"):
+        h.update(np.ascontiguousarray(r[k]).tobytes())
+print("RESULT " + h.hexdigest())
+ctx.free()
+"""
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("BARK_SIM_FULL") != "1", reason="about five minutes per arm under emulation (the fine stage): set BARK_SIM_FULL=1")
+def test_few_slot_experiment_gives_the_default_job_on_the_emulated_engine(sim_engine, toy_model):
+    """BARK_HIP_SLOT_PS / BARK_HIP_SLOT_GEMV end to end on the emulated engine: a ragged job of four utterances (one sampled) on
+    eight slots - host plumbing, graph capture per live slot count, the per-slot kernels - gives the ids and the PCM of the default lock-step route."""
+    got = []
+    procs = []
+    for arm in ({}, {"BARK_HIP_SLOT_PS": "8", "BARK_HIP_SLOT_GEMV": "8"}):
+        env = dict(os.environ, BARK_HIP_LIBRARY=sim_engine); env.update(arm)
+        procs.append(subprocess.Popen([sys.executable, "-c", _SLOT_JOB_CHILD % (ROOT, toy_model)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=3000)
+        line = [l for l in out.splitlines() if l.startswith("RESULT ")]
+        assert p.returncode == 0 and line, (out[-500:], err[-1500:])
+        got.append(line[0])
+    assert got[0] == got[1]
