@@ -231,7 +231,9 @@ inline int sim_readlane(int v, int lane) { return (int) (uint32_t) sim::exchange
 #define __builtin_amdgcn_readlane(v, lane) sim_readlane(v, lane)
 #define __builtin_amdgcn_readfirstlane(v) sim_readlane(v, 0)
 #define __builtin_amdgcn_sched_barrier(x) ((void) 0)
-#define __builtin_amdgcn_s_waitcnt(x) ((void) 0)
+// s_waitcnt as the kernels use it - "the wave's own LDS writes have landed" before one lane reads what the other lanes wrote - relies on the lanes of a
+// wave running in lock step; fibers do not, so it is a rendezvous of the wave here (every use sits in wave-uniform code; a divergent one would deadlock and abort)
+#define __builtin_amdgcn_s_waitcnt(x) sim::wait(sim::wave().bar)
 inline float __shfl_xor(float v, int mask, int = 64) { uint32_t u; memcpy(&u, &v, 4); u = (uint32_t) sim::exchange(u, sim::lane_id ^ mask); memcpy(&v, &u, 4); return v; }
 inline double __shfl_xor(double v, int mask, int = 64) { uint64_t u; memcpy(&u, &v, 8); u = sim::exchange(u, sim::lane_id ^ mask); memcpy(&v, &u, 8); return v; }
 inline int __shfl_xor(int v, int mask, int = 64) { return (int) (uint32_t) sim::exchange((uint32_t) v, sim::lane_id ^ mask); }
