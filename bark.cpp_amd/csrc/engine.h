@@ -125,6 +125,9 @@ struct bark_context {
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
         float * slot_par = nullptr;                      // the slots' own temperatures [cap] and min_eos_p [cap] (bark_hip_request_params)
+        // pinned host memory (hipHostMalloc, freed by the context): where the sampled ids [cap][2048] and the states [cap] of the live slots land at
+        // a poll / window end, and the staging rows of the states uploaded at a window start
+        int32_t * h_ids = nullptr; barkhip::StepState * h_state = nullptr, * h_state_in = nullptr;
         // window prompts of all slots in ONE pass (batch_prefill_many): row scratch for cap * P rows, the prompts' ids, the sequence table
         float * pf_x = nullptr, * pf_q = nullptr; barkhip::half_t * pf_xn = nullptr, * pf_att = nullptr, * pf_h = nullptr;
         int32_t * pf_tokens = nullptr; barkhip::SeqTab * pf_tab = nullptr;

@@ -74,7 +74,57 @@ void ensure_batch(bark_context * c, int B) {
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.slot_par = dev_alloc<float>(c, (size_t) 2 * B);               // [0, B): temperatures, [B, 2 B): min_eos_p
     c->h_slot_par.assign((size_t) 2 * B, 0.0f);
+    // pinned landing zone of the per-window / per-poll read-back (ids of all slots + their states): read_back() below
+    HIP_OK(hipHostMalloc((void **) &bb.h_ids, (size_t) B * 2048 * sizeof(int32_t), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void **) &bb.h_state, (size_t) B * sizeof(StepState), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void **) &bb.h_state_in, (size_t) B * sizeof(StepState), hipHostMallocDefault));
     bb.cap = B;
+}
+
+// How the host learns what the lock steps produced: the sampled ids of the live slots (rows of 2048) and their stage states.
+// The stream is synchronised BEFORE the copies are issued and the copies land in pinned memory: the copy engine then reads device memory that
+// no kernel is writing any more, and nothing depends on how the runtime stages a pageable destination (root cause of round 4's
+// red GPU suite).  BARK_HIP_READBACK=legacy|pinned are the arms that led there (tools/clone_stress.py): pageable destination without / pinned
+// destination without the synchronisation in front; BARK_HIP_READBACK_CHECK=1 re-reads everything after a device-wide synchronisation and
+// reports differences on stderr.
+int readback_mode() {
+    static const int v = [] { const char * e = getenv("BARK_HIP_READBACK"); return !e ? 0 : !strcmp(e, "legacy") ? 1 : !strcmp(e, "pinned") ? 2 : 0; }();
+    return v;
+}
+void read_back(bark_context * c, int B, std::vector<int32_t> * ids, std::vector<StepState> & st, const char * where) {
+    bark_context::Batch & bb = c->batch;
+    static const bool check = getenv("BARK_HIP_READBACK_CHECK") && atoi(getenv("BARK_HIP_READBACK_CHECK")) != 0;
+    const int mode = readback_mode();
+    st.resize((size_t) B);
+    if (ids) ids->resize((size_t) B * 2048);
+    if (mode == 1) {
+        if (ids) HIP_OK(hipMemcpyAsync(ids->data(), bb.out_tokens, ids->size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(st.data(), bb.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    } else {
+        if (mode == 0) HIP_OK(hipStreamSynchronize(c->stream));
+        if (ids) HIP_OK(hipMemcpyAsync(bb.h_ids, bb.out_tokens, ids->size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(bb.h_state, bb.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (ids) memcpy(ids->data(), bb.h_ids, ids->size() * 4);
+        memcpy(st.data(), bb.h_state, sizeof(StepState) * B);
+    }
+    if (check) {
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<int32_t> ids2(ids ? ids->size() : 0); std::vector<StepState> st2((size_t) B);
+        if (ids) copy_to_host(c, ids2.data(), bb.out_tokens, ids2.size() * 4);
+        copy_to_host(c, st2.data(), bb.state, sizeof(StepState) * B);
+        for (int b = 0; b < B; b++) {
+            const int n_out = std::min(st2[(size_t) b].n_out, 2048);
+            int bad = 0, first = -1;
+            if (ids) for (int i = 0; i < n_out; i++) if ((*ids)[(size_t) b * 2048 + i] != ids2[(size_t) b * 2048 + i]) { if (!bad) first = i; bad++; }
+            const bool sbad = memcmp(&st[(size_t) b], &st2[(size_t) b], sizeof(StepState)) != 0;
+            if (bad || sbad)
+                fprintf(stderr, "bark-hip READBACK MISMATCH (%s, ctx %p, mode %d, %d slots): slot %d: %d of %d ids differ from the copy taken after a device-wide sync (first at %d: %d vs %d); state %s (n_out %d vs %d, n_past %d vs %d)\n",
+                        where, (void *) c, mode, B, b, bad, n_out, first, first >= 0 ? (*ids)[(size_t) b * 2048 + first] : 0, first >= 0 ? ids2[(size_t) b * 2048 + first] : 0,
+                        sbad ? "DIFFERS" : "equal", st[(size_t) b].n_out, st2[(size_t) b].n_out, st[(size_t) b].n_past, st2[(size_t) b].n_past);
+        }
+    }
 }
 
 // the slots' own sampling parameters (bark_hip_request_params): host mirror -> device
@@ -110,12 +160,6 @@ SampleArgs slot_sample_args(bark_context * c, const StageCfg & s, const bark_con
 void set_slot_state(bark_context * c, int slot, const StepState & st) {
     HIP_OK(hipMemcpyAsync(c->batch.state + slot, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-}
-std::vector<StepState> get_slot_states(bark_context * c, int B) {
-    std::vector<StepState> st((size_t) B);
-    HIP_OK(hipMemcpyAsync(st.data(), c->batch.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    return st;
 }
 
 // all slots: layers -> LM head -> greedy sample (+ embedding of the sampled token)
@@ -821,12 +865,13 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             const int k = std::max(0, std::min(32, std::min(most_left, room)));
             for (int j = 0; j < k; j++) batch_step(c, s, B);
             for (int b = 0; b < B; b++) us[(size_t) slot_utt[(size_t) b]].issued += k;
-            std::vector<StepState> st = get_slot_states(c, B);
+            std::vector<StepState> st;
+            read_back(c, B, nullptr, st, "semantic poll");
             for (auto & v : st) if (v.fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
             // retire from the back so that a move never touches a slot that is still to be looked at
             bool moved = false, any_done = false;
             for (int b = 0; b < B; b++) any_done = any_done || !(st[(size_t) b].eos_step == INT32_MAX && us[(size_t) slot_utt[(size_t) b]].issued < us[(size_t) slot_utt[(size_t) b]].cap);
-            if (any_done) { ids_all.resize((size_t) B * 2048); copy_to_host(c, ids_all.data(), bb.out_tokens, ids_all.size() * 4); }
+            if (any_done) read_back(c, B, &ids_all, st, "semantic retire");          // the stream is idle: one more copy, taken only when somebody leaves
             for (int b = B - 1; b >= 0; b--) {
                 const Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].eos_step == INT32_MAX && u.issued < u.cap) continue;
@@ -917,9 +962,10 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 if ((int) ins[(size_t) b].size() + max_here - 1 > m.hp.block_size) throw std::runtime_error("coarse: a lock-step window exceeds the context of a slot (history + sliding window too long for a batch)");
             int lock_steps = max_here - 1;                               // batched steps after every slot has its first sample
             std::vector<int> pf_slots, pf_L, pf_step; std::vector<const std::vector<int32_t> *> pf_ids;
-            // states of the slots that continue with a decode step: uploaded without a host synchronisation per slot - the staging vector lives until
-            // get_slot_states() below has synchronised the stream (64 slots x 13 windows of 25 us round trips otherwise)
-            std::vector<StepState> stage_st((size_t) B);
+            // states of the slots that continue with a decode step: uploaded without a host synchronisation per slot (64 slots x 13 windows of
+            // 25 us round trips otherwise) from a pinned staging row per slot, which is not touched again before read_back() below has
+            // synchronised the stream
+            StepState * stage_st = bb.h_state_in;
             for (int b = 0; b < B; b++) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 const auto & in = ins[(size_t) b];
@@ -927,7 +973,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 c->stats.n_prefix_rows_reused += L;
                 if ((int) in.size() - L == 1) {
                     // the prompt is the cached sequence plus one token: a decode step (prefix reuse, see engine_coarse)
-                    StepState & st1 = stage_st[(size_t) b];
+                    StepState & st1 = stage_st[b];
                     st1 = fresh_state(); st1.step = u.step_idx; st1.n_past = L; st1.cur_token = in[(size_t) L];
                     HIP_OK(hipMemcpyAsync(bb.state + b, &st1, sizeof(StepState), hipMemcpyHostToDevice, c->stream));
                     embed_slot(c, s, b);
@@ -943,11 +989,10 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             // a slot whose last window is shorter than the others' keeps stepping to the end of the window (its further ids are discarded;
             // window prompt + sliding_window_size rows fit the context by the check above, as every window is even the parity stays shared)
             for (int j = 0; j < lock_steps; j++) batch_step(c, s, B);
-            // the window's ids of all slots in ONE copy (rows of 2048 per slot, 512 KB at 64 slots), enqueued in front of the states' copy whose
-            // synchronisation covers both
-            std::vector<int32_t> ids_all((size_t) B * 2048);
-            HIP_OK(hipMemcpyAsync(ids_all.data(), bb.out_tokens, ids_all.size() * 4, hipMemcpyDeviceToHost, c->stream));
-            const std::vector<StepState> st = get_slot_states(c, B);
+            // the window's ids of all slots in ONE copy (rows of 2048 per slot, 512 KB at 64 slots) and their states
+            std::vector<int32_t> ids_all;
+            std::vector<StepState> st;
+            read_back(c, B, &ids_all, st, "coarse window");
             for (int b = 0; b < B; b++) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");

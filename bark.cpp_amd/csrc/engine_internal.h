@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,10 +30,22 @@ inline int64_t now_us() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// BARK_HIP_POISON=1 (diagnostic): every run-time allocation (KV caches, slot rows, scratch, partial scores) starts as 0xFF bytes - NaN as
+// f32 / f16, -1 as an id - so that a read of memory nobody has written shows up in the results whatever a fresh box happens to hand out
+// (the GPU suite is expected to pass unchanged under it)
+inline bool poison_allocations() {
+    static const bool v = getenv("BARK_HIP_POISON") && atoi(getenv("BARK_HIP_POISON")) != 0;
+    return v;
+}
 template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
     void * p = nullptr;
-    HIP_OK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_OK(hipMalloc(&p, bytes));
     ctx->allocs.push_back(p);
+    if (poison_allocations() && ctx->stream) {
+        HIP_OK(hipMemsetAsync(p, 0xFF, bytes, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+    }
     return (T *) p;
 }
 

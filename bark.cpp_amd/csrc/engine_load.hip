@@ -88,6 +88,9 @@ bark_context::~bark_context() {
     if (codec_graph.exec) (void) hipGraphExecDestroy(codec_graph.exec);
     for (auto & g : fine_graphs) if (g) (void) hipGraphExecDestroy(g);
     for (void * p : allocs) (void) hipFree(p);
+    if (batch.h_ids) (void) hipHostFree(batch.h_ids);
+    if (batch.h_state) (void) hipHostFree(batch.h_state);
+    if (batch.h_state_in) (void) hipHostFree(batch.h_state_in);
     if (stream) (void) hipStreamDestroy(stream);
 }
 bark_context::SharedWeights::~SharedWeights() {
