@@ -337,7 +337,10 @@ class BarkContext:
         """The context's own values of the per-utterance parameters, with overrides (temp, fine_temp, min_eos_p, n_steps_text_encoder, seed)."""
         p = self._params if self._params is not None else default_params()
         r = BarkHipRequestParams(p.temp, p.fine_temp, p.min_eos_p, p.n_steps_text_encoder, 0)
+        known = {name for name, _ in BarkHipRequestParams._fields_}
         for k, v in over.items():
+            if k not in known:             # setattr on a ctypes.Structure accepts any name silently: a typo would run with the context's value
+                raise TypeError(f"request_params: unknown parameter {k!r} (one of {sorted(known)})")
             setattr(r, k, v)
         return r
 

@@ -91,13 +91,21 @@ BARK_API struct bark_hip_batcher * bark_hip_batcher_create_ex(struct bark_contex
     try {
         b->ctx = bctx; b->max_batch = max_batch; b->max_wait = std::chrono::microseconds((int64_t) max_wait_ms * 1000);
         b->ctxs.push_back(bctx);
-        for (int i = 1; i < n_streams; i++) b->ctxs.push_back(engine_clone(bctx, (uint32_t) i));
+        for (int i = 1; i < n_streams; i++) {
+            b->ctxs.push_back(engine_clone(bctx, (uint32_t) i));
+            // the progress callback belongs to the thread that calls into the context (bark.h contract): the further job streams run on
+            // threads of their own, so they report nothing instead of calling the user's function concurrently with the same user_data
+            b->ctxs.back()->params.progress_callback = nullptr; b->ctxs.back()->params.progress_callback_user_data = nullptr;
+        }
         for (bark_context * c : b->ctxs) engine_reserve_batch(c, std::min(max_batch, 64));   // the slot count is fixed by the first use; a larger job queues for the slots
         bark_hip_batcher * raw = b.get();
         for (int i = 0; i < n_streams; i++) b->workers.emplace_back([raw, i] { raw->run(i); });
         return b.release();
     } catch (const std::exception & e) {
         fprintf(stderr, "bark_hip_batcher_create: %s\n", e.what());
+        // workers that did start must be joined before the object goes away (a joinable std::thread's destructor terminates the process)
+        { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }
+        for (auto & w : b->workers) if (w.joinable()) w.join();
         for (size_t i = 1; i < b->ctxs.size(); i++) delete b->ctxs[i];
         return nullptr;
     }

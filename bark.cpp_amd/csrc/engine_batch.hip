@@ -110,7 +110,8 @@ void read_back(bark_context * c, int B, std::vector<int32_t> * ids, std::vector<
         memcpy(st.data(), bb.h_state, sizeof(StepState) * B);
     }
     if (check) {
-        HIP_OK(hipDeviceSynchronize());
+        // (never hipDeviceSynchronize here: it is refused while ANY stream of the process captures - and poisons that capture, round 5 call 1)
+        HIP_OK(hipStreamSynchronize(c->stream));
         std::vector<int32_t> ids2(ids ? ids->size() : 0); std::vector<StepState> st2((size_t) B);
         if (ids) copy_to_host(c, ids2.data(), bb.out_tokens, ids2.size() * 4);
         copy_to_host(c, st2.data(), bb.state, sizeof(StepState) * B);
@@ -120,7 +121,7 @@ void read_back(bark_context * c, int B, std::vector<int32_t> * ids, std::vector<
             if (ids) for (int i = 0; i < n_out; i++) if ((*ids)[(size_t) b * 2048 + i] != ids2[(size_t) b * 2048 + i]) { if (!bad) first = i; bad++; }
             const bool sbad = memcmp(&st[(size_t) b], &st2[(size_t) b], sizeof(StepState)) != 0;
             if (bad || sbad)
-                fprintf(stderr, "bark-hip READBACK MISMATCH (%s, ctx %p, mode %d, %d slots): slot %d: %d of %d ids differ from the copy taken after a device-wide sync (first at %d: %d vs %d); state %s (n_out %d vs %d, n_past %d vs %d)\n",
+                fprintf(stderr, "bark-hip READBACK MISMATCH (%s, ctx %p, mode %d, %d slots): slot %d: %d of %d ids differ from a second copy taken after one more stream sync (first at %d: %d vs %d); state %s (n_out %d vs %d, n_past %d vs %d)\n",
                         where, (void *) c, mode, B, b, bad, n_out, first, first >= 0 ? (*ids)[(size_t) b * 2048 + first] : 0, first >= 0 ? ids2[(size_t) b * 2048 + first] : 0,
                         sbad ? "DIFFERS" : "equal", st[(size_t) b].n_out, st2[(size_t) b].n_out, st[(size_t) b].n_past, st2[(size_t) b].n_past);
         }
@@ -527,11 +528,15 @@ void engine_profile_lock_step(bark_context * c, int which, int B, int ctxlen, in
     out.emplace_back("step (graph replay)", (double) ms * 1000.0 / reps);
 }
 
+namespace { bool ensure_tail_context(bark_context * c); bool tail_stream_enabled(); }
+
 void engine_reserve_batch(bark_context * c, int slots) {
     HIP_OK(hipSetDevice(c->device));
     if (slots < 1 || slots > kMaxSlots) throw std::runtime_error("reserve_batch: 1..64 slots");
     if (c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32) return;          // these contexts run batches sequentially
     ensure_batch(c, std::max(slots, 8));
+    // the clone the tail of a job runs on: made here, off the hot path, instead of inside the first job
+    if (slots > 1 && tail_stream_enabled() && !c->host_sampling) (void) ensure_tail_context(c);
 }
 
 namespace {
@@ -571,6 +576,46 @@ void set_slot_params(bark_context * c, int slot, const Utt & u) {
 }
 
 
+// The clone a job's tail runs on (JobTail below): a second set of KV caches, scratch, fine-batch and codec buffers on a stream of its own, kept
+// until bark_free - i.e. a context that runs lock-step jobs holds about twice the run-time memory of one that does not.  Created by
+// bark_hip_reserve_batch / the request collector (explicit, off the hot path) or by the first job with more than one utterance.
+// BARK_HIP_TAIL_CUS=<n> confines the helper's stream to the first n CUs through hipExtStreamCreateWithCUMask, which takes no flags: that stream
+// is a BLOCKING one (it synchronises with the legacy stream), so the switch is for measurements on one context only, not for servers whose
+// threads capture graphs.  false: no clone could be made (said once on stderr); the job keeps its tail on its own stream.
+// BARK_HIP_TAIL_STREAM=0 keeps the tail behind the coarse stage on the job's own stream; read per call: tests flip it
+bool tail_stream_enabled() { const char * e = getenv("BARK_HIP_TAIL_STREAM"); return !(e && !strcmp(e, "0")); }
+
+bool ensure_tail_context(bark_context * c) {
+    if (c->tail) return true;
+    try {
+        c->tail = engine_clone(c, 0);
+        // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever
+        // a CU frees up), optionally confined to a part of the chip
+        const char * pe = getenv("BARK_HIP_TAIL_PRIORITY"), * ce = getenv("BARK_HIP_TAIL_CUS");
+        const int low = pe ? atoi(pe) : 1, cus = ce ? atoi(ce) : 0;
+        if (low || cus > 0) {
+            HIP_OK(hipStreamSynchronize(c->tail->stream));
+            HIP_OK(hipStreamDestroy(c->tail->stream)); c->tail->stream = nullptr;
+            if (cus > 0) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < std::min(cus, 256); i++) mask[i >> 5] |= 1u << (i & 31);
+                HIP_OK(hipExtStreamCreateWithCUMask(&c->tail->stream, 8, mask));
+            } else {
+                int least = 0, greatest = 0;
+                HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
+            }
+        }
+        return true;
+    } catch (const std::exception & e) {
+        // e.g. no memory for a second set of caches and scratch
+        static bool said = false;
+        if (!said) { fprintf(stderr, "bark-hip: no second stream for the tail of lock-step jobs (%s)\n", e.what()); said = true; }
+        delete c->tail; c->tail = nullptr;
+        return false;
+    }
+}
+
 // The tail of a job: fine passes (bark.cpp:1961-2059) and codec (bark.cpp:2143-2167) of the utterances that have left the coarse stage.
 // With a second context (a clone: own non-blocking stream, scratch and graphs, the same weights) it runs on a helper thread WHILE the lock
 // steps of the remaining utterances go on: a lock step is a chain of ~100 small dependent kernels that leaves most of the chip idle, the fine
@@ -594,34 +639,7 @@ struct JobTail {
     float saved_fine_temp = 0.0f;
 
     JobTail(bark_context * job, std::vector<Utt> & utts, bool second_stream) : c(job), t(job), us(utts) {
-        if (second_stream && !c->tail) {
-            try {
-                c->tail = engine_clone(c, 0);
-                // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever
-                // a CU frees up), optionally confined to a part of the chip (BARK_HIP_TAIL_CUS = n: a CU mask of the first n CUs)
-                const char * pe = getenv("BARK_HIP_TAIL_PRIORITY"), * ce = getenv("BARK_HIP_TAIL_CUS");
-                const int low = pe ? atoi(pe) : 1, cus = ce ? atoi(ce) : 0;
-                if (low || cus > 0) {
-                    HIP_OK(hipStreamSynchronize(c->tail->stream));
-                    HIP_OK(hipStreamDestroy(c->tail->stream)); c->tail->stream = nullptr;
-                    if (cus > 0) {
-                        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        for (int i = 0; i < std::min(cus, 256); i++) mask[i >> 5] |= 1u << (i & 31);
-                        HIP_OK(hipExtStreamCreateWithCUMask(&c->tail->stream, 8, mask));
-                    } else {
-                        int least = 0, greatest = 0;
-                        HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                        HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
-                    }
-                }
-            } catch (const std::exception & e) {
-                // e.g. no memory for a second set of caches and scratch: the job keeps its tail on its own stream (said once)
-                static bool said = false;
-                if (!said) { fprintf(stderr, "bark-hip: no second stream for the tail of lock-step jobs (%s)\n", e.what()); said = true; }
-                delete c->tail; c->tail = nullptr;
-                second_stream = false;
-            }
-        }
+        if (second_stream && !ensure_tail_context(c)) second_stream = false;
         if (second_stream) {
             t = c->tail;
             // its captured fine passes bake the fine temperature (bark_hip_set_params on the job's context drops them too: engine_invalidate_graphs)
@@ -806,7 +824,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
         pp.block_size = m.hp.block_size; pp.text_encoding_offset = p.text_encoding_offset; pp.text_pad_token = p.text_pad_token;
         pp.semantic_pad_token = p.semantic_pad_token; pp.semantic_infer_token = p.semantic_infer_token;
         std::deque<int> queue;
-        int total_steps = 0, done_steps = 0;
+        int total_steps = 0, done_steps = 0, last_pct = 0;
         for (int i = 0; i < n; i++) {
             us[(size_t) i].cap = std::max(0, std::min(us[(size_t) i].rp.n_steps_text_encoder, cap_max));
             if (us[(size_t) i].cap > 0) { queue.push_back(i); total_steps += us[(size_t) i].cap; }
@@ -858,11 +876,13 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 }
             }
             const int B = (int) slot_utt.size();
-            // lock steps until the next poll: at most 32, no further than the utterance with the most steps left needs, and never past the
-            // end of a slot's context (an utterance that has met its stop rule or cap keeps stepping until the poll; its ids are discarded)
-            int most_left = 0, room = INT32_MAX;
-            for (int b = 0; b < B; b++) { const Utt & u = us[(size_t) slot_utt[(size_t) b]]; most_left = std::max(most_left, u.cap - u.issued); room = std::min(room, cap_max - u.issued); }
-            const int k = std::max(0, std::min(32, std::min(most_left, room)));
+            // lock steps until the next poll: at most 32, and no further than the live utterance with the FEWEST steps left needs - a slot is looked at
+            // exactly when its cap is reached, so no lock step is spent on an utterance that is known to be finished and the queue refills its slot at once
+            // (an utterance that meets its STOP RULE between two polls keeps stepping until the next one, at most 31 steps; its further ids are discarded).
+            // issued <= cap <= cap_max for every live slot, so no step runs past the end of a slot's context.
+            int least_left = INT32_MAX;
+            for (int b = 0; b < B; b++) { const Utt & u = us[(size_t) slot_utt[(size_t) b]]; least_left = std::min(least_left, u.cap - u.issued); }
+            const int k = B ? std::max(0, std::min(32, least_left)) : 0;
             for (int j = 0; j < k; j++) batch_step(c, s, B);
             for (int b = 0; b < B; b++) us[(size_t) slot_utt[(size_t) b]].issued += k;
             std::vector<StepState> st;
@@ -882,14 +902,15 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
                 slot_utt.pop_back();
             }
             if (moved) upload_slot_params(c);
-            progress(c, SEMANTIC, total_steps ? (int) (100ll * done_steps / total_steps) : 100);
+            // admissions grow total_steps: the reported percentage never goes backwards
+            last_pct = std::max(last_pct, total_steps ? (int) (100ll * done_steps / total_steps) : 100);
+            progress(c, SEMANTIC, last_pct);
         }
     }
     c->stats.t_semantic_us = now_us() - t;
 
     // the job's tail on a second stream (JobTail): utterances are handed over as they leave the coarse stage
-    const bool tail_stream_env = !(getenv("BARK_HIP_TAIL_STREAM") && !strcmp(getenv("BARK_HIP_TAIL_STREAM"), "0"));      // read per job: tests flip it
-    JobTail tail(c, us, tail_stream_env && n > 1);
+    JobTail tail(c, us, tail_stream_enabled() && n > 1);
 
     // ---- coarse (bark.cpp:1745-1863): windows in lock step, slots refilled at window boundaries ------------------------------------------
     t = now_us();

@@ -115,7 +115,7 @@ void engine_invalidate_graphs(bark_context * ctx) {
 }
 
 // per-context mutable state: stream, KV caches, activation scratch, GELU table
-static void init_runtime(bark_context * ctxp) {
+static void init_runtime(bark_context * ctxp, bool weights_uploaded_now) {
     struct Holder { bark_context * p; bark_context * get() const { return p; } bark_context * operator->() const { return p; } } ctx{ctxp};
     // ---- KV caches, scratch ------------------------------------------------------------------------
     const int P = ctx->P;
@@ -181,9 +181,10 @@ static void init_runtime(bark_context * ctxp) {
         HIP_OK(hipMemcpyAsync(ctx->d_gelu_lut, lut.data(), 65536 * 2, hipMemcpyHostToDevice, ctx->stream));
         HIP_OK(hipStreamSynchronize(ctx->stream));               // `lut` leaves scope
     }
-    // everything the load put on the legacy stream (weight uploads) or on this one is in place before the first kernel of the non-blocking stream
+    // everything the load put on the legacy stream (weight uploads) or on this one is in place before the first kernel of the non-blocking stream;
+    // a clone shares weights that are long in place and must not stall the other streams of a running server with a device-wide synchronisation
     HIP_OK(hipStreamSynchronize(ctx->stream));
-    HIP_OK(hipDeviceSynchronize());
+    if (weights_uploaded_now) HIP_OK(hipDeviceSynchronize());
 }
 
 // bark_load_model_from_file (bark.cpp:1080-1163): parse the container, upload every tensor of the hot path.
@@ -478,7 +479,7 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         cm.codebooks = cb;
     }
 
-    init_runtime(ctx.get());
+    init_runtime(ctx.get(), true);
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, ctx->device));
     char buf[512];
@@ -510,7 +511,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
     ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4; ctx->any_w32 = src->any_w32;
     HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    init_runtime(ctx.get());
+    init_runtime(ctx.get(), false);
     ctx->description = src->description + " (clone)";
     return ctx.release();
 }

@@ -483,6 +483,18 @@ def main():
         out["roofline_fine_pass"] = {"bound": "mfma", "achieved": flops / (fus * 1e-6) / 1e12, "unit": "TFLOP/s", "us_per_pass": fus,
                                      "peak_note": "products (%.0f %% of the flops) run at the f16 rate (peak 2500), the attention at the f32 rate (peak 157.3)" % (100.0 * (1 - att_flops / flops) if att_flops else 0),
                                      "frac_of_f16_mfma_peak_2500TF": flops / (fus * 1e-6) / 2.5e15, "frac_of_f32_mfma_peak_157TF": flops / (fus * 1e-6) / 157.3e12}
+        # north_star's phrasing ("HBM roofline on the fine-model forward"), SURVEY.md 8(d): algorithmic bytes of one pass = the fine model's weights
+        # + the window ids in + the picks out, over the pass time and the 8 TB/s datasheet rate.  The pass is MFMA-bound (arithmetic intensity
+        # flops / bytes ~ 1.2 k FLOP/B against a ridge of ~ 312): the >= 40 % HBM target cannot apply to it, the MFMA fractions above are the binding ones
+        hp2 = ctx.hparams(2)
+        fine_bytes = None
+        if hp2["ftype"] == 1:            # f16 file: 2 bytes per weight (171.5 MB at bark-small)
+            fine_bytes = 2.0 * (12.0 * hp2["n_layer"] * hp2["n_embd"] ** 2 + hp2["n_out"] * hp2["n_embd"]) + 8 * 1024 * 4 + 1024 * 4
+        if fine_bytes:
+            out["roofline_fine_pass"].update({"hbm_algorithmic_bytes": fine_bytes, "hbm_achieved_GBps": fine_bytes / (fus * 1e-6) / 1e9,
+                                              "hbm_frac": fine_bytes / (fus * 1e-6) / 8.0e12, "arithmetic_intensity_flop_per_byte": flops / fine_bytes,
+                                              "hbm_target_note": "north_star's >= 40 % HBM roofline on the fine forward is inapplicable: at ~1.2 k FLOP/B the pass is bound by the matrix cores, "
+                                                                 "not by memory (ridge ~312 FLOP/B at 2.5 PFLOP/s over 8 TB/s); hbm_frac is reported for completeness"})
         # the pass a lock-step batch runs: the fine windows of 8 utterances side by side (engine_fine_many)
         fus8, flops8 = ctx.time_fine_pass(3, 8)
         out["roofline_fine_pass"]["eight_windows_side_by_side"] = {"us_per_window": fus8 / 8, "achieved": flops8 / (fus8 * 1e-6) / 1e12,

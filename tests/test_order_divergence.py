@@ -1,0 +1,46 @@
+"""How far the matrix-core orders (C1m: fine model, C9m: codec convolutions - oracle/mfma_f16_emu.h) sit from the reference restatement.
+
+The reference accumulates f16 products in f32 (ggml's f16 dot / im2col + mul_mat); the oracle restates that as
+the orders C1 / C9 (`set_fine_mfma(False)`, `set_codec_mfma(False)`), and THAT mode is the restatement of the reference.  The engine's default
+for the fine model and the codec is the arithmetic of `v_mfma_f32_32x32x16_f16` (C1m / C9m), which the oracle emulates bit for bit - so
+"bit-exact against the oracle" pins indexing, layout and control flow there, while agreement with the reference's own arithmetic is a
+TOLERANCE statement.  This file is that statement, measured between the oracle's two modes on the same inputs (round 4's review: the two
+orders were each only tested against themselves):
+
+  * fine logits of one forward pass: max |diff| <= 2.5e-3 (f16 rounding noise of the activations; measured 3e-4 toy, 8e-4 mini, scale 1.2 - 1.6)
+  * greedy pick per position: agreement >= 99.5 % per pass (measured 99.9 - 100 %)
+  * fine stage on the same coarse ids: >= 98 % of the ids equal (measured 100 % toy, 99.7 % mini; a flipped id feeds later codebooks)
+  * codec on the same codes: SNR >= 55 dB, max |diff| <= 2e-2 at a peak of 5 - 6 (measured 63 - 66 dB, 5.6e-3)
+
+bark-small on the device (BARK_HIP_CROSSCHECK=1280 keeps C1 / C9 there): profiles/r05_order_divergence_small.txt.
+Reference: /root/reference/bark.cpp:1416-1584 (fine graph), encodec.cpp's decoder."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("preset", ["toy", "mini"])
+def test_matrix_core_orders_stay_within_tolerance_of_the_reference_restatement(preset, toy_oracle, mini_oracle):
+    o = toy_oracle if preset == "toy" else mini_oracle
+    rng = np.random.default_rng(7)
+    tok = rng.integers(0, 1024, size=(8, 1024)).astype(np.int32)
+    try:
+        for nn in (2, 5, 7):
+            o.set_fine_mfma(True); a = np.asarray(o.fine_eval(tok, nn))
+            o.set_fine_mfma(False); b = np.asarray(o.fine_eval(tok, nn))
+            assert np.abs(a - b).max() <= 2.5e-3, f"fine logits nn={nn}: {np.abs(a - b).max()}"
+            agree = (a[:, :1024].argmax(1) == b[:, :1024].argmax(1)).mean()
+            assert agree >= 0.995, f"greedy picks nn={nn}: {agree}"
+        coarse = rng.integers(0, 1024, size=(300, 2)).astype(np.int32)
+        p = o.params(temp=0.0, fine_temp=0.0)
+        o.set_fine_mfma(True); fa = np.asarray(o.fine(coarse, p))
+        o.set_fine_mfma(False); fb = np.asarray(o.fine(coarse, p))
+        assert np.array_equal(fa[:, :2], fb[:, :2])                  # the coarse codebooks pass through
+        assert (fa == fb).mean() >= 0.98, f"fine ids: {(fa == fb).mean()}"
+        codes = np.ascontiguousarray(fb.T)
+        o.set_codec_mfma(True); pa = np.asarray(o.codec_decode(codes))
+        o.set_codec_mfma(False); pb = np.asarray(o.codec_decode(codes))
+        err = pa - pb
+        snr = 10 * np.log10(float((pb.astype(np.float64) ** 2).sum()) / max(float((err.astype(np.float64) ** 2).sum()), 1e-30))
+        assert snr >= 55.0 and np.abs(err).max() <= 2e-2, f"codec: SNR {snr:.1f} dB, max |diff| {np.abs(err).max()}"
+    finally:
+        o.set_fine_mfma(True); o.set_codec_mfma(True)
