@@ -256,8 +256,6 @@ __global__ __launch_bounds__(256) void attn_fused_ps_kernel(const AttnDecodeArgs
 // leading parameters: what the first loads need (preloaded into SGPRs at wave launch, see gemv_kernel in kernels.hip)
 // ------------------------------------------------------------------------------------------------
 constexpr int SNEW_WAVE = 3;                                    // last wave of the first key group: owns keys in every context, never mixes
-// NW (opt-in, BARK_HIP_WPREFETCH): the waves that do not mix touch the weight rows a later kernel of the step will stream (NextWeights, kernels.h)
-template <bool NW>
 __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict__ ps, const float * __restrict__ vt, const StepState * __restrict__ st,
                                                       const float * __restrict__ knew, const float * __restrict__ q, const int H, const int ng, const AttnDecodeArgs a) {
     TRACE_T0();
@@ -271,11 +269,7 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
     __shared__ float snew;
     const int g8 = blockIdx.x >> 3, x8 = blockIdx.x & 7;          // slices of a head get ids congruent mod 8 (same XCD), as attn_dslice_kernel
     const int h = x8 + 8 * (g8 / S), s = g8 % S;
-    [[maybe_unused]] unsigned nw_sink = 0;
-    if (h >= H) {                                                   // padding workgroups of the last head group
-        if constexpr (NW) { prefetch_next_weights(a.nw, threadIdx.x, 1024, nw_sink); prefetch_sink_hold(nw_sink); }     // (their share of the XCD's slices would otherwise stay cold)
-        return;
-    }
+    if (h >= H) return;                                             // padding workgroups of the last head group
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // every stream is a buffer load: uniform base + lane offset + scalar offset (device_utils.h).  The keys below 256 ng (the launch's
@@ -312,7 +306,6 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
     float sc = -INFINITY;
     if (tid < ctx - 1) sc = ((p4.x + p4.y) + (p4.z + p4.w)) * 0.125f;
     *reinterpret_cast<float4 *>(vl + tid * DS) = va;
-    if constexpr (NW) { if (a.nw.early) prefetch_next_weights(a.nw, tid, 1024, nw_sink); }
     [[maybe_unused]] unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;     // diagnostic build: score ready, softmax statistics ready, mix done
     TRACE_SET(stamp0, sc);
     float mx = fmaxf(wave_max(sc), s_new);
@@ -352,8 +345,6 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
         TRACE_SET(stamp2, acc);
         part[chain][d] = acc;
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
-    } else if constexpr (NW) {
-        if (!a.nw.early) prefetch_next_weights(a.nw, tid - 16 * DS, 1024 - 16 * DS, nw_sink, e);        // 15 waves with nothing left to do but the last barrier
     }
     __syncthreads();
     if (tid < DS) {
@@ -367,7 +358,6 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
         const int o = h * 64 + DS * s + tid;
         if (a.att32) a.att32[o] = p[0]; else a.att[o] = to_half(p[0]);
     }
-    if constexpr (NW) prefetch_sink_hold(nw_sink);
 #ifdef BARK_TRACE
     trace_emit(a.tr, _tr0, _tr1, stamp2, trace_clock(), stamp0, stamp1);
 #endif
@@ -497,8 +487,7 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
         if (a.nbatch != 1 || a.P != 1024) { kernel_fail("bark-hip: partial-score decode attention needs one sequence and block_size 1024"); }
         if (!a.knew) kernel_fail("bark-hip: partial-score decode attention needs the fixed-address copy of the appended K row");
         if (!a.vt) kernel_fail("bark-hip: partial-score decode attention needs the K-layout copy of V");
-        if (a.nw.base) hipLaunchKernelGGL(attn_ps_kernel<true>, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
-        else           hipLaunchKernelGGL(attn_ps_kernel<false>, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
+        hipLaunchKernelGGL(attn_ps_kernel, dim3(8 * 16 * ((a.H + 7) / 8)), dim3(1024), 0, s, a.ps, a.vt, a.st, a.knew, a.q, a.H, std::max(1, std::min(a.ng, 4)), a);
         return;
     }
     // lock-step batches with more (head, slot) pairs than CUs: scores and softmax + mix as two launches.  Measured per call at 8 / 16 / 32

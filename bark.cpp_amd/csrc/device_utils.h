@@ -205,33 +205,6 @@ DEVINL float4 buf_ld_f4(const BufRsrc & r, unsigned lane_bytes, unsigned scalar_
     return float4{u.x, u.y, u.z, u.w};
 }
 
-// NextWeights (kernels.h): touch the slices of the later kernel's workgroups that will run on this workgroup's XCD.  The loads are
-// inline asm and nobody waits for them (s_endpgm drains the wave's memory counters).  Two things keep that safe:
-//   * returns are in order, so a wait the compiler placed for an older load can only wait longer, never too little;
-//   * the destination register must not be given to another value while a request is in flight: every request reads and writes ONE
-//     variable (`sink`, a tied operand), and the kernel names it once more in its last statement (prefetch_sink_hold), so its live range
-//     spans everything behind the first request.  tests/test_prefetch_isa.py checks the compiled code for exactly that.
-// `after`: a value the requests must not be scheduled in front of (the asm names it as an operand): the wave's finished dot product when
-// the requests are to follow the arrival of its own operands.
-DEVINL void prefetch_next_weights(const NextWeights & nw, unsigned tid, unsigned n_threads, unsigned & sink, float after = 0.0f) {
-    if (!nw.base) return;
-    const unsigned G = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned i = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned x = i & 7u, np = (G - x + 7u) >> 3;           // producers of this launch on XCD x
-    const unsigned step = n_threads * nw.stride;
-    const unsigned per = 1u << nw.group_shift, n_groups = nw.n_wg >> nw.group_shift;
-    const size_t pitch = nw.slice_stride ? nw.slice_stride : nw.wg_bytes;
-    for (unsigned s = i >> 3; x + 8u * s < n_groups; s += np) {
-        for (unsigned sub = 0; sub < per; sub++) {
-            const char * p = static_cast<const char *>(nw.base) + (size_t) (((x + 8u * s) << nw.group_shift) + sub) * pitch;
-            #pragma unroll 1
-            for (unsigned off = tid * nw.stride; off < nw.wg_bytes; off += step)
-                asm volatile("global_load_dword %0, %1, off ; NWPF" : "+v"(sink) : "v"(p + off), "v"(after));
-        }
-    }
-}
-DEVINL void prefetch_sink_hold(unsigned sink) { asm volatile("; NWPF hold %0" :: "v"(sink)); }
-
 // C2: one 16-d block of an attention score: kq = the block's four d-quads of the key, qb = the block's 16 q values; one fmaf chain
 DEVINL float score_block_f4(const float4 * kq, const float * qb) {
     float acc = 0.0f;

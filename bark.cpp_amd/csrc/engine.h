@@ -84,6 +84,7 @@ struct bark_context {
     std::shared_ptr<SharedWeights> weights;
     size_t weight_bytes = 0;
     std::vector<void *> allocs;                         // everything else (freed in destroy)
+    std::vector<std::pair<void *, size_t>> guarded;     // BARK_HIP_GUARD: {base of the allocation, bytes between its two guard bands}
     // GPT scratch
     float * x = nullptr, * q = nullptr, * logits = nullptr;
     float * knew = nullptr;                             // [E] K row appended by the current decode step (fixed-address copy)

@@ -110,78 +110,37 @@ void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float *
     }
 }
 
-int weight_prefetch_mode() {
-    static const int mode = [] { const char * e = getenv("BARK_HIP_WPREFETCH"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : 0; }();
-    return mode;
-}
-// the slices a later decode GEMV's workgroups will stream: rows_per_wg = 16 (gemv_ln_wg_kernel) or 4 (gemv_kernel) rows of K f16 each
-NextWeights next_weights(const half_t * W, int rows, int K, int rows_per_wg) {
-    static const int stride = [] { const char * e = getenv("BARK_HIP_WPREFETCH_STRIDE"); const int v = e ? atoi(e) : 128; return v >= 4 && v <= 4096 && v % 4 == 0 ? v : 128; }();
-    static const int early = getenv("BARK_HIP_WPREFETCH_EARLY") ? atoi(getenv("BARK_HIP_WPREFETCH_EARLY")) : 0;
-    NextWeights nw;
-    if (!W || rows < rows_per_wg) return nw;
-    nw.base = W; nw.wg_bytes = (unsigned) (rows_per_wg * K * 2); nw.n_wg = (unsigned) (rows / rows_per_wg); nw.stride = (unsigned) stride; nw.early = early ? 1 : 0;
-    return nw;
-}
-
-NextWeights next_k_quads(const float * k_layer, int E, int P, int ng) {
-    static const int on = getenv("BARK_HIP_KPREFETCH") ? atoi(getenv("BARK_HIP_KPREFETCH")) : 0;
-    NextWeights nw;
-    // q workgroup w (16 rows of q = one C2 block of one head) and its copies run on XCD w % 8 when the main workgroups (3 E / 16) and the q
-    // workgroups (E / 16) both come in multiples of 8 (gemv_ln_wg_kernel<PS>); its four d-quad rows are rows 4 w .. 4 w + 3 of [H * 16][P] float4
-    if (!on || !weight_prefetch_mode() || !k_layer || P != 1024 || (E / 16) % 8 != 0 || (3 * E / 16) % 8 != 0) return nw;
-    const NextWeights tmpl = next_weights(reinterpret_cast<const half_t *>(k_layer), 16, 128, 16);      // stride / early as configured
-    nw.base = k_layer; nw.wg_bytes = (unsigned) (256 * std::max(1, std::min(ng, 4)) * 16); nw.n_wg = (unsigned) (E / 4); nw.slice_stride = (unsigned) (P * 16); nw.group_shift = 2;
-    nw.stride = tmpl.stride; nw.early = tmpl.early;
-    return nw;
-}
-
 // one token through all layers; position / token come from the device-resident StepState
-void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_head_nw) {
+void run_layers_decode(bark_context * c, GptModel & m) {
     const int E = m.hp.n_embd, H = m.hp.n_head, P = c->P;
     hipStream_t s = c->stream;
-    // opt-in experiment: kernel i asks for the weights of kernel i + wpf of the chain QKV, attention, proj, FC, MLP proj, QKV', ... (f16 files)
-    const int wpf = (!m.q4 && !m.w32 && E <= 1024) ? weight_prefetch_mode() : 0;
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
-        NextWeights nw_qkv, nw_attn, nw_proj, nw_fc, nw_mproj, nw_knext;
         const bool ps = !(crosscheck_mask() & 4) && !m.w32 && P == 1024 && m.vtcache && E <= 1024;
-        if (wpf) {
-            const bool last = l + 1 == m.hp.n_layer;
-            const NextWeights w_proj = next_weights(L.proj_w, E, E, 4), w_fc = next_weights(L.fc_w, 4 * E, E, 16), w_mproj = next_weights(L.mproj_w, E, 4 * E, 4);
-            const NextWeights w_next = last ? (lm_head_nw ? *lm_head_nw : NextWeights{}) : next_weights(m.layers[(size_t) l + 1].attn_w, 3 * E, E, 16);
-            if (wpf == 1) { nw_attn = w_proj; nw_proj = w_fc; nw_fc = w_mproj; nw_mproj = w_next; }
-            else          { nw_qkv = w_proj; nw_attn = w_fc; nw_proj = w_mproj; nw_fc = w_next; }
-            if (!last && ps) nw_knext = next_k_quads(layer_k(m, l + 1), E, P, c->decode_ng);        // rides with the next layer's QKV rows
-        }
         LinArgs a;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = c->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = c->q; a.kc = layer_k(m, l); a.vc = layer_v(m, l); a.vt = layer_vt(m, l); a.E = E; a.P = P; a.pos0 = 0; a.st = c->d_state;
         // f16 weights: the QKV kernel also forms the partial scores of the cached keys (C2 blocks), attn_ps_kernel finishes them
         if (ps) { a.ps = c->ps; a.knew = c->knew; a.ng = c->decode_ng; }
-        a.nw = nw_qkv;
         BARK_TRACE_SET(c, a, (a.M + 3) / 4 + 4 * (E / 4));        // room for all four copies of the q workgroups
         launch_linear(s, a);
         AttnDecodeArgs at;
         at.q = c->q; at.kc = layer_k(m, l); at.vc = layer_v(m, l); at.H = H; at.P = P; at.st = c->d_state; at.att = c->att;
         at.att32 = m.q4 ? c->att32 : nullptr;
-        if (ps) { at.ps = c->ps; at.knew = c->knew; at.ng = c->decode_ng; at.vt = layer_vt(m, l); at.nw = nw_attn; }
+        if (ps) { at.ps = c->ps; at.knew = c->knew; at.ng = c->decode_ng; at.vt = layer_vt(m, l); }
         BARK_TRACE_SET(c, at, 8 * 16 * ((H + 7) / 8) * 16);      // up to 16 slices per head, 16 waves per workgroup
         launch_attn_decode(s, at);
         LinArgs p;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = c->att32; else p.x_f16 = c->att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = c->x;
-        p.nw = nw_proj;
         BARK_TRACE_SET(c, p, (p.M + 3) / 4);
         launch_linear(s, p);
         LinArgs f;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = c->x; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = c->hbuf; f.out_h32 = m.q4 ? c->h32 : nullptr; f.lut = c->d_gelu_lut;
-        f.nw = nw_fc; if (wpf == 2) f.nw2 = nw_knext;
         BARK_TRACE_SET(c, f, (f.M + 3) / 4);
         launch_linear(s, f);
         LinArgs o;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = c->h32; else o.x_f16 = c->hbuf; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = c->x;
-        o.nw = nw_mproj; if (wpf == 1) o.nw2 = nw_knext;
         BARK_TRACE_SET(c, o, (o.M + 3) / 4);
         launch_linear(s, o);
     }
@@ -195,11 +154,6 @@ void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, i
     a.M = n_rows; a.K = m.hp.n_embd; a.N = 1;
     a.x_f32 = xrow; a.ln_g = m.lnf_g; a.ln_b = m.lnf_b; a.epi = EPI_LOGITS; a.out = c->logits; a.ld_out = n_rows;
     a.parity_rows = parity_rows; a.st = c->d_state; a.out_div = out_div;
-    // opt-in experiment: the head asks for the first layer's QKV rows of the NEXT step (the sampler between them is one workgroup)
-    if (!m.q4 && !m.w32 && m.hp.n_embd <= 1024 && weight_prefetch_mode()) {
-        a.nw = next_weights(m.layers[0].attn_w, 3 * m.hp.n_embd, m.hp.n_embd, 16);
-        if (!(crosscheck_mask() & 4) && m.vtcache) a.nw2 = next_k_quads(layer_k(m, 0), m.hp.n_embd, c->P, c->decode_ng);
-    }
     BARK_TRACE_SET(c, a, (a.M + 3) / 4);
     launch_linear(c->stream, a);
 }
@@ -282,13 +236,7 @@ void enqueue_decode_step(bark_context * c, const StageCfg & s, bool sample, int 
         e.wte = m.wte[0]; e.wte_q = m.wte_q[0]; e.wpe = m.wpe; e.E = m.hp.n_embd; e.n_in = m.hp.n_in_vocab; e.P = c->P; e.n_rows = 1; e.st = c->d_state; e.x = c->x;
         launch_embed_causal(c->stream, e);
     }
-    // (opt-in weight prefetch: the last layer asks for the head's rows - both parity windows of the coarse head, whose workgroups j and
-    // j + parity_rows / 16 share an XCD when parity_rows is a multiple of 128)
-    NextWeights head_nw;
-    if (weight_prefetch_mode() && !m.q4 && !m.w32 && (s.parity_rows % 128) == 0)
-        head_nw = next_weights(m.lm_head[0] + (size_t) s.lm_row0 * m.hp.n_embd, std::min(s.parity_rows ? s.lm_rows + s.parity_rows : s.lm_rows, m.hp.n_out_vocab - s.lm_row0),
-                               m.hp.n_embd, 16);                   // never beyond the matrix
-    run_layers_decode(c, m, &head_nw);
+    run_layers_decode(c, m);
     // greedy decode step: the LM head divides by 0.7 itself (2512 waves instead of one workgroup doing 10 048 divisions)
     const bool prescale = sample && s.temp == 0.0f;
     run_lm_head(c, m, c->x, s.lm_row0, s.lm_rows, s.parity_rows, prescale ? 0.7f : 0.0f);

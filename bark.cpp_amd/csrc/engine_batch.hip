@@ -30,20 +30,21 @@ namespace {
 
 constexpr int kMaxSlots = 64;                            // lock-step slots of a context (KV caches of both causal models per slot: 151 MB at bark-small)
 
-// BARK_HIP_SLOT_PS=<n> (opt-in experiment, default 0, unmeasured at the end of round 4): lock steps over 2 .. n live slots (f16 files, block_size 1024)
-// run their QKV product per slot as the single-utterance step does - LayerNorm per workgroup, partial scores of the cached keys formed where q is
-// born (gemv_ln_slots_ps_kernel) - and the attention on those scores (attn_fused_ps_kernel) instead of streaming every pair's K through one CU
-int slot_ps_max() {
-    static const int v = [] { const char * e = getenv("BARK_HIP_SLOT_PS"); const int n = e ? atoi(e) : 0; return n >= 2 && n <= kMaxSlots ? n : 0; }();
-    return v;
-}
-
-// BARK_HIP_SLOT_GEMV=<n> (second opt-in experiment, default 0): lock steps over 2 .. n live slots run the FC product per slot on the VALU with the
-// LayerNorm in the workgroup (gemv_ln_slots_ps_kernel<PS = false>) instead of gemm_slots16_kernel<LNF>, and the two out-projections as the
-// single-utterance GEMV with a slot dimension (gemv_slots_kernel) instead of gemv_batch_kernel - a timing question only, same C1 / C6 bits
-int slot_gemv_max() {
-    static const int v = [] { const char * e = getenv("BARK_HIP_SLOT_GEMV"); const int n = e ? atoi(e) : 0; return n >= 2 && n <= kMaxSlots ? n : 0; }();
-    return v;
+// Lock steps over 2 .. kFewSlots live slots (f16 files, n_embd <= 1024, block_size 1024) take the few-slot route: slot-group products (weights requested
+// once per group of 8 slots, kernels.hip: gemv_ln_slotgroup_kernel), the partial attention scores formed where q is born and the attention on them
+// (attn_fused_ps_kernel), out-projections with 8 slots per wave.  Above, the matrix-core tiles of gemm_slots16_kernel and the streaming attention
+// kernels take over.  Cross-over measured on MI355X: profiles/r05_few_slot_routes.txt.  BARK_HIP_FEW_SLOTS=<n> moves it (0: off) - the A/B handle
+// of tools/r05_sweep.py, not a tuning knob.
+// BARK_HIP_FEW_SLOTS=<n>[,<n_attention>]: products / partial-score attention up to that many live slots
+int few_slots_max(int which = 0) {
+    static const std::pair<int, int> v = [] {
+        const char * e = getenv("BARK_HIP_FEW_SLOTS");
+        int n = 16, na = 16;
+        if (e) { n = na = atoi(e); if (const char * k = strchr(e, ',')) na = atoi(k + 1); }
+        auto ok = [](int x) { return x >= 2 && x <= kMaxSlots ? x : 0; };
+        return std::make_pair(ok(n), ok(na));
+    }();
+    return which ? v.second : v.first;
 }
 
 void ensure_batch(bark_context * c, int B) {
@@ -70,7 +71,7 @@ void ensure_batch(bark_context * c, int B) {
     bb.eos_trace = dev_alloc<float>(c, (size_t) B * 2048);
     bb.u = dev_alloc<double>(c, (size_t) B * 8192);
     bb.sc = dev_alloc<float>(c, (size_t) B * c->max_H * c->P);
-    if (slot_ps_max() > 0) bb.ps = dev_alloc<float>(c, (size_t) B * c->max_H * 4 * c->P);
+    if (few_slots_max(1) > 0) bb.ps = dev_alloc<float>(c, (size_t) std::min(B, few_slots_max(1)) * c->max_H * 4 * c->P);
     if (c->any_q4) { bb.att32 = dev_alloc<float>(c, (size_t) B * E); bb.h32 = dev_alloc<float>(c, (size_t) B * 4 * E); }
     bb.slot_par = dev_alloc<float>(c, (size_t) 2 * B);               // [0, B): temperatures, [B, 2 B): min_eos_p
     c->h_slot_par.assign((size_t) 2 * B, 0.0f);
@@ -198,8 +199,10 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.ln_stats = nullptr;
         launch_linear_slots(st, a);
     };
-    // opt-in experiment: QKV per slot with partial scores + attention on them (see slot_ps_max)
-    const bool slot_ps = bb.ps && B >= 2 && B <= slot_ps_max() && !m.q4 && !m.w32 && P == 1024 && E <= 1024 && (E & 127) == 0;
+    // few live slots: slot-group products, partial scores where q is born + the attention on them (see few_slots_max)
+    const bool few_ok = !m.q4 && !m.w32 && P == 1024 && E <= 1024 && (E & 127) == 0 && B >= 2 && !(crosscheck_mask() & 2);
+    const bool few = few_ok && B <= few_slots_max(0);
+    const bool slot_ps = few_ok && bb.ps && B <= few_slots_max(1);
     for (int l = 0; l < m.hp.n_layer; l++) {
         const GptModel::Layer & L = m.layers[(size_t) l];
         float * kl = kc0 + m.kv_layer_stride * (size_t) l, * vl = vc0 + m.kv_layer_stride * (size_t) l;
@@ -208,7 +211,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
-        if (slot_ps) { a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = nullptr; a.ps = bb.ps; launch_linear_slots_ps(st, a); }
+        if (few || slot_ps) { a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = nullptr; if (slot_ps) a.ps = bb.ps; launch_linear_slotgroup(st, a); }
         else product(a, L.ln1_g, L.ln1_b);
         mark("ln1+qkv");
         AttnDecodeArgs at;
@@ -221,21 +224,20 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
-        const bool slot_gemv = B >= 2 && B <= slot_gemv_max() && !m.q4 && !m.w32;
-        if (slot_gemv) launch_linear_slots_gemv(st, p); else product(p, nullptr, nullptr);
+        if (few) { p.slots_per_wave = 8; launch_linear(st, p); } else product(p, nullptr, nullptr);
         mark("proj");
         if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
-        if (B >= 2 && B <= slot_gemv_max() && !m.q4 && !m.w32 && E <= 1024 && (E & 127) == 0) { f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_stats = nullptr; f.E = E; launch_linear_slots_ps(st, f); }
+        if (few) { f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_stats = nullptr; f.E = E; launch_linear_slotgroup(st, f); }
         else product(f, L.ln2_g, L.ln2_b);
         mark("ln2+fc+gelu");
         LinArgs o;
         o.batched = 1; o.nbatch = B;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
-        if (slot_gemv) launch_linear_slots_gemv(st, o); else product(o, nullptr, nullptr);
+        if (few) { o.slots_per_wave = 8; launch_linear(st, o); } else product(o, nullptr, nullptr);
         mark("mlp_proj");
     }
     if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
@@ -244,7 +246,8 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, E); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * E;
     h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
-    product(h, m.lnf_g, m.lnf_b);
+    if (few) { h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.ln_stats = nullptr; h.E = E; launch_linear_slotgroup(st, h); }
+    else product(h, m.lnf_g, m.lnf_b);
     mark("lnf+lm_head");
     launch_sample_greedy(st, slot_sample_args(c, s, bb, 0, B, 1));
     mark("sample+embed");
@@ -660,6 +663,9 @@ struct JobTail {
     static void drop_fine_graphs_of(bark_context * x) { for (auto & g : x->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
     void drop_fine_graphs() { drop_fine_graphs_of(t); }
     void push(const std::vector<int> & utts) {
+        // BARK_HIP_DIAG_NO_TAIL=1 (root-cause runs of round 5 only): no fine passes, no codec - the job returns the semantic and coarse ids
+        static const bool no_tail = getenv("BARK_HIP_DIAG_NO_TAIL") && atoi(getenv("BARK_HIP_DIAG_NO_TAIL")) != 0;
+        if (no_tail) { for (int b : utts) { c->batch_results[(size_t) b].ok = true; good++; } return; }
         if (utts.empty()) return;
         { std::lock_guard<std::mutex> g(mu); for (int b : utts) pending.push_back(b); }
         cv.notify_all();
@@ -1055,6 +1061,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
 
     // ---- fine + codec: whatever the helper has not finished yet (everything, without a second stream) ------------------------------------
     tail.finish();
+    if (guard_allocations()) { (void) guard_check(c, "end of a lock-step job"); if (c->tail) (void) guard_check(c->tail, "end of a lock-step job, tail clone"); }
     if (tail.t != c) progress(c, FINE, 100);                         // the helper reports nothing (the callback belongs to the calling thread)
     const int good = tail.good;
     c->stats.t_eval_us = now_us() - t0;

@@ -37,9 +37,27 @@ inline bool poison_allocations() {
     static const bool v = getenv("BARK_HIP_POISON") && atoi(getenv("BARK_HIP_POISON")) != 0;
     return v;
 }
+// BARK_HIP_GUARD=1 (diagnostic): every run-time allocation sits between two 64 KB guard bands filled with 0xA5; guard_check() (engine_load.hip)
+// verifies them at the end of every lock-step job and when the context is freed - a write of any kernel of the process that lands just outside one of
+// this context's buffers (or runs over from a neighbour) is reported on stderr with the buffer's index and the offset
+constexpr size_t kGuardBytes = 64 * 1024;
+inline bool guard_allocations() {
+    static const bool v = getenv("BARK_HIP_GUARD") && atoi(getenv("BARK_HIP_GUARD")) != 0;
+    return v;
+}
 template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
     void * p = nullptr;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (guard_allocations() && ctx->stream) {
+        const size_t body = (bytes + 255) & ~(size_t) 255;
+        HIP_OK(hipMalloc(&p, body + 2 * kGuardBytes));
+        ctx->allocs.push_back(p);
+        ctx->guarded.push_back({p, body});
+        HIP_OK(hipMemsetAsync(p, 0xA5, body + 2 * kGuardBytes, ctx->stream));
+        if (poison_allocations()) HIP_OK(hipMemsetAsync((char *) p + kGuardBytes, 0xFF, body, ctx->stream));
+        HIP_OK(hipStreamSynchronize(ctx->stream));
+        return (T *) ((char *) p + kGuardBytes);
+    }
     HIP_OK(hipMalloc(&p, bytes));
     ctx->allocs.push_back(p);
     if (poison_allocations() && ctx->stream) {
@@ -48,6 +66,7 @@ template <typename T> T * dev_alloc(bark_context * ctx, size_t count) {
     }
     return (T *) p;
 }
+int guard_check(bark_context * ctx, const char * where);      // number of damaged guard bands (0 without BARK_HIP_GUARD)
 
 // device -> host on the context's own (non-blocking) stream, complete on return: never the legacy stream, which refuses work while ANY blocking
 // stream of the process captures a graph (other contexts on other host threads do)
@@ -79,15 +98,7 @@ bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool 
 // seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
                      const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0, const SeqTab * seqtab = nullptr);
-void run_layers_decode(bark_context * c, GptModel & m, const NextWeights * lm_head_nw = nullptr);
-// BARK_HIP_WPREFETCH (opt-in experiment, default 0): 1 / 2 = every decode kernel of a single-utterance step asks for the weight rows of the
-// kernel one / two places behind it (NextWeights, kernels.h); BARK_HIP_WPREFETCH_STRIDE (bytes between touched words, default 128),
-// BARK_HIP_WPREFETCH_EARLY=1 (ask before the own operands have arrived instead of after)
-int weight_prefetch_mode();
-NextWeights next_weights(const half_t * W, int rows, int K, int rows_per_wg);
-// BARK_HIP_KPREFETCH=1 (with BARK_HIP_WPREFETCH): the kernel that asks for a layer's QKV rows also asks for the K quads the partial-score copies of
-// that QKV kernel will stream (the first 256 ng keys of every d-quad row of the layer's K cache)
-NextWeights next_k_quads(const float * k_layer, int E, int P, int ng);
+void run_layers_decode(bark_context * c, GptModel & m);
 void run_lm_head(bark_context * c, GptModel & m, const float * xrow, int row0, int n_rows, int parity_rows, float out_div = 0.0f);
 void set_state(bark_context * c, const StepState & st);
 StepState get_state(bark_context * c);

@@ -78,6 +78,7 @@ float gelu_tanh_host(float x) {
 bark_context::~bark_context() {
     delete tail;
     (void) hipSetDevice(device);
+    try { (void) barkhip::detail::guard_check(this, "bark_free"); } catch (...) { }
     for (auto & g : gpt) {
         for (auto & e : g.decode_graph) if (e) (void) hipGraphExecDestroy(e);
         for (auto & e : g.decode_graph8) if (e) (void) hipGraphExecDestroy(e);
@@ -101,6 +102,32 @@ bark_context::SharedWeights::~SharedWeights() {
 }
 
 namespace barkhip {
+
+namespace detail {
+int guard_check(bark_context * ctx, const char * where) {
+    if (ctx->guarded.empty() || !ctx->stream) return 0;
+    int bad = 0;
+    std::vector<unsigned char> h(kGuardBytes);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->guarded.size(); i++) {
+        for (int side = 0; side < 2; side++) {
+            const char * g = (const char *) ctx->guarded[i].first + (side ? kGuardBytes + ctx->guarded[i].second : 0);
+            HIP_OK(hipMemcpyAsync(h.data(), g, kGuardBytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_OK(hipStreamSynchronize(ctx->stream));
+            size_t first = kGuardBytes, n = 0;
+            for (size_t k = 0; k < kGuardBytes; k++) if (h[k] != 0xA5) { if (first == kGuardBytes) first = k; n++; }
+            if (n) {
+                bad++;
+                fprintf(stderr, "bark-hip GUARD DAMAGED (%s, ctx %p): allocation %zu (%zu bytes), %s band: %zu bytes overwritten, first at offset %zu (value 0x%02x)\n",
+                        where, (void *) ctx, i, ctx->guarded[i].second, side ? "upper" : "lower", n, first, h[first]);
+                HIP_OK(hipMemsetAsync((void *) g, 0xA5, kGuardBytes, ctx->stream));          // report once
+            }
+        }
+    }
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    return bad;
+}
+}  // namespace detail
 
 void engine_invalidate_graphs(bark_context * ctx) {
     if (ctx->tail) engine_invalidate_graphs(ctx->tail);       // the clone that runs the tail of lock-step jobs replays graphs with the same constants

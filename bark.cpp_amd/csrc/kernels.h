@@ -56,14 +56,6 @@ struct TraceSink { unsigned long long * rec = nullptr; unsigned * pos = nullptr;
 // of every activation, continue its cache (utterance slot `slot`) at position pos0; rows len .. seq - 1 are padding
 struct SeqTab { int slot, pos0, len, pad; };
 
-// Opt-in experiment (BARK_HIP_WPREFETCH, engine.hip: plan_weight_prefetch): a decode kernel asks for the weight rows a LATER kernel of the
-// step will stream, so that they wait in the XCD's L2 when that kernel starts.  Consumer workgroup j reads the wg_bytes at base + j wg_bytes
-// and runs on XCD j % 8 (round-robin dispatch), so the producer workgroups of XCD x touch the slices of the consumers j % 8 == x: one dword
-// per `stride` bytes, results discarded.  Results cannot change (loads only); default off until measured on the device.
-// Strided form (the K quads the partial-score copies of the next QKV kernel stream, BARK_HIP_KPREFETCH): slice j starts at base + j slice_stride
-// (0: wg_bytes, slices back to back) and 2^group_shift consecutive slices belong to ONE consumer workgroup, i.e. slice j sits on XCD (j >> group_shift) % 8.
-struct NextWeights { const void * base = nullptr; unsigned wg_bytes = 0, n_wg = 0, stride = 128; int early = 0; unsigned slice_stride = 0, group_shift = 0; };
-
 enum LinEpi { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3, EPI_QKV16 = 4 };      // EPI_QKV16: tolerance route only (fast_kernels.hip)
 
 // One linear operator  y[n][m] = epi( C1dot(W[m], x[n]) + bias[m] )  for n < N, m < M.
@@ -105,6 +97,7 @@ struct LinArgs {
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
+    int slots_per_wave = 2;               // batched rows that are f16 already (gemv_batch_kernel): 2, 4 or 8 slots share the weight chunks of a wave
     // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order
     // (gemm_f16_tile_kernel, fast_kernels.hip).  Same operands and roundings as the canonical product (R1), only the ORDER of the f32
     // additions differs from C1: results agree to f32 rounding noise, not bit for bit, so this route is never the one the parity tests check.
@@ -116,18 +109,16 @@ struct LinArgs {
     // n / seq, whose cache starts kv_slot_stride floats behind its predecessor's - or, with seqtab, position seqtab[z].pos0 + n % seq of the
     // cache of slot seqtab[z].slot (rows at or beyond seqtab[z].len are padding and store nothing)
     const SeqTab * seqtab = nullptr;
-    NextWeights nw, nw2;                  // decode GEMVs (N == 1, f16 weights) only
     BARK_TRACE_FIELD
 };
 void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
 void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel; x_f32 + ln_g: the LayerNorm of the rows fused (when linear_slots_fuses_ln(K))
 bool linear_slots_fuses_ln(int K);
-// opt-in experiment (BARK_HIP_SLOT_PS): the QKV product of a lock step at few slots per slot as in the single-utterance step, forming the partial scores
-// of the cached keys (a.ps: [nbatch][H][4][P]) that attn_fused_ps_kernel finishes; a.x_f32 [nbatch][K] + LayerNorm, batched EPI_QKV epilogue
-void launch_linear_slots_ps(hipStream_t s, const LinArgs & a);
-// BARK_HIP_SLOT_GEMV: the out-projections of a few-slot lock step as the single-utterance GEMV with a slot dimension (a.x_f16 [nbatch][K])
-void launch_linear_slots_gemv(hipStream_t s, const LinArgs & a);
+// lock steps at few slots: LayerNorm-fused products with a GROUP of up to 8 slots inside the workgroup (gemv_ln_slotgroup_kernel: weight rows requested
+// once per group); a.x_f32 [nbatch][K] + LayerNorm, any batched epilogue, parity windows; a.ps set (QKV): copies of the q workgroups form the partial
+// scores of the cached keys (a.ps: [nbatch][H][4][P]) that attn_fused_ps_kernel finishes
+void launch_linear_slotgroup(hipStream_t s, const LinArgs & a);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {
@@ -162,7 +153,6 @@ struct AttnDecodeArgs {
     const float * ps = nullptr;           // [H][4][P] partial scores of the cached keys from the QKV kernel (LinArgs::ps); nullptr: scores are formed here
     int nbatch = 1; size_t kv_slot_stride = 0;   // batched decode: slot b uses q/att + b*E, st[b], kc/vc + b*kv_slot_stride
     float * sc = nullptr;                  // lock-step batches: [nbatch][H][P] scores between attn_slots_scores_kernel and attn_slots_mix_kernel (nullptr: attn_fused_kernel)
-    NextWeights nw;                        // attn_ps_kernel only
     BARK_TRACE_FIELD
 };
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a);      // a.ps set: attn_ps_kernel; otherwise attn_fused_kernel (one workgroup per head and slot)

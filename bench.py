@@ -157,31 +157,7 @@ def cpu_baseline_leg(model_path: str, prompt: str, n_semantic: int) -> dict:
                                    "fine": ref["t_predict_fine_us"] / 1000.0 / max(1, ref["n_sample_fine"])}}
 
 
-EXPERIMENT_CHILD = r"""
-import sys, json, time, hashlib
-sys.path.insert(0, %r)
-import numpy as np
-from bark_amd_loader import load_package
-pkg = load_package()
-ctx = pkg.BarkContext.load_model(%r, pkg.default_params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=%d), 0)
-texts = %r
-assert ctx.generate_audio(texts[0])
-h = hashlib.sha256()
-t0 = time.perf_counter(); audio = 0.0
-for t in texts[1:]:
-    assert ctx.generate_audio(t)
-    audio += ctx.stats()["n_samples"] / 24000.0
-    for a in (ctx.semantic_tokens(), ctx.coarse_tokens(), ctx.fine_tokens(), ctx.audio_data()):
-        h.update(np.ascontiguousarray(a).tobytes())
-dt = time.perf_counter() - t0
-st = ctx.stats()
-print("RESULT " + json.dumps({"rtf": audio / dt, "sha256_ids_and_pcm": h.hexdigest(), "decode_step_us": {str(c): round(ctx.time_decode_step(0, c, 400)[0], 2) for c in (300, 640)},
-                              "semantic_ms_per_token": st["t_semantic_us"] / 1000.0 / max(1, st["n_sample_semantic"])}))
-ctx.free()
-"""
-
-
-EXPERIMENT_JOB_CHILD = r"""
+FEW_SLOT_JOB_CHILD = r"""
 import sys, json, time, hashlib
 sys.path.insert(0, %r)
 import numpy as np
@@ -218,70 +194,26 @@ ctx.free()
 """
 
 
-def job_experiments_leg(path: str, prompts, n_semantic: int, deadline: float = float("inf")) -> dict:
-    """Opt-in, not yet measured switches of the lock-step path, each arm a process of its own: a job of 3 x slots prompts on 8 / 16 slots (the
-    per-GPU share of config 5 at N = 8 / N = 4), prompts/s and bit-equality with the default arm of the same slot count.
-    BARK_HIP_SLOT_PS: per-slot QKV with partial scores + attention on them (engine_batch.hip: slot_ps_max); BARK_HIP_SLOT_GEMV: the FC product
-    per slot on the VALU as well (slot_gemv_max)."""
+def few_slot_jobs_leg(path: str, prompts, n_semantic: int, deadline: float = float("inf")) -> dict:
+    """Config 5's per-GPU share at N = 8 / N = 4: a job of 3 x slots prompts on a context with 8 / 16 lock-step slots (a process of its own per
+    slot count: the slot count of a context is fixed by its first job), prompts/s, stage times and the per-site time line of one lock step.
+    These are the points the strong-scaling curve of the 64-prompt job passes through."""
     import subprocess
     out = {}
-    for slots, ragged in ((8, 0), (16, 0), (64, 1)):
-        # 3 x slots equal prompts on 8 / 16 slots; on 64 slots the ragged form of config 5 (caps 64 .. 256 by prompt length: the live slot count falls
-        # through 16 .. 2 in the job's tail, where the experimental route takes over)
-        texts = list(prompts) if ragged else [prompts[i % len(prompts)] for i in range(3 * slots)]
-        ref = None
-        arms = [("default", {}), ("slot_ps", {"BARK_HIP_SLOT_PS": str(min(slots, 16))})]
-        if not ragged:
-            arms.append(("slot_ps_and_gemv", {"BARK_HIP_SLOT_PS": str(slots), "BARK_HIP_SLOT_GEMV": str(slots)}))
-        for name, env_add in arms:
-            env = dict(os.environ); env.update(env_add)
-            key = "%s_%d_slots%s" % (name, slots, "_ragged" if ragged else "")
-            if time.perf_counter() > deadline:
-                out[key] = {"skipped": "time budget of the experiment legs used up"}
-                continue
-            try:
-                p = subprocess.run([sys.executable, "-c", EXPERIMENT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts, ragged)], env=env, capture_output=True, text=True, timeout=90)
-                line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
-                out[key] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
-            except Exception as e:      # noqa: BLE001
-                out[key] = {"error": str(e)}
-            sha = out[key].pop("sha256_ids_and_pcm", None)
-            if name == "default":
-                ref = sha
-            elif sha is not None:
-                out[key]["bits_equal_to_the_default_arm"] = bool(ref) and sha == ref
-    out["note"] = "opt-in, default off; 3 x slots prompts as one job on a context with that many slots, second run timed"
-    return out
-
-
-def experiments_leg(path: str, texts, n_semantic: int, deadline: float = float("inf")) -> dict:
-    """Opt-in switches that are off by default because they have not been measured yet, each in a process of its own (the switches are read
-    once per process) on the headline workload: RTF, decode-step time, and whether the ids and the PCM equal the default arm's bit for bit.
-    Reported BESIDE the headline, never instead of it.  BARK_HIP_WPREFETCH: DESIGN.md section 8 item 9."""
-    import subprocess
-    arms = {"default": {}, "wprefetch_1": {"BARK_HIP_WPREFETCH": "1"}, "wprefetch_2": {"BARK_HIP_WPREFETCH": "2"},
-            "wprefetch_2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"},
-            "wprefetch_1_stride64": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_WPREFETCH_STRIDE": "64"},
-            "wprefetch_2_stride64": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_STRIDE": "64"},
-            "wprefetch_1_kquads": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_KPREFETCH": "1"},
-            "wprefetch_2_kquads": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_KPREFETCH": "1"}}
-    out = {}
-    for name, env_add in arms.items():
-        env = dict(os.environ); env.update(env_add)
+    for slots in (8, 16):
+        texts = [prompts[i % len(prompts)] for i in range(3 * slots)]
+        key = "%d_slots" % slots
         if time.perf_counter() > deadline:
-            out[name] = {"skipped": "time budget of the experiment legs used up"}
+            out[key] = {"skipped": "time budget of the leg used up"}
             continue
         try:
-            p = subprocess.run([sys.executable, "-c", EXPERIMENT_CHILD % (ROOT, path, n_semantic, list(texts))], env=env, capture_output=True, text=True, timeout=60)
+            p = subprocess.run([sys.executable, "-c", FEW_SLOT_JOB_CHILD % (ROOT, path, n_semantic, slots, texts, 0)], env=dict(os.environ), capture_output=True, text=True, timeout=90)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
-            out[name] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+            out[key] = json.loads(line[0][7:]) if (p.returncode == 0 and line) else {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+            out[key].pop("sha256_ids_and_pcm", None)
         except Exception as e:      # noqa: BLE001
-            out[name] = {"error": str(e)}
-    ref = out.get("default", {}).get("sha256_ids_and_pcm")
-    for name, r in out.items():
-        if "sha256_ids_and_pcm" in r:
-            r["bits_equal_to_the_default_arm"] = bool(ref) and r.pop("sha256_ids_and_pcm") == ref
-    out["note"] = "opt-in, default off; arms run as separate processes of the same build on the same prompts (first prompt untimed)"
+            out[key] = {"error": str(e)}
+    out["note"] = "3 x slots prompts as one job on a context with that many slots, second run timed"
     return out
 
 
@@ -298,7 +230,7 @@ def main():
     ap.add_argument("--no-q4", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the bark-large leg (BASELINE config 3)")
     ap.add_argument("--no-fast", action="store_true", help="skip the tolerance-route leg (BARK_HIP_FAST_GEMM=1)")
-    ap.add_argument("--no-experiments", action="store_true", help="skip the A/B of the opt-in, not yet measured switches (separate processes)")
+    ap.add_argument("--no-few-slots", action="store_true", help="skip the 8- / 16-slot jobs (config 5's per-GPU share at N = 8 / N = 4; separate processes)")
     ap.add_argument("--no-roofline-legs", action="store_true", help="skip the kernel timing legs (rocprofv3 passes: the statistics then hold the prompts' kernels only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the --n-prompts job split over the ranks (BASELINE config 5); weak = --n-prompts per rank")
@@ -645,15 +577,11 @@ def main():
             qctx.free()
         except Exception as e:      # noqa: BLE001
             out["q4_0"] = {"error": str(e)}
-    if not a.no_experiments:
+    if not a.no_batched and not a.no_few_slots:
         try:
-            t_exp = time.perf_counter()                          # both legs together: arms are started for at most ~2.5 minutes
-            out["opt_in_experiments"] = experiments_leg(path, [prompts[k % len(prompts)] for k in range(3)], a.n_semantic, t_exp + 75.0)
-            if not a.no_batched:
-                out["opt_in_experiments"]["lock_step_jobs"] = job_experiments_leg(path, prompts, a.n_semantic, t_exp + 150.0)
-            out["opt_in_experiments"]["wall_s"] = time.perf_counter() - t_exp
+            out["config5_per_gpu_share_at_8_and_4_gpus"] = few_slot_jobs_leg(path, prompts, a.n_semantic, time.perf_counter() + 100.0)
         except Exception as e:      # noqa: BLE001
-            out["opt_in_experiments"] = {"error": str(e)}
+            out["config5_per_gpu_share_at_8_and_4_gpus"] = {"error": str(e)}
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(path, prompts[a.warmup % len(prompts)], a.n_semantic)
     print(json.dumps(out))

@@ -33,7 +33,7 @@ _GPU_GROUP_BY_NAME = {
         "test_randomised_lock_step_jobs", "test_job_larger_than_the_slots", "test_job_tail_on_a_second_stream", "test_small_ragged_job", "test_lock_step_time_line_hook",
         "test_ragged_job_on_quantised", "test_few_slot_"),
     4: ("test_cloned_contexts_", "test_request_batcher_", "test_request_collector_", "test_native_batch_server", "test_device_and_host_sampling_agree_on_many",
-        "test_weight_prefetch_experiment", "test_slot_partial_score_experiment", "test_concurrent_"),
+        "test_concurrent_"),
 }
 
 

@@ -162,91 +162,6 @@ def test_attention_rank_order_keeps_a_head_on_one_xcd():
         assert len(owner) == H * Z and all(len(v) <= QT // share + 2 for v in owner.values())
 
 
-# ---- opt-in weight prefetch (NextWeights, kernels.h; prefetch_next_weights, device_utils.h; the plan in engine.hip) -------------------------
-def _prefetch_touches(G, n_threads, n_wg, wg_bytes, stride, slice_stride=0, group_shift=0):
-    """prefetch_next_weights restated: producer workgroup i of a launch of G workgroups (XCD i % 8) walks the consumer GROUPS g = x + 8 s of its
-    XCD, s = i / 8, i / 8 + np, ... (a group = 2^group_shift consecutive slices, all read by one consumer workgroup); slice j starts at
-    j * (slice_stride or wg_bytes); thread t touches byte offsets t stride, (t + n_threads) stride, ... below wg_bytes of a slice.  Returns
-    {slice j: (producer XCDs that touched it, absolute byte addresses)}."""
-    out = {}
-    pitch = slice_stride or wg_bytes
-    for i in range(G):
-        x, np_ = i & 7, (G - (i & 7) + 7) >> 3
-        s = i >> 3
-        while x + 8 * s < (n_wg >> group_shift):
-            for sub in range(1 << group_shift):
-                j = ((x + 8 * s) << group_shift) + sub
-                xs, offs = out.setdefault(j, (set(), []))
-                xs.add(x)
-                for t in range(n_threads):
-                    off = t * stride
-                    while off < wg_bytes:
-                        offs.append(j * pitch + off)
-                        off += n_threads * stride
-            s += np_
-    return out
-
-
-def test_weight_prefetch_covers_every_consumer_slice_once_on_its_own_xcd():
-    """Every consumer workgroup's slice is touched exactly once per `stride` bytes, by producers of the consumer's own XCD (j % 8), for the
-    producer / consumer geometries of a bark-small and a bark-large decode step and a few awkward ones."""
-    E = 768
-    cases = []
-    for E in (768, 1024, 128):
-        qkv_main = 3 * E // 16
-        gemv4 = lambda M: (M + 3) // 4
-        ln16 = lambda M: (M + 15) // 16
-        attn_grid = 8 * 16 * ((E // 64 + 7) // 8)
-        producers = {"qkv": (qkv_main + 2 * (E // 16), 256), "attn": (attn_grid, 1024), "attn_late": (attn_grid, 1024 - 64), "proj": (gemv4(E), 64), "fc": (ln16(4 * E), 256),
-                     "mproj": (gemv4(E), 64), "head": (ln16(10048), 256)}
-        consumers = {"proj": (E // 4, 4 * E * 2), "fc": (4 * E // 16, 16 * E * 2), "mproj": (E // 4, 4 * 4 * E * 2), "qkv": (3 * E // 16, 16 * E * 2),
-                     "head": (10048 // 16, 16 * E * 2), "coarse_head_both_windows": (2048 // 16, 16 * E * 2)}
-        for pn, (G, nt) in producers.items():
-            for cn, (n_wg, wg_bytes) in consumers.items():
-                cases.append((G, nt, n_wg, wg_bytes))
-    cases += [(5, 64, 19, 1000), (192, 64, 3, 6144), (9, 256, 64, 128)]
-    seen = set()
-    for G, nt, n_wg, wg_bytes in cases:
-        for stride in (64, 128, 256):
-            key = (G, nt, n_wg, wg_bytes, stride)
-            if key in seen:
-                continue
-            seen.add(key)
-            got = _prefetch_touches(G, nt, n_wg, wg_bytes, stride)
-            # every slice whose XCD holds at least one producer is covered; with fewer than 8 producers the other XCDs' slices stay cold
-            for j in range(n_wg):
-                if (j & 7) >= G:
-                    assert j not in got
-                    continue
-                xs, offs = got[j]
-                assert xs == {j & 7}, (key, j, xs)
-                assert sorted(offs) == list(range(j * wg_bytes, (j + 1) * wg_bytes, stride)), (key, j)
-
-
-def test_k_quad_prefetch_matches_the_partial_score_copies():
-    """BARK_HIP_KPREFETCH (next_k_quads, engine.hip): the K quads a q workgroup's copies stream in gemv_ln_wg_kernel<PS> - rows 4 w .. 4 w + 3 of the
-    layer's [H * 16][P] float4 K cache, keys below 256 ng - are touched by producers of XCD w % 8 (where the copies of q workgroup w run: workgroup
-    ids n_main + rep n_q + w with n_main and n_q multiples of 8), and nothing beyond the keys the launch's context bound allows."""
-    P = 1024
-    for E in (768, 1024, 128):
-        n_q, n_main = E // 16, 3 * E // 16
-        assert n_q % 8 == 0 and n_main % 8 == 0
-        for ng in (1, 3, 4):
-            for G in ((E + 3) // 4, 4 * E // 16, 10048 // 16):              # MLP out-projection, FC and LM head as producers
-                got = _prefetch_touches(G, 64 if G == (E + 3) // 4 else 256, E // 4, 256 * ng * 16, 128, slice_stride=P * 16, group_shift=2)
-                for w in range(n_q):
-                    hq, blk = (16 * w) >> 6, ((16 * w) >> 4) & 3
-                    for i in range(4):
-                        row = hq * 16 + 4 * blk + i                             # load_kq: kc + ((hq * 16 + 4 * blk) * 1024 + ...) float4, quad i at + i * 16384 bytes
-                        assert row == 4 * w + i
-                        if (w & 7) >= G:
-                            continue
-                        xs, offs = got[row]
-                        assert xs == {w & 7}, (E, ng, G, w, xs)
-                        assert sorted(offs) == list(range(row * P * 16, row * P * 16 + 256 * ng * 16, 128))
-                assert set(got) <= set(range(E // 4))
-
-
 # ---- opt-in lock-step route for few slots (BARK_HIP_SLOT_PS): gemv_ln_slots_ps_kernel (kernels.hip) -> attn_fused_ps_kernel (attention_kernels.hip) ----
 def _mul32(a, b):
     return np.float32(np.float32(a) * np.float32(b))

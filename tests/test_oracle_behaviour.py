@@ -127,9 +127,13 @@ def test_many_row_and_single_row_products_agree_bit_for_bit(toy_model, quantized
 @pytest.mark.parametrize("fmt", ["f16", "q4_0", "large"])
 def test_committed_bench_workload_fixture_is_what_the_oracle_generates(fmt):
     """tests/golden/oracle_small_bench_<fmt>.npz stands in for a live oracle run in the -m gpu test of the benchmark workload
-    (test_bench_workload_matches_the_oracle); here the oracle re-derives it, so the two cannot drift apart."""
+    (test_bench_workload_matches_the_oracle); here the oracle re-derives it, so the two cannot drift apart.  The f16 fixture (the
+    headline workload) is re-derived in every run; q4_0 and bark-large take 2.5 CPU-minutes more and run with BARK_FULL_CPU_SUITE=1
+    (tools/make_oracle_golden.py regenerates all of them; the CPU suite is sized to finish in a few minutes)."""
     import os
     import sys
+    if fmt != "f16" and not os.environ.get("BARK_FULL_CPU_SUITE"):
+        pytest.skip("BARK_FULL_CPU_SUITE=1 re-derives the q4_0 and bark-large fixtures too")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import make_oracle_golden

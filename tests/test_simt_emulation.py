@@ -65,7 +65,7 @@ def _states(ctxs):
     return st
 
 
-@pytest.mark.parametrize("E,ctxs", [(128, [5, 300, 700]), (256, [1, 513])])
+@pytest.mark.parametrize("E,ctxs", [(128, [5, 300, 700]), (256, [1, 513]), (128, [5, 300, 700, 1, 64, 65, 255, 256, 257, 512, 1000])])      # 11 slots: two slot groups, 8 + 3
 def test_slot_kernels_equal_the_kernels_they_replace(sim, E, ctxs):
     rng = np.random.default_rng(E)
     B, H, P = len(ctxs), E // 64, 1024

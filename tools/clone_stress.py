@@ -7,7 +7,7 @@ iteration: G clones, one host thread each, J jobs per thread back to back; every
 base context AND with its own oracle run (so a difference says which side is wrong), and every differing index is printed with both
 values and with what the slot held at those positions in the clone's previous job (a stale read-back shows up as exactly those).
 
-    python tools/clone_stress.py [iterations=10] [preset=mini] [G=4] [J=3]
+    python tools/clone_stress.py [iterations=10] [preset=mini] [G=4] [J=3] [seconds=inf]
 
 Arms are environment variables of the engine (set by the caller): BARK_HIP_READBACK=legacy|pinned, BARK_HIP_READBACK_CHECK=1,
 BARK_HIP_TAIL_STREAM=0, BARK_HIP_GRAPH=0, BARK_HIP_POISON=1.  Exit status 1 if anything differed."""
@@ -27,6 +27,8 @@ def main():
     preset = sys.argv[2] if len(sys.argv) > 2 else "mini"
     G = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     J = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    budget_s = float(sys.argv[5]) if len(sys.argv) > 5 else float("inf")      # stop after this many seconds of iterations
+    KEYS = ("semantic", "coarse") if os.environ.get("BARK_HIP_DIAG_NO_TAIL") else ("semantic", "coarse", "fine", "pcm")
     import bench
     from bark_amd_loader import load_package
     from oracle.pyoracle import Oracle
@@ -49,13 +51,17 @@ def main():
                 if text not in want:
                     orc.seed(0)
                     want[text] = orc.generate(text, orc.params(temp=0.0, fine_temp=0.0, n_steps_text_encoder=cap))
-                for k in ("semantic", "coarse", "fine", "pcm"):
+                for k in KEYS:
                     if not np.array_equal(np.asarray(ref[g][j][i][k]), np.asarray(want[text][k])):
                         print(f"BASE differs from the oracle: thread {g} job {j} utterance {i} {k}", flush=True)
     orc.close()
     n_bad = 0
     t0 = time.time()
+    done = 0
     for it in range(iters):
+        if time.time() - t0 > budget_s:
+            break
+        done += 1
         clones = [base.clone(g + 1) for g in range(G)]
         got = [[None] * J for _ in range(G)]
         errors = []
@@ -77,7 +83,7 @@ def main():
         for g in range(G):
             for j in range(J):
                 for i, (a, b) in enumerate(zip(got[g][j], ref[g][j])):
-                    for k in ("semantic", "coarse", "fine", "pcm"):
+                    for k in KEYS:
                         x, y = np.asarray(a[k]).ravel(), np.asarray(b[k]).ravel()
                         if x.shape == y.shape and np.array_equal(x, y):
                             continue
@@ -96,7 +102,7 @@ def main():
                         print(line, flush=True)
         print(f"iteration {it} done, {n_bad} differing arrays so far, {time.time() - t0:.0f} s", flush=True)
     base.free()
-    print(f"clone_stress: {n_bad} differing arrays in {iters} iterations")
+    print(f"clone_stress: {n_bad} differing arrays in {done} iterations ({G} threads x {J} jobs), {time.time() - t0:.0f} s")
     return 1 if n_bad else 0
 
 

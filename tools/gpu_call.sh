@@ -1,6 +1,6 @@
 #!/bin/bash
 # One parameterised GPU-box script (replaces the per-call scripts of rounds 1 - 3): gpurun -- 'tools/gpu_call.sh <tag> <step> [<step> ...]'
-#   steps:  test:<pytest -k expression | all>   fine_ab   batch_tp   bench   stats   soak   wprefetch_ab   experiments (bench.py's opt_in_experiments legs: every unmeasured switch against the default arm)   <any other word>: tools/<word>.py if it exists
+#   steps:  test:<pytest -k expression | all>   fine_ab   batch_tp   bench   stats   soak   <any other word>: tools/<word>.py if it exists
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"; mkdir -p gpurun_out
 TAG=$1; shift
@@ -11,8 +11,6 @@ for step in "$@"; do
         fine_ab)  timeout 300 python tools/fine_ab.py base rows_attn:BARK_HIP_CROSSCHECK=512 c1:BARK_HIP_CROSSCHECK=768 base_x8:FINE_WINDOWS=8 rows_attn_x8:BARK_HIP_CROSSCHECK=512,FINE_WINDOWS=8 c1_x8:BARK_HIP_CROSSCHECK=768,FINE_WINDOWS=8 tol:BARK_HIP_FAST_GEMM=1 tol_x8:BARK_HIP_FAST_GEMM=1,FINE_WINDOWS=8 > gpurun_out/${TAG}_fine_ab.txt 2>&1; cat gpurun_out/${TAG}_fine_ab.txt ;;
         batch_tp) timeout 600 python tools/batch_throughput.py 256 small > gpurun_out/${TAG}_batch_tp.txt 2>&1; cat gpurun_out/${TAG}_batch_tp.txt ;;
         bench)    timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 1500 gpurun_out/${TAG}_bench.json ;;
-        wprefetch_ab) timeout 1200 python tools/decode_ab.py base pf1:BARK_HIP_WPREFETCH=1 pf2:BARK_HIP_WPREFETCH=2 pf1_early:BARK_HIP_WPREFETCH=1,BARK_HIP_WPREFETCH_EARLY=1 pf2_early:BARK_HIP_WPREFETCH=2,BARK_HIP_WPREFETCH_EARLY=1 pf2_s64:BARK_HIP_WPREFETCH=2,BARK_HIP_WPREFETCH_STRIDE=64 pf2_s256:BARK_HIP_WPREFETCH=2,BARK_HIP_WPREFETCH_STRIDE=256 pf1_k:BARK_HIP_WPREFETCH=1,BARK_HIP_KPREFETCH=1 pf2_k:BARK_HIP_WPREFETCH=2,BARK_HIP_KPREFETCH=1 > gpurun_out/${TAG}_wprefetch_ab.txt 2>&1; cat gpurun_out/${TAG}_wprefetch_ab.txt ;;
-        experiments) timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-large --no-q4 --no-fast > gpurun_out/${TAG}_bench_experiments.json 2> gpurun_out/${TAG}_bench_experiments.err; python -c "import json,sys; d=json.loads(open('gpurun_out/${TAG}_bench_experiments.json').read().strip().splitlines()[-1]); print(json.dumps(d.get('opt_in_experiments'), indent=1))" ;;
         soak)     python tools/mfma_f16_order.py soak gpurun_out/${TAG}_mfma_f16_soak.txt ;;
         *)        if [ -f "tools/$step.py" ]; then timeout 900 python "tools/$step.py" > gpurun_out/${TAG}_$step.txt 2>&1; tail -30 gpurun_out/${TAG}_$step.txt; else echo "unknown step $step"; fi ;;
     esac

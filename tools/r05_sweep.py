@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Round 5: one measurement of every opt-in switch that round 4 left unmeasured, so that each can be adopted or deleted.
 
-  part 1 (single-utterance decode step): BARK_HIP_WPREFETCH arms - decode-step time at three contexts + a short greedy generate whose ids / PCM
-          hash must equal the default arm's.
-  part 2 (lock steps at few slots): BARK_HIP_SLOT_PS / BARK_HIP_SLOT_GEMV arms - graph-replayed lock step (bark_hip_profile_lock_step) at
-          2 .. 32 live slots for both causal models, per-site times at 8 slots.
+  part 1 (single-utterance decode step): the BARK_HIP_WPREFETCH arms of round 4 - measured in round 5 (every arm 10 - 17 % SLOWER than the default,
+          profiles/r05_gpu_suite_reordered_first_run.log) and deleted with the experiment; the part is kept as the decode-step timer of the default build.
+  part 2 (lock steps at few slots): BARK_HIP_FEW_SLOTS arms - graph-replayed lock step (bark_hip_profile_lock_step) at 2 .. 32 live slots for both
+          causal models, per-site times at 4 / 8 / 16 slots.
 Every arm is a process of its own (the switches are read once per process).   python tools/r05_sweep.py [part1|part2|all]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,17 +61,16 @@ def run(child, env_add):
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 out = {}
 if what in ("part1", "all"):
-    arms = {"default": {}, "pf1": {"BARK_HIP_WPREFETCH": "1"}, "pf2": {"BARK_HIP_WPREFETCH": "2"},
-            "pf1_early": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_WPREFETCH_EARLY": "1"}, "pf2_early": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_EARLY": "1"},
-            "pf1_s64": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_WPREFETCH_STRIDE": "64"}, "pf2_s256": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_WPREFETCH_STRIDE": "256"},
-            "pf1_k": {"BARK_HIP_WPREFETCH": "1", "BARK_HIP_KPREFETCH": "1"}, "pf2_k": {"BARK_HIP_WPREFETCH": "2", "BARK_HIP_KPREFETCH": "1"}, "default_again": {}}
+    arms = {"default": {}, "default_again": {}}
     for name, env in arms.items():
         out[name] = run(CHILD1, env)
         print("decode", name, json.dumps(out[name]), flush=True)
     ref = out["default"].get("sha")
     print("bits equal to the default arm:", {k: v.get("sha") == ref for k, v in out.items()}, flush=True)
 if what in ("part2", "all"):
-    arms = {"default": {}, "ps": {"BARK_HIP_SLOT_PS": "32"}, "gemv": {"BARK_HIP_SLOT_GEMV": "32"}, "ps+gemv": {"BARK_HIP_SLOT_PS": "32", "BARK_HIP_SLOT_GEMV": "32"}}
+    # round 4's per-slot kernels (measured in call 2 of round 5, profiles/r05_few_slot_routes.txt) were replaced by the slot-group kernels; arms now:
+    arms = {"matrix_core_route": {"BARK_HIP_FEW_SLOTS": "0"}, "few_slot_route": {"BARK_HIP_FEW_SLOTS": "32"},
+            "products_only": {"BARK_HIP_FEW_SLOTS": "32,0"}, "attention_only": {"BARK_HIP_FEW_SLOTS": "0,32"}}
     for name, env in arms.items():
         out["slots_" + name] = run(CHILD2, env)
         print("lock step", name, json.dumps(out["slots_" + name]), flush=True)
