@@ -82,53 +82,22 @@ void ensure_batch(bark_context * c, int B) {
     bb.cap = B;
 }
 
-// How the host learns what the lock steps produced: the sampled ids of the live slots (rows of 2048) and their stage states.
-// The stream is synchronised BEFORE the copies are issued and the copies land in pinned memory: the copy engine then reads device memory that
-// no kernel is writing any more, and nothing depends on how the runtime stages a pageable destination (root cause of round 4's
-// red GPU suite).  BARK_HIP_READBACK=legacy|pinned are the arms that led there (tools/clone_stress.py): pageable destination without / pinned
-// destination without the synchronisation in front; BARK_HIP_READBACK_CHECK=1 re-reads everything after a device-wide synchronisation and
-// reports differences on stderr.
-int readback_mode() {
-    static const int v = [] { const char * e = getenv("BARK_HIP_READBACK"); return !e ? 0 : !strcmp(e, "legacy") ? 1 : !strcmp(e, "pinned") ? 2 : 0; }();
-    return v;
-}
-void read_back(bark_context * c, int B, std::vector<int32_t> * ids, std::vector<StepState> & st, const char * where) {
+// How the host learns what the lock steps produced: the sampled ids of the live slots (rows of 2048) and their stage states, in one pair of copies
+// into pinned memory behind a synchronisation of the stream (the copy engine reads device memory that no kernel is writing any more, and nothing
+// depends on how the runtime stages a pageable destination).  Round 5 measured this form against round 4's (pageable destination, copies enqueued
+// straight behind the lock steps) while hunting the r04 divergence: both forms read back exactly what the device holds (a second copy after one
+// more synchronisation never differed in 800 stress iterations) - the divergence was on the device.
+void read_back(bark_context * c, int B, std::vector<int32_t> * ids, std::vector<StepState> & st) {
     bark_context::Batch & bb = c->batch;
-    static const bool check = getenv("BARK_HIP_READBACK_CHECK") && atoi(getenv("BARK_HIP_READBACK_CHECK")) != 0;
-    const int mode = readback_mode();
     st.resize((size_t) B);
     if (ids) ids->resize((size_t) B * 2048);
-    if (mode == 1) {
-        if (ids) HIP_OK(hipMemcpyAsync(ids->data(), bb.out_tokens, ids->size() * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipMemcpyAsync(st.data(), bb.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));
-    } else {
-        if (mode == 0) HIP_OK(hipStreamSynchronize(c->stream));
-        if (ids) HIP_OK(hipMemcpyAsync(bb.h_ids, bb.out_tokens, ids->size() * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipMemcpyAsync(bb.h_state, bb.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));
-        if (ids) memcpy(ids->data(), bb.h_ids, ids->size() * 4);
-        memcpy(st.data(), bb.h_state, sizeof(StepState) * B);
-    }
-    if (check) {
-        // (never hipDeviceSynchronize here: it is refused while ANY stream of the process captures - and poisons that capture, round 5 call 1)
-        HIP_OK(hipStreamSynchronize(c->stream));
-        std::vector<int32_t> ids2(ids ? ids->size() : 0); std::vector<StepState> st2((size_t) B);
-        if (ids) copy_to_host(c, ids2.data(), bb.out_tokens, ids2.size() * 4);
-        copy_to_host(c, st2.data(), bb.state, sizeof(StepState) * B);
-        for (int b = 0; b < B; b++) {
-            const int n_out = std::min(st2[(size_t) b].n_out, 2048);
-            int bad = 0, first = -1;
-            if (ids) for (int i = 0; i < n_out; i++) if ((*ids)[(size_t) b * 2048 + i] != ids2[(size_t) b * 2048 + i]) { if (!bad) first = i; bad++; }
-            const bool sbad = memcmp(&st[(size_t) b], &st2[(size_t) b], sizeof(StepState)) != 0;
-            if (bad || sbad)
-                fprintf(stderr, "bark-hip READBACK MISMATCH (%s, ctx %p, mode %d, %d slots): slot %d: %d of %d ids differ from a second copy taken after one more stream sync (first at %d: %d vs %d); state %s (n_out %d vs %d, n_past %d vs %d)\n",
-                        where, (void *) c, mode, B, b, bad, n_out, first, first >= 0 ? (*ids)[(size_t) b * 2048 + first] : 0, first >= 0 ? ids2[(size_t) b * 2048 + first] : 0,
-                        sbad ? "DIFFERS" : "equal", st[(size_t) b].n_out, st2[(size_t) b].n_out, st[(size_t) b].n_past, st2[(size_t) b].n_past);
-        }
-    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (ids) HIP_OK(hipMemcpyAsync(bb.h_ids, bb.out_tokens, ids->size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(bb.h_state, bb.state, sizeof(StepState) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (ids) memcpy(ids->data(), bb.h_ids, ids->size() * 4);
+    memcpy(st.data(), bb.h_state, sizeof(StepState) * B);
 }
-
 // the slots' own sampling parameters (bark_hip_request_params): host mirror -> device
 void upload_slot_params(bark_context * c) {
     bark_context::Batch & bb = c->batch;
@@ -892,12 +861,12 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             for (int j = 0; j < k; j++) batch_step(c, s, B);
             for (int b = 0; b < B; b++) us[(size_t) slot_utt[(size_t) b]].issued += k;
             std::vector<StepState> st;
-            read_back(c, B, nullptr, st, "semantic poll");
+            read_back(c, B, nullptr, st);
             for (auto & v : st) if (v.fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");
             // retire from the back so that a move never touches a slot that is still to be looked at
             bool moved = false, any_done = false;
             for (int b = 0; b < B; b++) any_done = any_done || !(st[(size_t) b].eos_step == INT32_MAX && us[(size_t) slot_utt[(size_t) b]].issued < us[(size_t) slot_utt[(size_t) b]].cap);
-            if (any_done) read_back(c, B, &ids_all, st, "semantic retire");          // the stream is idle: one more copy, taken only when somebody leaves
+            if (any_done) read_back(c, B, &ids_all, st);          // the stream is idle: one more copy, taken only when somebody leaves
             for (int b = B - 1; b >= 0; b--) {
                 const Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].eos_step == INT32_MAX && u.issued < u.cap) continue;
@@ -1019,7 +988,7 @@ int engine_generate_batch(bark_context * c, const char * const * texts, int n, c
             // the window's ids of all slots in ONE copy (rows of 2048 per slot, 512 KB at 64 slots) and their states
             std::vector<int32_t> ids_all;
             std::vector<StepState> st;
-            read_back(c, B, &ids_all, st, "coarse window");
+            read_back(c, B, &ids_all, st);
             for (int b = 0; b < B; b++) {
                 Utt & u = us[(size_t) slot_utt[(size_t) b]];
                 if (st[(size_t) b].fault) throw std::runtime_error("lock step launched with a context bound below the cached keys");

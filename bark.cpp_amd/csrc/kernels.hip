@@ -542,12 +542,12 @@ static void launch_gemv_batch_n(hipStream_t s, const LinArgs & a) {
     dim3 grid((a.M + 3) / 4, (a.nbatch + BPW - 1) / BPW), block(64);
     // rows that are f16 already (the two out-projections of a lock step): 4 / 8 slots per wave - the weight chunks of a wave are requested once
     // for all of them (a one-wave workgroup may hold 8 x 8 chunks of x beside them); measured against 2 per wave at 8 / 16 slots (profiles/r05_*)
-    // (register budget of a one-wave workgroup: 8 slots fit up to K = 1024, 4 slots up to K = 3072; beyond, the chunks of x would spill)
+    // (register budget of a one-wave workgroup: 8 slots fit up to K = 1024, 4 slots up to K = 2048; beyond, the chunks of x would spill to scratch)
     if (!a.x_f32 && a.nbatch > 2 && a.slots_per_wave > 2) {
         if constexpr (NBLK <= 8) {
             if (a.nbatch > 4 && a.slots_per_wave >= 8) { hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, 8>), dim3(grid.x, (a.nbatch + 7) / 8), block, 0, s, a); return; }
         }
-        if constexpr (NBLK <= 24) {
+        if constexpr (NBLK <= 16) {
             hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, 4>), dim3(grid.x, (a.nbatch + 3) / 4), block, 0, s, a);
             return;
         }
