@@ -30,16 +30,22 @@ namespace {
 
 constexpr int kMaxSlots = 64;                            // lock-step slots of a context (KV caches of both causal models per slot: 151 MB at bark-small)
 
-// Lock steps over 2 .. kFewSlots live slots (f16 files, n_embd <= 1024, block_size 1024) take the few-slot route: slot-group products (weights requested
-// once per group of 8 slots, kernels.hip: gemv_ln_slotgroup_kernel), the partial attention scores formed where q is born and the attention on them
-// (attn_fused_ps_kernel), out-projections with 8 slots per wave.  Above, the matrix-core tiles of gemm_slots16_kernel and the streaming attention
-// kernels take over.  Cross-over measured on MI355X: profiles/r05_few_slot_routes.txt.  BARK_HIP_FEW_SLOTS=<n> moves it (0: off) - the A/B handle
-// of tools/r05_sweep.py, not a tuning knob.
-// BARK_HIP_FEW_SLOTS=<n>[,<n_attention>]: products / partial-score attention up to that many live slots
+// Lock steps over few live slots (f16 files, n_embd <= 1024, block_size 1024) do not use the matrix-core tiles of gemm_slots16_kernel / the one-CU
+// attention of attn_fused_kernel.  Measured on MI355X (graph-replayed coarse step at context 640, bark-small, us; profiles/r05_few_slot_routes_round4_kernels.txt):
+//     live slots                                   2     4     6     8    12    16    24    32
+//     matrix-core / per-pair route (round 4)     390   477   521   434   506   555   688   753
+//     per-slot products only                     330   389   414   395   471   512   682   787
+//     + partial scores where q is born           277   319   362   388   478   544   761   892
+// so: up to kFewSlotsScores live slots the QKV product runs per slot and forms the partial attention scores of the cached keys where q is born
+// (gemv_ln_slots_ps_kernel, attention on them: attn_fused_ps_kernel); up to kFewSlotsProducts the FC product and the two out-projections run per slot
+// on the VALU (weights out of the XCD's L2 after the first slot).  A slot-group form (8 slots inside the workgroup, weights requested once) was built
+// and measured in round 5 too: slower at every size (494 us at 8 slots: its epilogues serialise per slot; profiles/r05_few_slot_routes_slot_group_kernels.txt).
+// BARK_HIP_FEW_SLOTS=<products>[,<scores>] moves the cross-overs (0: off) - the A/B handle of tools/r05_sweep.py and of the route-equality test.
+constexpr int kFewSlotsProducts = 16, kFewSlotsScores = 8;
 int few_slots_max(int which = 0) {
     static const std::pair<int, int> v = [] {
         const char * e = getenv("BARK_HIP_FEW_SLOTS");
-        int n = 16, na = 16;
+        int n = kFewSlotsProducts, na = kFewSlotsScores;
         if (e) { n = na = atoi(e); if (const char * k = strchr(e, ',')) na = atoi(k + 1); }
         auto ok = [](int x) { return x >= 2 && x <= kMaxSlots ? x : 0; };
         return std::make_pair(ok(n), ok(na));
@@ -168,7 +174,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.ln_stats = nullptr;
         launch_linear_slots(st, a);
     };
-    // few live slots: slot-group products, partial scores where q is born + the attention on them (see few_slots_max)
+    // few live slots: per-slot products, partial scores where q is born + the attention on them (see few_slots_max)
     const bool few_ok = !m.q4 && !m.w32 && P == 1024 && E <= 1024 && (E & 127) == 0 && B >= 2 && !(crosscheck_mask() & 2);
     const bool few = few_ok && B <= few_slots_max(0);
     const bool slot_ps = few_ok && bb.ps && B <= few_slots_max(1);
@@ -180,7 +186,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         a.batched = 1; a.nbatch = B; a.kv_slot_stride = slot; a.ln_stats = hoist ? bb.ln_stats : nullptr;
         a.W = L.attn_w; a.wq = L.attn_q; a.M = 3 * E; a.K = E; a.N = 1; a.x_f32 = bb.x; a.bias = L.attn_b;
         a.epi = EPI_QKV; a.q = bb.q; a.kc = kl; a.vc = vl; a.E = E; a.P = P; a.pos0 = 0; a.st = bb.state;
-        if (few || slot_ps) { a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = nullptr; if (slot_ps) a.ps = bb.ps; launch_linear_slotgroup(st, a); }
+        if (slot_ps) { a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.ln_stats = nullptr; a.ps = bb.ps; launch_linear_slots_ps(st, a); }
         else product(a, L.ln1_g, L.ln1_b);
         mark("ln1+qkv");
         AttnDecodeArgs at;
@@ -193,20 +199,20 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
         LinArgs p;
         p.batched = 1; p.nbatch = B;
         p.W = L.proj_w; p.wq = L.proj_q; p.M = E; p.K = E; p.N = 1; if (m.q4) p.x_f32 = bb.att32; else p.x_f16 = bb.att; p.bias = L.proj_b; p.epi = EPI_RESID; p.res = bb.x;
-        if (few) { p.slots_per_wave = 8; launch_linear(st, p); } else product(p, nullptr, nullptr);
+        if (few) launch_linear_slots_gemv(st, p); else product(p, nullptr, nullptr);
         mark("proj");
         if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
         LinArgs f;
         f.batched = 1; f.nbatch = B; f.ln_stats = hoist ? bb.ln_stats : nullptr;
         f.W = L.fc_w; f.wq = L.fc_q; f.M = 4 * E; f.K = E; f.N = 1; f.x_f32 = bb.x; f.bias = L.fc_b;
         f.epi = EPI_GELU; f.out_h = bb.h; f.out_h32 = m.q4 ? bb.h32 : nullptr; f.lut = c->d_gelu_lut;
-        if (few) { f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_stats = nullptr; f.E = E; launch_linear_slotgroup(st, f); }
+        if (few) { f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_stats = nullptr; f.E = E; launch_linear_slots_ps(st, f); }
         else product(f, L.ln2_g, L.ln2_b);
         mark("ln2+fc+gelu");
         LinArgs o;
         o.batched = 1; o.nbatch = B;
         o.W = L.mproj_w; o.wq = L.mproj_q; o.M = E; o.K = 4 * E; o.N = 1; if (m.q4) o.x_f32 = bb.h32; else o.x_f16 = bb.h; o.bias = L.mproj_b; o.epi = EPI_RESID; o.res = bb.x;
-        if (few) { o.slots_per_wave = 8; launch_linear(st, o); } else product(o, nullptr, nullptr);
+        if (few) launch_linear_slots_gemv(st, o); else product(o, nullptr, nullptr);
         mark("mlp_proj");
     }
     if (hoist && !mfma) launch_ln_stats(st, bb.x, B, E, bb.ln_stats);
@@ -215,8 +221,7 @@ void enqueue_batch_step(bark_context * c, const StageCfg & s, int B, const bark_
     if (m.q4) h.wq = q4_rows(m.lm_head_q[0], (size_t) s.lm_row0, E); else h.W = m.lm_head[0] + (size_t) s.lm_row0 * E;
     h.M = s.lm_rows; h.K = E; h.N = 1; h.x_f32 = bb.x;
     h.epi = EPI_LOGITS; h.out = bb.logits; h.ld_out = (int) bb.ld_logits; h.parity_rows = s.parity_rows; h.st = bb.state;
-    if (few) { h.ln_g = m.lnf_g; h.ln_b = m.lnf_b; h.ln_stats = nullptr; h.E = E; launch_linear_slotgroup(st, h); }
-    else product(h, m.lnf_g, m.lnf_b);
+    product(h, m.lnf_g, m.lnf_b);
     mark("lnf+lm_head");
     launch_sample_greedy(st, slot_sample_args(c, s, bb, 0, B, 1));
     mark("sample+embed");

@@ -97,7 +97,6 @@ struct LinArgs {
     // batched decode (several utterances in lock step): row n of x / q / res / out_h / out is sequence slot n, which has
     // its own StepState st[n] and its own KV cache at kc/vc + n * kv_slot_stride
     int batched = 0, nbatch = 1; size_t kv_slot_stride = 0;
-    int slots_per_wave = 2;               // batched rows that are f16 already (gemv_batch_kernel): 2, 4 or 8 slots share the weight chunks of a wave
     // N > 1, f16 weights, opt-in (BARK_HIP_FAST_GEMM=1): v_mfma_f32_32x32x16_f16 with the matrix core's own f32 accumulation order
     // (gemm_f16_tile_kernel, fast_kernels.hip).  Same operands and roundings as the canonical product (R1), only the ORDER of the f32
     // additions differs from C1: results agree to f32 rounding noise, not bit for bit, so this route is never the one the parity tests check.
@@ -115,10 +114,11 @@ void launch_linear(hipStream_t s, const LinArgs & a);
 // lock-step decode of up to 32 slots on the f32 matrix cores (a.batched, f16 rows a.x_f16 [nbatch][K], f16 weights)
 void launch_linear_slots(hipStream_t s, const LinArgs & a);                // gemm_slots16_kernel; x_f32 + ln_g: the LayerNorm of the rows fused (when linear_slots_fuses_ln(K))
 bool linear_slots_fuses_ln(int K);
-// lock steps at few slots: LayerNorm-fused products with a GROUP of up to 8 slots inside the workgroup (gemv_ln_slotgroup_kernel: weight rows requested
-// once per group); a.x_f32 [nbatch][K] + LayerNorm, any batched epilogue, parity windows; a.ps set (QKV): copies of the q workgroups form the partial
-// scores of the cached keys (a.ps: [nbatch][H][4][P]) that attn_fused_ps_kernel finishes
-void launch_linear_slotgroup(hipStream_t s, const LinArgs & a);
+// lock steps at few slots: the QKV product per slot as in the single-utterance step, forming the partial scores of the cached keys (a.ps:
+// [nbatch][H][4][P]) that attn_fused_ps_kernel finishes; a.x_f32 [nbatch][K] + LayerNorm, batched epilogue; a.ps == nullptr: no copies (FC product)
+void launch_linear_slots_ps(hipStream_t s, const LinArgs & a);
+// ... and their out-projections as the single-utterance GEMV with a slot dimension (a.x_f16 [nbatch][K])
+void launch_linear_slots_gemv(hipStream_t s, const LinArgs & a);
 
 // x[i] = wte[tok] (+ wte[tok2] for merged prompt rows) + wpe[pos]      (bark.cpp:1220-1259)
 struct EmbedArgs {

@@ -249,54 +249,44 @@ static void launch_gemv_n(hipStream_t s, const LinArgs & a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lock steps at FEW slots (2 .. 16 live slots): the LayerNorm-fused products (QKV, FC + GELU, LM head) as gemv_ln_wg_kernel with the slots
-// INSIDE the workgroup.  A lock step at 8 slots is a latency chain; per-slot workgroups (round 4's experiment) pull every weight row once per
-// slot out of the L2, and the matrix-core tiles of gemm_slots16_kernel<LNF> wait behind a LayerNorm per tile.  Here one workgroup = 16 output
-// rows x a GROUP of up to 8 slots: its weight rows are requested ONCE (16 bytes per lane and chunk, as in the single-utterance kernel), wave w
-// normalises the rows of the group's slots w and w + 4 (C6, the statement of gemv_ln_wg_kernel) into LDS, and every lane then walks its C1
-// chain once per slot against the published f16 rows.  Same arithmetic per element as every other route: the same bits.
-// PS = true (QKV): the partial C2 block scores of the cached keys are formed where q is born, as in the single-utterance step - by COPIES of
-// the q workgroups, one per (slot, key range of kpc keys, 16-row q block), which normalise their slot's row, repeat their 16 rows of the
-// product and stream 64 bytes per key of the slot's K cache; attn_fused_ps_kernel (attention_kernels.hip) finishes the scores.  A copy whose
-// keys lie beyond its slot's context leaves once the context length has arrived (the captured step serves every context).
-// Workgroup ids: [0, n_main nG) main (row block = id % n_main, slot group = id / n_main), then the copies (q block fastest: copies of one
-// q block are congruent mod 8 - one XCD, one L2 - because n_main and E / 16 are multiples of 8 for every bark shape).
+// Lock steps at FEW slots (engine_batch.hip: kFewSlotsScores / kFewSlotsProducts; measured in round 5, profiles/r05_few_slot_routes_*.txt): the QKV product as gemv_ln_wg_kernel<PS>
+// with a slot dimension (blockIdx.y).  At 8 slots a lock step is a latency chain whose longest link is the attention: one workgroup per
+// (head, slot, value half) pulls the pair's whole K (164 KB at 640 keys) through one CU to form scores.  The single-utterance step does not:
+// the workgroup that produces 16 consecutive q values also forms that C2 block's partial score against every cached key, spread over the
+// q workgroups' copies.  This kernel does the same per slot: slot b's workgroups normalise ITS row, read the same weight rows (from the XCD's L2
+// after the first slot: ids congruent mod 8 share it, grid.x is a multiple of 8), write q / K / V of slot b through the batched epilogue and the
+// partial scores to ps + b * H * 4 * P; attn_fused_ps_kernel (attention_kernels.hip) finishes them.  Same arithmetic per element as
+// gemv_ln_wg_kernel (C6 LayerNorm, C1 chains, C2 blocks): bit-equal to the lock step's gemm_slots16_kernel + attn_fused_kernel route.
+// A copy whose keys lie beyond its slot's context leaves once the context length has arrived (the lock step's graph is captured for any context,
+// so copies for all 1024 keys are launched).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSlotGroup = 8;
+// PS = false: the same per-slot LayerNorm-fused product without copies and partial scores, for the FC product of a lock step at few slots
+// (any batched epilogue) - ahead of gemm_slots16_kernel<LNF> up to 16 slots.
 template <int NBLK, bool LNB, bool PS>
-__global__ __launch_bounds__(256) void gemv_ln_slotgroup_kernel(const half_t * __restrict__ W, const float * __restrict__ X, const float * __restrict__ ln_g,
-                                                                const float * __restrict__ ln_b, const float * __restrict__ kc0, const StepState * __restrict__ st0, const int M,
-                                                                const int E, const int kpc, const int n_main, const LinArgs a) {
+__global__ __launch_bounds__(256) void gemv_ln_slots_ps_kernel(const half_t * __restrict__ W, const float * __restrict__ X, const float * __restrict__ ln_g,
+                                                               const float * __restrict__ ln_b, const float * __restrict__ kc0, const StepState * __restrict__ st0, const int M,
+                                                               const int E, const int kpc, const LinArgs a) {
     constexpr int K = NBLK * 128;
     constexpr int EPT = K / 64;
-    constexpr int SG = kSlotGroup;
-    __shared__ __attribute__((aligned(16))) half_t xs[SG][K];
+    __shared__ __attribute__((aligned(16))) half_t xs[K];
     __shared__ float qs[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, rg = lane >> 4;
-    const int B = a.nbatch, nG = (B + SG - 1) / SG;
-    [[maybe_unused]] const int n_q = E >> 4;
-    const bool copy = PS && (int) blockIdx.x >= n_main * nG;
-    int wg, s0, ns;
-    [[maybe_unused]] int rep = 0;
-    if (!copy) { wg = (int) blockIdx.x % n_main; s0 = ((int) blockIdx.x / n_main) * SG; ns = min(SG, B - s0); }
-    else { const int j = (int) blockIdx.x - n_main * nG, n_copy = 1024 / kpc; wg = j % n_q; rep = (j / n_q) % n_copy; s0 = j / (n_q * n_copy); ns = 1; }
-    const int row_off = a.parity_rows ? a.parity_rows * (st0->step & 1) : 0;      // the slots of a lock step share the parity of their step
+    const int slot = blockIdx.y;
+    const float * __restrict__ x_f32 = X + (size_t) slot * K;
+    const StepState * __restrict__ st = st0 + slot;
+    const float * __restrict__ kc = kc0 + (size_t) slot * a.kv_slot_stride;
+    [[maybe_unused]] const int n_main = (M + 15) >> 4, n_q = PS ? E >> 4 : 1;
+    const bool copy = PS && (int) blockIdx.x >= n_main;
+    [[maybe_unused]] const int rep = copy ? ((int) blockIdx.x - n_main) / n_q : 0;
+    const int wg = copy ? ((int) blockIdx.x - n_main) % n_q : (int) blockIdx.x;
     const int m = (wg * 4 + wave) * 4 + rg;
     const bool live = m < M;
-    const half_t * wrow = W + (size_t) (row_off + (live ? m : 0)) * K + (c << 3);
-    // wave w normalises the rows of the group's slots w and w + 4: everything they need is requested now
-    float xv[2][EPT], gv[EPT], bv[EPT];
-    #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int ls = wave + 4 * r;
-        if (ls < ns) {
-            const float * __restrict__ xr = X + (size_t) (s0 + ls) * K;
-            #pragma unroll
-            for (int i = 0; i < EPT; i++) xv[r][i] = xr[lane + 64 * i];
-        }
-    }
-    if (wave < ns) {
+    const half_t * wrow = W + (size_t) (live ? m : 0) * K + (c << 3);
+    float xv[EPT], gv[EPT], bv[EPT];
+    if (wave == 0) {
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) xv[i] = x_f32[lane + 64 * i];
         #pragma unroll
         for (int i = 0; i < EPT; i++) {
             gv[i] = ln_g[lane + 64 * i];
@@ -310,43 +300,35 @@ __global__ __launch_bounds__(256) void gemv_ln_slotgroup_kernel(const half_t * _
     [[maybe_unused]] float4 kq[2][4];
     [[maybe_unused]] const int m0 = wg * 16;
     [[maybe_unused]] const int hq = m0 >> 6, blk = (m0 >> 4) & 3;
-    [[maybe_unused]] int n_past_c = 0;
-    if constexpr (PS) { if (copy) n_past_c = st0[s0].n_past; }
+    [[maybe_unused]] int n_past = 0;
+    if constexpr (PS) n_past = st->n_past;
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PS) { if (copy && rep * kpc >= n_past_c) return; }      // uniform per workgroup: none of this copy's keys is cached yet
-    // the epilogues' operands (bias; the slots' context lengths for the K / V rows of a QKV product)
-    EpiPre pre[SG];
-    #pragma unroll
-    for (int s = 0; s < SG; s++) if (s < ns) pre[s] = epilogue_prefetch(a, s0 + s, live ? m : 0, row_off);
-    #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int ls = wave + 4 * r;
-        if (ls < ns) {
-            // ggml_norm (+mul, +add) exactly as gemv_ln_wg_kernel: double sums in four partial chains per lane, Markstein division by the row length
-            double p1[4] = {0.0, 0.0, 0.0, 0.0};
-            #pragma unroll
-            for (int i = 0; i < EPT; i++) p1[i & 3] += (double) xv[r][i];
-            const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
-            const float mean = (float) div_by_const<K>(s1);
-            double p2[4] = {0.0, 0.0, 0.0, 0.0};
-            #pragma unroll
-            for (int i = 0; i < EPT; i++) { xv[r][i] = xv[r][i] - mean; p2[i & 3] += (double) (xv[r][i] * xv[r][i]); }
-            const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
-            const float var = (float) div_by_const<K>(s2);
-            const float scale = 1.0f / sqrtf(var + 1e-5f);
-            #pragma unroll
-            for (int i = 0; i < EPT; i++) {
-                float v = xv[r][i] * scale;
-                v = v * gv[i];
-                if constexpr (LNB) v = v + bv[i];
-                xs[ls][lane + 64 * i] = to_half(v);
-            }
+    if constexpr (PS) { if (copy && rep * kpc >= n_past) return; }      // uniform per workgroup: none of this copy's keys is cached yet
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, 0);       // batched: bias, the slot's context length
+    if (wave == 0) {
+        // ggml_norm (+mul, +add) exactly as gemv_ln_wg_kernel: double sums in four partial chains per lane, Markstein division by the row length
+        double p1[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) p1[i & 3] += (double) xv[i];
+        const double s1 = wave_sum((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        const float mean = (float) div_by_const<K>(s1);
+        double p2[4] = {0.0, 0.0, 0.0, 0.0};
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) { xv[i] = xv[i] - mean; p2[i & 3] += (double) (xv[i] * xv[i]); }
+        const double s2 = wave_sum((p2[0] + p2[1]) + (p2[2] + p2[3]));
+        const float var = (float) div_by_const<K>(s2);
+        const float scale = 1.0f / sqrtf(var + 1e-5f);
+        #pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            float v = xv[i] * scale;
+            v = v * gv[i];
+            if constexpr (LNB) v = v + bv[i];
+            xs[lane + 64 * i] = to_half(v);
         }
     }
     __syncthreads();
     if constexpr (PS) {
         if (copy) {
-            const float * __restrict__ kc = kc0 + (size_t) s0 * a.kv_slot_stride;
             const BufRsrc kr = buf_rsrc(reinterpret_cast<const float4 *>(kc) + ((size_t) hq * 16 + 4 * blk) * 1024 + rep * kpc);     // P == 1024
             #pragma unroll
             for (int i = 0; i < 4; i++) kq[0][i] = buf_ld_f4(kr, (unsigned) tid * 16u, (unsigned) i * 16384u);
@@ -356,68 +338,109 @@ __global__ __launch_bounds__(256) void gemv_ln_slotgroup_kernel(const half_t * _
             }
         }
     }
-    float q_acc = 0.0f;
+    float acc = 0.0f;
     #pragma unroll
-    for (int s = 0; s < SG; s++) {
-        if (s < ns) {
-            float acc = 0.0f;
-            #pragma unroll
-            for (int b = 0; b < NBLK; b++) {
-                const half8 xh = *reinterpret_cast<const half8 *>(&xs[s][(b * 16 + c) << 3]);
-                #pragma unroll
-                for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
-            }
-            acc = wave_xor_add16(acc);
-            if (live && c == 0 && !copy) linear_epilogue_pre(a, s0 + s, m, acc, pre[s]);
-            if (s == 0) q_acc = acc;
-        }
+    for (int b = 0; b < NBLK; b++) {
+        const half8 xh = *reinterpret_cast<const half8 *>(xs + ((b * 16 + c) << 3));
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[b][e], (float) xh[e], acc);
     }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0 && !copy) linear_epilogue_pre(a, slot, m, acc, pre);
     if constexpr (PS) {
+        // the copies cover the keys below (copies per q block) x kpc; a launch whose bound on the context was too small must not pass silently
+        if (blockIdx.x == 0 && tid == 0 && n_past > (((int) gridDim.x - n_main) / n_q) * kpc) const_cast<StepState *>(st)->fault = 1;
         if (copy) {                                              // uniform per workgroup
-            if (c == 0) qs[wave * 4 + rg] = a.bias ? q_acc + pre[0].bias : q_acc;       // the q value the epilogue stores
+            if (c == 0) qs[wave * 4 + rg] = a.bias ? acc + pre.bias : acc;       // the q value the epilogue stores
             __syncthreads();
             float qb[16];
             #pragma unroll
             for (int i = 0; i < 16; i++) qb[i] = qs[i];
-            float * __restrict__ psl = a.ps + (size_t) s0 * (size_t) (E >> 6) * 4 * a.P + ((size_t) hq * 4 + blk) * a.P;
+            float * __restrict__ psl = a.ps + (size_t) slot * (size_t) (E >> 6) * 4 * a.P + ((size_t) hq * 4 + blk) * a.P;
             const int j = rep * kpc + tid;
-            if (j < n_past_c) psl[j] = score_block_f4(kq[0], qb);
-            if (tid + 256 < kpc && j + 256 < n_past_c) psl[j + 256] = score_block_f4(kq[1], qb);
+            if (j < n_past) psl[j] = score_block_f4(kq[0], qb);
+            if (tid + 256 < kpc && j + 256 < n_past) psl[j + 256] = score_block_f4(kq[1], qb);
         }
     }
 }
 
+// The plain decode GEMV (gemv_kernel: one wave = 4 output rows, every chunk of the row requested up front) with a slot dimension - the out-projections of
+// a lock step at few slots (ahead of gemv_batch_kernel, two slots per wave sharing the weight loads, up to 16 slots).  Slot b reads
+// its f16 row X + b K and finishes through the batched epilogue; the weight rows come out of the XCD's L2 after the first slot (grid.x is a multiple of 8
+// for every bark shape).  Same C1 chains.
 template <int NBLK>
-static void launch_slotgroup_n(hipStream_t s, const LinArgs & a) {
-    if constexpr (NBLK <= 8) {
-        const int n_main = (a.M + 15) / 16, nG = (a.nbatch + kSlotGroup - 1) / kSlotGroup;
-        const dim3 b256(256);
-        if (!a.ps) {
-            const dim3 g0(n_main * nG);
-            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slotgroup_kernel<NBLK, true, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, n_main, a);
-            else        hipLaunchKernelGGL((gemv_ln_slotgroup_kernel<NBLK, false, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, n_main, a);
-            return;
-        }
-        // the lock step's graph serves every context: copies for all 1024 keys, two per q block and slot of 512 keys each (as the single-utterance launch at ng = 4)
-        const int n_copy = 2, kpc = 512, n_q = a.E / 16;
-        const dim3 grid(n_main * nG + a.nbatch * n_copy * n_q);
-        if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slotgroup_kernel<NBLK, true, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, n_main, a);
-        else        hipLaunchKernelGGL((gemv_ln_slotgroup_kernel<NBLK, false, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, n_main, a);
-    } else { kernel_fail("bark-hip: the slot-group LayerNorm-fused product supports n_embd <= 1024"); }
+__global__ __launch_bounds__(64) void gemv_slots_kernel(const half_t * __restrict__ W, const half_t * __restrict__ X, const int M, const LinArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, rg = lane >> 4;
+    const int m = blockIdx.x * 4 + rg;
+    const int slot = blockIdx.y;
+    const bool live = m < M;
+    constexpr int K = NBLK * 128;
+    const half_t * wrow = W + (size_t) (live ? m : 0) * K + (c << 3);
+    const half_t * xrow = X + (size_t) slot * K + (c << 3);
+    half8 wv[NBLK], xv[NBLK];
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) { wv[i] = ld_half8_w(wrow + (i << 7)); xv[i] = ld_half8(xrow + (i << 7)); }
+    __builtin_amdgcn_sched_barrier(0);
+    const EpiPre pre = epilogue_prefetch(a, slot, live ? m : 0, 0);
+    float acc = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+        #pragma unroll
+        for (int e = 0; e < 8; e++) acc = fmaf((float) wv[i][e], (float) xv[i][e], acc);
+    }
+    acc = wave_xor_add16(acc);
+    if (live && c == 0) linear_epilogue_pre(a, slot, m, acc, pre);
 }
-void launch_linear_slotgroup(hipStream_t s, const LinArgs & a) {
-    if (!a.batched || !a.x_f32 || !a.ln_g || !a.W || a.wq.qs || (a.K & 127) != 0 || a.knew || a.vt)
-        kernel_fail("bark-hip: the slot-group LayerNorm-fused product takes f32 rows + LayerNorm and f16 weights, K %% 128 == 0");
-    if (a.ps && (a.epi != EPI_QKV || a.P != 1024 || a.M != 3 * a.E || a.K != a.E || !a.st))
-        kernel_fail("bark-hip: the slot-group partial-score QKV product needs block_size 1024");
-    if ((a.epi == EPI_QKV || a.parity_rows) && !a.st) kernel_fail("bark-hip: a QKV product / a parity window needs the slots' states");
+template <int NBLK>
+static void launch_gemv_slots_n(hipStream_t s, const LinArgs & a) {
+    hipLaunchKernelGGL((gemv_slots_kernel<NBLK>), dim3((a.M + 3) / 4, a.nbatch), dim3(64), 0, s, a.W, a.x_f16, a.M, a);
+}
+void launch_linear_slots_gemv(hipStream_t s, const LinArgs & a) {
+    if (!a.batched || !a.x_f16 || a.x_f32 || !a.W || a.wq.qs || (a.K & 127) != 0 || a.K > 4096 || a.parity_rows || a.epi == EPI_QKV)
+        kernel_fail("bark-hip: the per-slot plain GEMV takes f16 rows, f16 weights and a residual / GELU / logits epilogue");
     switch (a.K >> 7) {
-        case 1: launch_slotgroup_n<1>(s, a); break;
-        case 2: launch_slotgroup_n<2>(s, a); break;
-        case 4: launch_slotgroup_n<4>(s, a); break;
-        case 6: launch_slotgroup_n<6>(s, a); break;
-        case 8: launch_slotgroup_n<8>(s, a); break;
-        default: kernel_fail("bark-hip: unsupported K=%d in the slot-group LayerNorm-fused product", a.K);
+        case 1:  launch_gemv_slots_n<1>(s, a); break;
+        case 2:  launch_gemv_slots_n<2>(s, a); break;
+        case 4:  launch_gemv_slots_n<4>(s, a); break;
+        case 6:  launch_gemv_slots_n<6>(s, a); break;
+        case 8:  launch_gemv_slots_n<8>(s, a); break;
+        case 16: launch_gemv_slots_n<16>(s, a); break;
+        case 24: launch_gemv_slots_n<24>(s, a); break;
+        case 32: launch_gemv_slots_n<32>(s, a); break;
+        default: kernel_fail("bark-hip: unsupported K=%d in the per-slot plain GEMV", a.K);
+    }
+}
+
+template <int NBLK>
+static void launch_slots_ps_n(hipStream_t s, const LinArgs & a) {
+    if constexpr (NBLK <= 8) {
+        const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
+        // the lock step's graph serves every context: copies for all 1024 keys, two per q block of 512 keys each (as the single-utterance launch at ng = 4)
+        const int n_copy = 2, kpc = 512;
+        const dim3 grid(n_main + n_copy * n_q, a.nbatch), b256(256);
+        if (!a.ps) {
+            const dim3 g0(n_main, a.nbatch);
+            if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a);
+            else        hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false, false>), g0, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a);
+        }
+        else if (a.ln_b) hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, true, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+        else             hipLaunchKernelGGL((gemv_ln_slots_ps_kernel<NBLK, false, true>), grid, b256, 0, s, a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, kpc, a);
+    } else { kernel_fail("bark-hip: the per-slot partial-score QKV product supports n_embd <= 1024"); }
+}
+void launch_linear_slots_ps(hipStream_t s, const LinArgs & a) {
+    if (!a.batched || !a.x_f32 || !a.ln_g || !a.W || a.wq.qs || (a.K & 127) != 0 || a.knew || a.vt || a.parity_rows)
+        kernel_fail("bark-hip: the per-slot LayerNorm-fused product takes f32 rows + LayerNorm and f16 weights, K %% 128 == 0");
+    if (a.ps && (a.epi != EPI_QKV || a.P != 1024 || a.M != 3 * a.E || a.K != a.E || !a.st))
+        kernel_fail("bark-hip: the per-slot partial-score QKV product needs block_size 1024");
+    if (a.epi == EPI_QKV && !a.st) kernel_fail("bark-hip: a QKV product needs the slots' states");
+    switch (a.K >> 7) {
+        case 1: launch_slots_ps_n<1>(s, a); break;
+        case 2: launch_slots_ps_n<2>(s, a); break;
+        case 4: launch_slots_ps_n<4>(s, a); break;
+        case 6: launch_slots_ps_n<6>(s, a); break;
+        case 8: launch_slots_ps_n<8>(s, a); break;
+        default: kernel_fail("bark-hip: unsupported K=%d in the per-slot partial-score QKV product", a.K);
     }
 }
 
@@ -540,18 +563,6 @@ template <int NBLK>
 static void launch_gemv_batch_n(hipStream_t s, const LinArgs & a) {
     constexpr int BPW = 2;
     dim3 grid((a.M + 3) / 4, (a.nbatch + BPW - 1) / BPW), block(64);
-    // rows that are f16 already (the two out-projections of a lock step): 4 / 8 slots per wave - the weight chunks of a wave are requested once
-    // for all of them (a one-wave workgroup may hold 8 x 8 chunks of x beside them); measured against 2 per wave at 8 / 16 slots (profiles/r05_*)
-    // (register budget of a one-wave workgroup: 8 slots fit up to K = 1024, 4 slots up to K = 2048; beyond, the chunks of x would spill to scratch)
-    if (!a.x_f32 && a.nbatch > 2 && a.slots_per_wave > 2) {
-        if constexpr (NBLK <= 8) {
-            if (a.nbatch > 4 && a.slots_per_wave >= 8) { hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, 8>), dim3(grid.x, (a.nbatch + 7) / 8), block, 0, s, a); return; }
-        }
-        if constexpr (NBLK <= 16) {
-            hipLaunchKernelGGL((gemv_batch_kernel<NBLK, false, false, 4>), dim3(grid.x, (a.nbatch + 3) / 4), block, 0, s, a);
-            return;
-        }
-    }
     if (a.x_f32) {
         if constexpr (NBLK <= 8) {
             if (a.ln_b) hipLaunchKernelGGL((gemv_batch_kernel<NBLK, true, true, BPW>), grid, block, 0, s, a);

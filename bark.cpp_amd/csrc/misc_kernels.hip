@@ -237,8 +237,19 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     StepState * st = st0 + slot;
     // everything the end of the kernel needs from memory is requested now: the stage state, and the position row of the next
     // step's embedding (its token row can only be fetched once the pick is known)
+    // VOLATILE loads: thread 0 rewrites the state at the END of this kernel, and on the fast path no barrier separates that store from the other
+    // waves' last use of `step` (the coarse stage's codebook parity in `tok`).  As plain loads the compiler is free to sink them below the barriers
+    // in between - it did: the scalar load of st->step sat behind the second __syncthreads(), so a wave that fell microseconds behind wave 0
+    // (other contexts' kernels competing for the SIMD) could read the step thread 0 had already advanced, take the other codebook's offset and
+    // write 64 elements of the NEXT token's embedding from the wrong row: one wrong sample for one slot, about once per 10^6 lock steps under 8+
+    // concurrent contexts - round 4's red GPU suite.  A volatile access is not moved across the barrier intrinsic.
+#ifdef BARK_DIAG_PLAIN_STATE_LOADS                              // tools/r05_state_race_demo.sh: the kernel as it was up to round 4, to show the race
     const int np_next = st->n_past + a.n_past_add;
     const int step = st->step;
+#else
+    const int np_next = *reinterpret_cast<const volatile int32_t *>(&st->n_past) + a.n_past_add;
+    const int step = *reinterpret_cast<const volatile int32_t *>(&st->step);
+#endif
     StepState s0{};
     if (tid == 0) s0 = *st;
     constexpr int MAXV = 12;                                   // up to 12288 logits
@@ -280,6 +291,13 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     best = wave_min_i32(best); close = wave_add_i32(close); sum = wave_add_f32(sum);
     if (lane == 0) { red_i[wave] = best; red_c[wave] = close; red_s[wave] = sum; }
     __syncthreads();
+#ifdef BARK_DIAG_LAG_WAVES                                      // the same demo: every wave but the one that rewrites the state falls ~N x 4 us behind
+    {   // one asm statement (no control flow for the compiler to schedule around): waves 1 .. 15 sleep BARK_DIAG_LAG_WAVES x ~4 us
+        const int w_uniform = __builtin_amdgcn_readfirstlane(wave);
+        int n_sleep = w_uniform ? BARK_DIAG_LAG_WAVES : 0;
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2f\n1:\n\ts_sleep 127\n\ts_sub_u32 %0, %0, 1\n\ts_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1b\n2:" : "+s"(n_sleep) :: "scc");
+    }
+#endif
     // every thread finishes the reduction itself (same order, same bits): no broadcast, no further barrier on the fast path
     best = red_i[0]; close = red_c[0]; sum = red_s[0];
     #pragma unroll

@@ -15,22 +15,21 @@ using namespace barkhip;
 
 namespace {
 template <int NBLK> void qkv_slots(const LinArgs & a, int B) {
-    const int n_main = (a.M + 15) / 16, n_q = a.E / 16, nG = (B + kSlotGroup - 1) / kSlotGroup;
-    sim::launch(dim3(n_main * nG + B * 2 * n_q), 256, [&] { gemv_ln_slotgroup_kernel<NBLK, true, true>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 512, n_main, a); });
+    const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
+    sim::launch(dim3(n_main + 2 * n_q, B), 256, [&] { gemv_ln_slots_ps_kernel<NBLK, true, true>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 512, a); });
 }
 template <int NBLK> void qkv_single(const LinArgs & a) {
     const int n_main = (a.M + 15) / 16, n_q = a.E / 16;
     sim::launch(dim3(n_main + 2 * n_q), 256, [&] { gemv_ln_wg_kernel<NBLK, true, true>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, 512, a); });
 }
 template <int NBLK> void fc_slots(const LinArgs & a, int B) {
-    const int n_main = (a.M + 15) / 16, nG = (B + kSlotGroup - 1) / kSlotGroup;
-    sim::launch(dim3(n_main * nG), 256, [&] { gemv_ln_slotgroup_kernel<NBLK, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, n_main, a); });
+    sim::launch(dim3((a.M + 15) / 16, B), 256, [&] { gemv_ln_slots_ps_kernel<NBLK, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, a.E, 0, a); });
 }
 template <int NBLK> void fc_single(const LinArgs & a) {
     sim::launch(dim3((a.M + 15) / 16), 256, [&] { gemv_ln_wg_kernel<NBLK, true, false>(a.W, a.x_f32, a.ln_g, a.ln_b, a.kc, a.st, a.M, 0, a.E, 0, a); });
 }
 template <int NBLK> void proj_slots(const LinArgs & a, int B) {
-    sim::launch(dim3((a.M + 3) / 4, (B + 7) / 8), 64, [&] { gemv_batch_kernel<NBLK, false, false, 8>(a); });
+    sim::launch(dim3((a.M + 3) / 4, B), 64, [&] { gemv_slots_kernel<NBLK>(a.W, a.x_f16, a.M, a); });
 }
 template <int NBLK> void proj_single(const LinArgs & a) {
     sim::launch(dim3((a.M + 3) / 4), 64, [&] { gemv_kernel<NBLK>(a.W, a.x_f16, a.M, 0, a); });
@@ -109,7 +108,7 @@ int sim_fc(int route, const void * W, const float * x, const float * ln_g, const
     return 0;
 }
 
-// out-projection + residual for B slots: res [B][M] f32 updated in place, xh [B][K] f16.  route 0: gemv_batch_kernel with 8 slots per wave; route 1: gemv_kernel per slot
+// out-projection + residual for B slots: res [B][M] f32 updated in place, xh [B][K] f16.  route 0: gemv_slots_kernel; route 1: gemv_kernel per slot
 int sim_proj(int route, const void * W, const void * xh, const float * bias, float * res, int K, int M, int B) {
     LinArgs a;
     a.W = (const half_t *) W; a.M = M; a.K = K; a.N = 1; a.bias = bias; a.epi = EPI_RESID;

@@ -68,9 +68,8 @@ if what in ("part1", "all"):
     ref = out["default"].get("sha")
     print("bits equal to the default arm:", {k: v.get("sha") == ref for k, v in out.items()}, flush=True)
 if what in ("part2", "all"):
-    # round 4's per-slot kernels (measured in call 2 of round 5, profiles/r05_few_slot_routes.txt) were replaced by the slot-group kernels; arms now:
-    arms = {"matrix_core_route": {"BARK_HIP_FEW_SLOTS": "0"}, "few_slot_route": {"BARK_HIP_FEW_SLOTS": "32"},
-            "products_only": {"BARK_HIP_FEW_SLOTS": "32,0"}, "attention_only": {"BARK_HIP_FEW_SLOTS": "0,32"}}
+    arms = {"matrix_core_route": {"BARK_HIP_FEW_SLOTS": "0"}, "default_products_16_scores_8": {}, "products_16_scores_16": {"BARK_HIP_FEW_SLOTS": "16,16"},
+            "products_32_scores_8": {"BARK_HIP_FEW_SLOTS": "32,8"}}
     for name, env in arms.items():
         out["slots_" + name] = run(CHILD2, env)
         print("lock step", name, json.dumps(out["slots_" + name]), flush=True)
