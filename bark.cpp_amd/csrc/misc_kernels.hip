@@ -292,10 +292,13 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     if (lane == 0) { red_i[wave] = best; red_c[wave] = close; red_s[wave] = sum; }
     __syncthreads();
 #ifdef BARK_DIAG_LAG_WAVES                                      // the same demo: every wave but the one that rewrites the state falls ~N x 4 us behind
-    {   // one asm statement (no control flow for the compiler to schedule around): waves 1 .. 15 sleep BARK_DIAG_LAG_WAVES x ~4 us
+    {   // one asm statement (no control flow for the compiler to schedule around): waves 1 .. 15 sleep BARK_DIAG_LAG_WAVES x ~4 us, then the scalar
+        // data cache is invalidated - what the dispatch of any other kernel on a neighbouring CU does to it.  (Without the invalidation the sunk
+        // s_load of st->step HITS the line the wave's earlier scalar loads of the state brought in and returns the old, i.e. right, value: the race
+        // needs a lagging wave AND a concurrent dispatch in that window, which is why it took 8+ busy contexts and ~10^6 lock steps to show.)
         const int w_uniform = __builtin_amdgcn_readfirstlane(wave);
         int n_sleep = w_uniform ? BARK_DIAG_LAG_WAVES : 0;
-        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2f\n1:\n\ts_sleep 127\n\ts_sub_u32 %0, %0, 1\n\ts_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1b\n2:" : "+s"(n_sleep) :: "scc");
+        asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 2f\n1:\n\ts_sleep 127\n\ts_sub_u32 %0, %0, 1\n\ts_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 1b\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n2:" : "+s"(n_sleep) :: "scc");     // (no "memory" clobber: it would pin the plain load in front of this statement)
     }
 #endif
     // every thread finishes the reduction itself (same order, same bits): no broadcast, no further barrier on the fast path

@@ -389,7 +389,7 @@ def main():
         step_us = 1000.0 * out["stage_ms_per_token"]["semantic"]
         us, nbytes = ctx.time_gemv(0, 2, 2400)
         pmc = {}
-        for name in ("r04_pmc_decode_step.json", "r03_pmc_gemv_fc.json"):
+        for name in ("r05_pmc_decode_step.json", "r04_pmc_decode_step.json", "r03_pmc_gemv_fc.json"):
             f = os.path.join(ROOT, "profiles", name)
             if os.path.exists(f):
                 pmc = json.load(open(f)); pmc["file"] = "profiles/" + name
@@ -399,7 +399,9 @@ def main():
                            "achieved": step_bytes / (step_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": step_bytes / (step_us * 1e-6) / 8e12,
                            "us_per_step": step_us, "bytes_per_step": step_bytes,
                            "time_source": "stage_ms_per_token.semantic of this run's timed region (host wall clock of the stage / sampled tokens: includes the prompt pass and the polls)",
-                           "traffic": pmc.get("step_traffic_bytes"), "traffic_note": "HBM-side bytes per decode step at context 640 from the committed PMC summary %s (counters cannot be read inside this run); null when absent" % pmc.get("file"),
+                           "traffic": pmc.get("step_traffic_bytes"),
+                           "traffic_note": "HBM-side bytes per decode step at context %s from the committed PMC summary %s (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes; counters cannot be read inside this run): %.2f x the algorithmic bytes at that context; null when absent"
+                                           % (pmc.get("context", 640), pmc.get("file"), pmc.get("step_traffic_over_algorithmic", float("nan"))),
                            "step_microloop": {"ctx": 640, "us_per_step": mus, "bytes_per_step": mbytes, "GB/s": mbytes / (mus * 1e-6) / 1e9, "frac": mbytes / (mus * 1e-6) / 8e12},
                            "kernel": {"name": "gemv_ln_wg_kernel<6> (LayerNorm + FC 3072x768 f16 + GELU, decode): dominant kernel by time (25 of 62 launches with its QKV / LM-head instances)",
                                       "us_per_launch": us, "bytes_per_launch": nbytes, "GB/s": nbytes / (us * 1e-6) / 1e9, "frac": nbytes / (us * 1e-6) / 8e12,
