@@ -556,9 +556,7 @@ void set_slot_params(bark_context * c, int slot, const Utt & u) {
 // The clone a job's tail runs on (JobTail below): a second set of KV caches, scratch, fine-batch and codec buffers on a stream of its own, kept
 // until bark_free - i.e. a context that runs lock-step jobs holds about twice the run-time memory of one that does not.  Created by
 // bark_hip_reserve_batch / the request collector (explicit, off the hot path) or by the first job with more than one utterance.
-// BARK_HIP_TAIL_CUS=<n> confines the helper's stream to the first n CUs through hipExtStreamCreateWithCUMask, which takes no flags: that stream
-// is a BLOCKING one (it synchronises with the legacy stream), so the switch is for measurements on one context only, not for servers whose
-// threads capture graphs.  false: no clone could be made (said once on stderr); the job keeps its tail on its own stream.
+// false: no clone could be made (said once on stderr); the job keeps its tail on its own stream.
 // BARK_HIP_TAIL_STREAM=0 keeps the tail behind the coarse stage on the job's own stream; read per call: tests flip it
 bool tail_stream_enabled() { const char * e = getenv("BARK_HIP_TAIL_STREAM"); return !(e && !strcmp(e, "0")); }
 
@@ -566,22 +564,15 @@ bool ensure_tail_context(bark_context * c) {
     if (c->tail) return true;
     try {
         c->tail = engine_clone(c, 0);
-        // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever
-        // a CU frees up), optionally confined to a part of the chip
-        const char * pe = getenv("BARK_HIP_TAIL_PRIORITY"), * ce = getenv("BARK_HIP_TAIL_CUS");
-        const int low = pe ? atoi(pe) : 1, cus = ce ? atoi(ce) : 0;
-        if (low || cus > 0) {
+        // the helper's stream yields to the decode chain: lowest priority (workgroups of the chain's small kernels are dispatched first whenever a CU
+        // frees up).  (Round 4 also tried confining it to a CU mask - hipExtStreamCreateWithCUMask yields a BLOCKING stream, unusable beside threads
+        // that capture graphs - and normal priority; neither paid, both knobs are gone.)
+        {
             HIP_OK(hipStreamSynchronize(c->tail->stream));
             HIP_OK(hipStreamDestroy(c->tail->stream)); c->tail->stream = nullptr;
-            if (cus > 0) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < std::min(cus, 256); i++) mask[i >> 5] |= 1u << (i & 31);
-                HIP_OK(hipExtStreamCreateWithCUMask(&c->tail->stream, 8, mask));
-            } else {
-                int least = 0, greatest = 0;
-                HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
-            }
+            int least = 0, greatest = 0;
+            HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_OK(hipStreamCreateWithPriority(&c->tail->stream, hipStreamNonBlocking, least));
         }
         return true;
     } catch (const std::exception & e) {
@@ -637,9 +628,6 @@ struct JobTail {
     static void drop_fine_graphs_of(bark_context * x) { for (auto & g : x->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
     void drop_fine_graphs() { drop_fine_graphs_of(t); }
     void push(const std::vector<int> & utts) {
-        // BARK_HIP_DIAG_NO_TAIL=1 (root-cause runs of round 5 only): no fine passes, no codec - the job returns the semantic and coarse ids
-        static const bool no_tail = getenv("BARK_HIP_DIAG_NO_TAIL") && atoi(getenv("BARK_HIP_DIAG_NO_TAIL")) != 0;
-        if (no_tail) { for (int b : utts) { c->batch_results[(size_t) b].ok = true; good++; } return; }
         if (utts.empty()) return;
         { std::lock_guard<std::mutex> g(mu); for (int b : utts) pending.push_back(b); }
         cv.notify_all();

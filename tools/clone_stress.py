@@ -9,8 +9,8 @@ values and with what the slot held at those positions in the clone's previous jo
 
     python tools/clone_stress.py [iterations=10] [preset=mini] [G=4] [J=3] [seconds=inf]
 
-Arms are environment variables of the engine (set by the caller): BARK_HIP_READBACK=legacy|pinned, BARK_HIP_READBACK_CHECK=1,
-BARK_HIP_TAIL_STREAM=0, BARK_HIP_GRAPH=0, BARK_HIP_POISON=1.  Exit status 1 if anything differed."""
+Arms are environment variables of the engine (set by the caller): BARK_HIP_TAIL_STREAM=0, BARK_HIP_GRAPH=0, BARK_HIP_FEW_SLOTS=0, BARK_HIP_POISON=1,
+BARK_HIP_GUARD=1 (the read-back / no-tail / tail-priority arms of calls 1 - 3 of round 5 were removed with their switches once the root cause was found).  Exit status 1 if anything differed."""
 import os
 import sys
 import threading
@@ -28,7 +28,7 @@ def main():
     G = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     J = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     budget_s = float(sys.argv[5]) if len(sys.argv) > 5 else float("inf")      # stop after this many seconds of iterations
-    KEYS = ("semantic", "coarse") if os.environ.get("BARK_HIP_DIAG_NO_TAIL") else ("semantic", "coarse", "fine", "pcm")
+    KEYS = ("semantic", "coarse", "fine", "pcm")
     import bench
     from bark_amd_loader import load_package
     from oracle.pyoracle import Oracle
