@@ -21,6 +21,14 @@
  * Environment (read at bark_load_model):
  *   BARK_HIP_DEVICE=<n>   HIP device ordinal (default: current device)
  *   BARK_HIP_GRAPH=0|1    replay decode steps from a captured hipGraph (default 1)
+ *   (the other switches: INTEGRATION.md section 2)
+ *
+ * Numerics.  Tokenizer, sampling rules and the token ids of the semantic and coarse stages follow the reference's f16-product / f32-accumulate
+ * arithmetic in one fixed summation order (bit-exact against the repository's CPU oracle, which restates it).  The fine model's weight products
+ * and the codec's convolutions run on the f16 matrix cores in the hardware's own accumulation order: their outputs are bit-exact against the
+ * oracle's emulation of that order and WITHIN TOLERANCE of the reference restatement, not bit-equal to it - fine logits within 2.5e-3, >= 98 % of
+ * the fine ids identical on the same coarse input, codec SNR >= 55 dB on the same codes (tests/test_order_divergence.py; BARK_HIP_CROSSCHECK=1280
+ * keeps the reference restatement on the device).  Parity against ggml itself is unpinned: the reference cannot be built here.
  */
 #pragma once
 #include "bark.h"
