@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Opt-in experiment (BARK_HIP_SLOT_PS, unmeasured at the end of round 4): attn_fused_kernel for lock steps whose QKV product has already formed
+// Lock steps over few live slots (engine_batch.hip: kFewSlotsScores; measured and adopted in round 5): attn_fused_kernel for lock steps whose QKV product has already formed
 // the partial scores of the cached keys (gemv_ln_slots_ps_kernel, kernels.hip: ps [slot][H][4][P]).  The workgroup of a (head, slot[, value
 // half]) then reads 16 bytes of partial scores per key instead of the key's 256 bytes of K: 92 KB instead of 246 KB through its CU at 640
 // keys with two value halves - the K stream was what the kernel's time is made of.  Scores: ((c0 + c1) + (c2 + c3)) * 0.125 over the four
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void attn_slots_mix_kernel(const AttnDecodeArg
 
 void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
     if (a.ps && a.nbatch > 1) {
-        // opt-in experiment (BARK_HIP_SLOT_PS): lock step at few slots, partial scores per slot from gemv_ln_slots_ps_kernel
+        // lock step at few slots: partial scores per slot from gemv_ln_slots_ps_kernel
         if (a.P != 1024 || a.knew || a.vt) kernel_fail("bark-hip: the lock-step partial-score attention takes block_size 1024 and the slots' own caches");
         static const int n_cu2 = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
         if (2 * a.H * a.nbatch <= n_cu2 && !(crosscheck_mask() & 32)) hipLaunchKernelGGL((attn_fused_ps_kernel<2>), dim3(a.H, a.nbatch, 2), dim3(256), 0, s, a);

@@ -122,7 +122,7 @@ struct bark_context {
         barkhip::StepState * state = nullptr; int32_t * out_tokens = nullptr; float * eos_trace = nullptr; float * ln_stats = nullptr;
         float * att32 = nullptr, * h32 = nullptr;        // quantised models: f32 activations per slot
         float * sc = nullptr;                            // [cap][max_H][P] attention scores of a lock step (scores kernel -> mix kernel)
-        float * ps = nullptr;                            // [cap][max_H][4][P] partial scores per slot (opt-in BARK_HIP_SLOT_PS: QKV kernel -> attn_fused_ps_kernel)
+        float * ps = nullptr;                            // [cap][max_H][4][P] partial scores per slot (few-slot lock steps: QKV kernel -> attn_fused_ps_kernel)
         double * u = nullptr;                            // [cap][8192] uniform draws of the slots' own generators (temp > 0)
         size_t ld_logits = 0;
         float * slot_par = nullptr;                      // the slots' own temperatures [cap] and min_eos_p [cap] (bark_hip_request_params)

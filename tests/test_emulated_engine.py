@@ -96,11 +96,11 @@ ctx.free()
 @pytest.mark.slow
 @pytest.mark.skipif(os.environ.get("BARK_SIM_FULL") != "1", reason="about five minutes per arm under emulation (the fine stage): set BARK_SIM_FULL=1")
 def test_few_slot_experiment_gives_the_default_job_on_the_emulated_engine(sim_engine, toy_model):
-    """BARK_HIP_SLOT_PS / BARK_HIP_SLOT_GEMV end to end on the emulated engine: a ragged job of four utterances (one sampled) on
+    """The few-slot lock-step route (BARK_HIP_FEW_SLOTS) end to end on the emulated engine: a ragged job of four utterances (one sampled) on
     eight slots - host plumbing, graph capture per live slot count, the per-slot kernels - gives the ids and the PCM of the default lock-step route."""
     got = []
     procs = []
-    for arm in ({}, {"BARK_HIP_SLOT_PS": "8", "BARK_HIP_SLOT_GEMV": "8"}):
+    for arm in ({"BARK_HIP_FEW_SLOTS": "0"}, {}):
         env = dict(os.environ, BARK_HIP_LIBRARY=sim_engine); env.update(arm)
         procs.append(subprocess.Popen([sys.executable, "-c", _SLOT_JOB_CHILD % (ROOT, toy_model)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:

@@ -162,7 +162,7 @@ def test_attention_rank_order_keeps_a_head_on_one_xcd():
         assert len(owner) == H * Z and all(len(v) <= QT // share + 2 for v in owner.values())
 
 
-# ---- opt-in lock-step route for few slots (BARK_HIP_SLOT_PS): gemv_ln_slots_ps_kernel (kernels.hip) -> attn_fused_ps_kernel (attention_kernels.hip) ----
+# ---- lock-step route for few slots (default up to 8 live slots, BARK_HIP_FEW_SLOTS): gemv_ln_slots_ps_kernel (kernels.hip) -> attn_fused_ps_kernel (attention_kernels.hip) ----
 def _mul32(a, b):
     return np.float32(np.float32(a) * np.float32(b))
 

@@ -1,4 +1,4 @@
-"""The opt-in few-slot lock-step kernels (BARK_HIP_SLOT_PS / BARK_HIP_SLOT_GEMV) were written without a GPU.  This test
+"""The few-slot lock-step kernels (default below 17 / 9 live slots since round 5, BARK_HIP_FEW_SLOTS) were written in round 4 without a GPU.  This test
 RUNS them - on the host: the kernel sources are compiled for x86 against a stand-in for <hip/hip_runtime.h> (tests/simt/hip/hip_runtime.h: one thread per
 work-item, one workgroup at a time, barriers / DPP / readlane as rendezvous) and executed work-item for work-item next to the kernels they must equal bit for
 bit, which the device has already been checked with:
