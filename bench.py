@@ -103,6 +103,21 @@ def gather_batch_results(pcms, idx, n_total: int, rank: int, world: int, device=
     return counts, out
 
 
+def n1_reference(a, n_prompts: int):
+    """The N = 1 point of the N > 1 workload, from the committed single-GPU bench line of the same build (profiles/r05_bench_small_n1.json): the
+    64-prompt job on one GPU (`config5_64_prompts`, or `config5_ragged` with --ragged).  The N > 1 line measures config 5; the N = 1 line's `value` is
+    config 2 (one prompt at a time), so the curve of config 5 starts from THIS number, not from value(1).  None when the workload differs from the
+    committed one (other preset / prompt count / step cap) or the file is absent."""
+    try:
+        if a.preset != "small" or n_prompts != 64 or a.n_semantic != 256 or a.scaling != "strong":
+            return None
+        line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_small_n1.json")).read().strip().splitlines()[-1])
+        leg = line["config5_ragged" if a.ragged else "config5_64_prompts"]
+        return {"audio_s_per_s": leg["audio_s_per_s"], "prompts_per_s": leg["prompts_per_s"], "source": "profiles/r05_bench_small_n1.json (N = 1 run of this build on one MI355X)"}
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def ragged_caps(prompts, lo: int = 64, hi: int = 256):
     """Ragged form of config 5: the step cap of a prompt grows with its length, from `lo` for the shortest prompt of the set to `hi` for
     the longest (the synthetic weights never meet the stop rule, so the caps are where the utterances end: 1.3 - 5.1 s of audio) - the
@@ -322,6 +337,7 @@ def main():
                 "prompts_per_s": len(prompts) * a.steps / dt,
                 "per_rank_s_per_step": {"generate": [float(x[0]) for x in all_ranks], "gather": [float(x[1]) for x in all_ranks]},
                 "roofline": None, "note": "roofline / cpu_baseline are reported by the N = 1 run (single-GPU kernels are the same)",
+                "n1_point_of_this_workload": n1_reference(a, len(prompts)),
                 "scaling_reference": "the N = 1 point of THIS workload is `config5_64_prompts.audio_s_per_s` of the N = 1 line (the 64-prompt job on one GPU), "
                                      "not its `value`: the N = 1 line's `value` is BASELINE config 2 (one prompt at a time, latency mode), so value(N) / (N x value(1)) "
                                      "compares two workloads",
