@@ -13,7 +13,9 @@ synthetic weights / synthetic prompts (no checkpoints offline), n_steps_text_enc
         counts are all-gathered and the PCM is gathered on rank 0 (RCCL over xGMI; edge collectives only).  Total work is fixed, so
         `scaling` is "strong"; `value` = audio seconds of all 64 prompts / MAX-over-ranks time.
 
-  python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched under torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]     (N > 1: one rank per GPU; under torch.distributed.run as the driver launches it, or
+                                                       plain - the process then re-executes itself under that launcher, launch_ranks();
+                                                       --gpus that disagrees with WORLD_SIZE or with the node's GPU count exits 2)
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel against HBM) and, at N = 1, `cpu_baseline` (the CPU oracle timed on
 this host, 4 pinned threads, on the headline workload itself - about 20 s; test infrastructure used as the measured-beside baseline
@@ -104,18 +106,38 @@ def gather_batch_results(pcms, idx, n_total: int, rank: int, world: int, device=
 
 
 def n1_reference(a, n_prompts: int):
-    """The N = 1 point of the N > 1 workload, from the committed single-GPU bench line of the same build (profiles/r05_bench_small_n1.json): the
+    """The N = 1 point of the N > 1 workload, from the newest committed single-GPU bench line (profiles/rNN_bench_small_n1.json; labelled as a committed reference - nothing ties it to the build being run): the
     64-prompt job on one GPU (`config5_64_prompts`, or `config5_ragged` with --ragged).  The N > 1 line measures config 5; the N = 1 line's `value` is
     config 2 (one prompt at a time), so the curve of config 5 starts from THIS number, not from value(1).  None when the workload differs from the
     committed one (other preset / prompt count / step cap) or the file is absent."""
     try:
         if a.preset != "small" or n_prompts != 64 or a.n_semantic != 256 or a.scaling != "strong":
             return None
-        line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_small_n1.json")).read().strip().splitlines()[-1])
+        import glob
+        name = os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_small_n1.json")))[-1])
+        line = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
         leg = line["config5_ragged" if a.ragged else "config5_64_prompts"]
-        return {"audio_s_per_s": leg["audio_s_per_s"], "prompts_per_s": leg["prompts_per_s"], "source": "profiles/r05_bench_small_n1.json (N = 1 run of this build on one MI355X)"}
+        return {"audio_s_per_s": leg["audio_s_per_s"], "prompts_per_s": leg["prompts_per_s"], "source": "committed reference: profiles/%s (an N = 1 run on one MI355X at the commit that file was added in, not measured by this job)" % name}
     except Exception:      # noqa: BLE001
         return None
+
+
+def lock_step_roofline(ctx, slots: int, context: int = 640) -> dict:
+    """`roofline` of an N > 1 line, measured on rank 0 after the timed region: one lock step of the coarse model (the stage a config-5 job spends 60 % of
+    its wall in) over this rank's live slots at `context`, replayed from its hipGraph between two HIP events on the engine's stream.  Algorithmic bytes
+    (SURVEY.md 8d per step, x the slots one launch chain serves): the model's weights ONCE for all slots + every slot's f32 K and V rows."""
+    try:
+        hp = ctx.hparams(1)
+        _, b1 = ctx.time_decode_step(1, context, 8)                       # weights + ONE sequence's K / V rows at this context
+        kv = 2.0 * context * hp["n_embd"] * hp["n_layer"] * 4.0
+        nbytes = b1 + (slots - 1) * kv
+        us = ctx.profile_lock_step(1, slots, context, 20)[-1]["us"]      # "step (graph replay)"
+        return {"bound": "hbm", "unit_of_work": f"one lock step of the coarse model over {slots} live slots at context {context} (graph replay, HIP events on the engine's stream, rank 0)",
+                "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / 8e12,
+                "us_per_step": us, "bytes_per_step": nbytes, "traffic": None,
+                "traffic_note": "PMC passes cannot run inside a multi-rank job; the single-GPU line carries the decode step's counter traffic"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": str(e)}
 
 
 def ragged_caps(prompts, lo: int = 64, hi: int = 256):
@@ -232,6 +254,27 @@ def few_slot_jobs_leg(path: str, prompts, n_semantic: int, deadline: float = flo
     return out
 
 
+def launch_ranks(n: int, all_on_device0: bool = False):
+    """`python bench.py --gpus N` without a launcher: this process replaces itself by the driver's own N > 1 form,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>`
+    (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher).  Refuses (exit 2, nothing on stdout) when the node
+    shows fewer than N GPUs - an N-GPU request must never turn into a line that says n_gpus = 1."""
+    import socket
+    if not all_on_device0:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but this node shows {have} GPU(s): refusing to run\n")
+            sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,16 +292,25 @@ def main():
     ap.add_argument("--no-roofline-legs", action="store_true", help="skip the kernel timing legs (rocprofv3 passes: the statistics then hold the prompts' kernels only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the --n-prompts job split over the ranks (BASELINE config 5); weak = --n-prompts per rank")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, strong scaling: skip the weak-scaling leg (a 64-prompt job per rank) reported beside it")
     ap.add_argument("--ragged", action="store_true", help="N > 1: the ragged job (bench.ragged_caps: step caps 64..256 by prompt length) instead of equal caps")
     ap.add_argument("--dump-pcm", default=None, help="rank 0 writes the gathered PCM of the last step here (.npz; tests)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for the 1-GPU dry run)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N > 1 path on a single GPU (with --backend gloo)")
     a = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and a.gpus > 1:
+        launch_ranks(a.gpus, a.all_ranks_on_device0)            # does not return: `python bench.py --gpus N` IS the N-rank job
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    world = int(world_env or "1")
+    if world != a.gpus:
+        # never print an N = 1 line for an N-GPU request (or the reverse): the driver computes the scaling curve from n_gpus / value
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to run (launch with --nproc-per-node {a.gpus}, or drop the launcher: "
+                         f"`python bench.py --gpus {a.gpus}` starts its own ranks)\n")
+        sys.exit(2)
     if a.all_ranks_on_device0:
         local_rank = 0
     os.environ["BARK_HIP_DEVICE"] = str(local_rank)
@@ -320,7 +372,24 @@ def main():
         per_rank = torch.tensor([t_gen / max(1, a.steps), t_gather / max(1, a.steps)], dtype=torch.float64, device=coll_dev)
         all_ranks = [torch.zeros_like(per_rank) for _ in range(world)]
         dist.all_gather(all_ranks, per_rank)
+        # the weak-scaling point of the same path beside the strong one (per-GPU work fixed: a 64-prompt job of its own on EVERY rank, no gather of PCM -
+        # "no data-path collective"): what a node serving independent batches sees.  A context of its own: the slot count is fixed by a context's first job
+        weak = None
+        if a.scaling == "strong" and not a.no_weak_leg and not a.ragged:
+            wctx = pkg.BarkContext.load_model(path, params, seed=0)
+            wprompts = synth_prompts(a.n_prompts, seed=rank)
+            widx = sorted(range(len(wprompts)), key=lambda i: (len(wprompts[i]), i))
+            run_shard(wctx, wprompts, widx)
+            sync_all()
+            tw = time.perf_counter()
+            wpcm = run_shard(wctx, wprompts, widx)
+            sync_all()
+            wdt, waudio = reduce_timing(time.perf_counter() - tw, sum(len(p) for p in wpcm) / 24000.0, world, device=coll_dev)
+            weak = {"scaling": "weak", "prompts_per_rank": len(wprompts), "audio_s_per_s": waudio / wdt, "prompts_per_s": len(wprompts) * world / wdt,
+                    "wall_ms": wdt * 1e3, "note": "every rank runs its own %d-prompt lock-step job (MAX wall over ranks, SUM of audio); no collective on the data path" % len(wprompts)}
+            wctx.free()
         if rank == 0:
+            roof = lock_step_roofline(ctx, min(64, len(idx)))
             assert len(gathered) == len(prompts) and int(counts.sum()) == sum(len(v) for v in gathered.values())
             if a.dump_pcm:
                 np.savez(a.dump_pcm, **{"p%03d" % i: v for i, v in gathered.items()})
@@ -336,7 +405,8 @@ def main():
                            "prompts_per_step": len(prompts), "audio_s_per_step": audio_total / max(1, a.steps)},
                 "prompts_per_s": len(prompts) * a.steps / dt,
                 "per_rank_s_per_step": {"generate": [float(x[0]) for x in all_ranks], "gather": [float(x[1]) for x in all_ranks]},
-                "roofline": None, "note": "roofline / cpu_baseline are reported by the N = 1 run (single-GPU kernels are the same)",
+                "weak_scaling_leg": weak,
+                "roofline": roof, "note": "cpu_baseline is reported by the N = 1 run (rank 0 at N = 1 only, bench contract)",
                 "n1_point_of_this_workload": n1_reference(a, len(prompts)),
                 "scaling_reference": "the N = 1 point of THIS workload is `config5_64_prompts.audio_s_per_s` of the N = 1 line (the 64-prompt job on one GPU), "
                                      "not its `value`: the N = 1 line's `value` is BASELINE config 2 (one prompt at a time, latency mode), so value(N) / (N x value(1)) "

@@ -96,3 +96,42 @@ def test_cpu_baseline_leg_reports_the_contract_keys(toy_model):
             os.sched_setaffinity(0, before)
     assert c["kind"] == "port" and c["unit"] == "audio-s/s" and 1 <= c["cores"] <= 4 and c["value"] > 0 and "n_steps_text_encoder=16" in c["sample"]
     assert set(c["stage_ms_per_token"]) == {"semantic", "coarse", "fine"}
+
+
+def test_gpus_flag_starts_its_own_ranks_or_refuses(monkeypatch, capsys):
+    """`python bench.py --gpus N` is the N-rank job: without a launcher the process re-executes itself under torch.distributed.run with
+    --nproc-per-node N on 127.0.0.1; when --gpus disagrees with WORLD_SIZE, or the node shows fewer GPUs than N, it exits 2 and prints NO line
+    (an N-GPU request must never produce an n_gpus = 1 record).  The plain two-rank command itself runs in the GPU suite
+    (tests/test_gpu_parity.py::test_two_ranks_gather_the_single_process_pcm)."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--backend", "gloo", "--all-ranks-on-device0"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    argv = seen["argv"]
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    k = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "4", "--steps", "2", "--backend", "gloo", "--all-ranks-on-device0"]
+    # under a launcher whose world differs from --gpus: refused, nothing on stdout
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and capsys.readouterr().out == ""
+    monkeypatch.delenv("WORLD_SIZE")
+    # a node with fewer GPUs than ranks (this container has none): refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and r.stdout.strip() == "" and "refusing" in r.stderr
