@@ -74,7 +74,7 @@ EXPORTS = [
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_generate_batch_ex", "bark_hip_reserve_batch", "bark_hip_profile_lock_step", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
-    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe",
+    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe", "bark_hip_set_fine_order",
     "bark_hip_batcher_create", "bark_hip_batcher_create_ex", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_admitted", "bark_hip_batcher_free",
 ]
 
@@ -123,6 +123,7 @@ def load_library() -> C.CDLL:
     lib.bark_hip_generate_batch_seeded.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint32)]
     lib.bark_hip_generate_batch_ex.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int, C.POINTER(BarkHipRequestParams)]
     lib.bark_hip_reserve_batch.argtypes = [vp, C.c_int]
+    lib.bark_hip_set_fine_order.argtypes = [vp, C.c_int]
     lib.bark_hip_profile_lock_step.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.bark_hip_batch_audio.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float))]
     lib.bark_hip_batch_tokens.argtypes = [vp, C.c_int, C.c_int, ip, C.c_int]
@@ -415,6 +416,11 @@ class BarkContext:
         s = BarkHipStats()
         self._lib.bark_hip_get_stats(self._h, C.byref(s))
         return s.as_dict()
+
+    def set_fine_order(self, order: int):
+        """0: default policy (C1 for generate_audio / stage calls, C1m inside lock-step jobs and fine_many); 1: C1 everywhere; 2: C1m everywhere."""
+        if self._lib.bark_hip_set_fine_order(self._h, int(order)) != 0:
+            raise RuntimeError("bark_hip_set_fine_order failed")
 
     def time_decode_step(self, which: int, ctx: int, iters: int):
         b = C.c_double(0)

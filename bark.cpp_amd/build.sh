@@ -7,6 +7,20 @@ OUT="$HERE/lib"
 mkdir -p "$OUT" "$OUT/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -Wall -Wno-unused-function -I$HERE/../include -I$SRC"
+# --variant <suffix> <extra flags...>: a DIAGNOSTIC library that differs from the product in one object - misc_kernels.hip compiled with the extra flags,
+# linked with the product's other objects (same flags, same object list: nothing to drift) into lib/diag/libbark_<suffix>.so, away from the product library
+# (tools/state_race_demo.sh: the sampler with an injected lag, with and without round 4's race)
+if [ "$1" = "--variant" ]; then
+    SUF="$2"; shift 2
+    [ -f "$OUT/libbark.so" ] || "$0" > /dev/null
+    mkdir -p "$OUT/diag/obj"
+    $HIPCC $FLAGS "$@" -c "$SRC/misc_kernels.hip" -o "$OUT/diag/obj/misc_kernels_$SUF.o"
+    VOBJS=()
+    for f in kernels fast_kernels quant_kernels attention_kernels codec_kernels engine_load engine engine_codec engine_batch engine_timing api batcher model_file tokenizer quantize; do VOBJS+=("$OUT/obj/$f.o"); done
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/diag/libbark_$SUF.so" "${VOBJS[@]}" "$OUT/diag/obj/misc_kernels_$SUF.o"
+    echo "built $OUT/diag/libbark_$SUF.so"
+    exit 0
+fi
 # explicit object list: stale objects of renamed / split sources are never linked
 OBJS=()
 pids=()

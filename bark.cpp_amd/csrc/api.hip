@@ -86,6 +86,9 @@ int bark_get_audio_data_size(struct bark_context * bctx) { return bctx ? (int) b
 int64_t bark_get_load_time(struct bark_context * bctx) { return bctx ? bctx->stats.t_load_us : 0; }
 int64_t bark_get_eval_time(struct bark_context * bctx) { return bctx ? bctx->stats.t_eval_us : 0; }
 
+// Deviation from the reference, kept on purpose: bark.cpp:2403-2407 zeroes the WHOLE statistics struct and bark_generate_audio
+// calls it first (bark.cpp:2131), so the reference's bark_get_load_time reads 0 after any generate call (examples/main prints "load time = 0.00 ms").
+// Here the load time survives a reset: it describes the context, not a call.
 void bark_reset_statistics(struct bark_context * bctx) {
     if (!bctx) return;
     const int64_t t_load = bctx->stats.t_load_us;
@@ -207,6 +210,15 @@ int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat
         off = 0;
         for (int i = 0; i < n; i++) { memcpy(out_concat + off * 8, r[(size_t) i].data(), r[(size_t) i].size() * 4); off += r[(size_t) i].size() / 8; }
         return (int) total;
+    });
+}
+
+int bark_hip_set_fine_order(struct bark_context * bctx, int order) {
+    if (!bctx || order < 0 || order > 2) return -1;
+    return guarded("bark_hip_set_fine_order", -1, [&] {
+        bctx->fine_order = order;
+        if (bctx->tail) bctx->tail->fine_order = order;
+        return 0;
     });
 }
 

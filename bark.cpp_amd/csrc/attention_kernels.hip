@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnDecodeArgs a)
     for (int i = 0; i < 4; i++) {
         const int j = tid + 256 * i;
         float e = 0.0f;
-        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        if (j < ctx) { e = canon_expf(s[i] - mx); lsum += (double) e; }
         es[j] = e;
     }
     lsum = wave_sum(lsum);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fused_ps_kernel(const AttnDecodeArgs
     for (int i = 0; i < 4; i++) {
         const int j = tid + 256 * i;
         float e = 0.0f;
-        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        if (j < ctx) { e = canon_expf(s[i] - mx); lsum += (double) e; }
         es[j] = e;
     }
     lsum = wave_sum(lsum);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
     for (int i = 1; i < 16; i++) mx = fmaxf(mx, red_f[i]);
     if (tid == ctx - 1) sc = snew;
     float e = 0.0f;
-    if (tid < ctx) e = (float) exp((double) (sc - mx));
+    if (tid < ctx) e = canon_expf(sc - mx);
     es[tid] = e;
     const double wsum = wave_sum((double) e);
     if (lane == 0) red_d[wave] = wsum;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(1024) void attn_ps_kernel(const float * __restrict_
 // the orders C2 / C4 / C5 allow: the scores of different keys are independent (C2), the mix of different value dims is independent (C5).
 //   attn_slots_scores_kernel   workgroup = (256-key group, head, slot), thread = key: 16 coalesced float4 of K, one C2 score -> sc [slot][head][P]
 //   attn_slots_mix_kernel<DS>  workgroup = (value slice of 64 / DS dims, head, slot): every thread takes its share of the scores (max, e =
-//                              (float) exp((double)(s - max)), double sum: C4, formed redundantly by the DS slices of a head), then lane
+//                              canon_expf(s - max), double sum: C4, formed redundantly by the DS slices of a head), then lane
 //                              (chain c, 4 dims) walks keys c, c + 16, ... with fmaf (C5) and the 16 chains meet in LDS in tree order.
 // One more kernel boundary (~1.5 us) and 1.5 MB of scores, for 5 x as many workgroups of a quarter of the bytes each.  Used when there are
 // more (head, slot) pairs than CUs (launch_attn_decode); with fewer pairs the single launch is faster: its time is the latency chain
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_slots_mix_kernel(const AttnDecodeArg
     for (int i = 0; i < KPT; i++) {
         const int j = tid + NT * i;
         float e = 0.0f;
-        if (j < ctx) { e = (float) exp((double) (s[i] - mx)); lsum += (double) e; }
+        if (j < ctx) { e = canon_expf(s[i] - mx); lsum += (double) e; }
         es[j] = e;
     }
     lsum = wave_sum(lsum);
@@ -508,7 +508,7 @@ void launch_attn_decode(hipStream_t s, const AttnDecodeArgs & a) {
 // Fused prefill / fine attention: one workgroup (8 waves) per (head, 32-query tile); the 32 x ctx score tile
 // lives in LDS (row stride 1026 floats: conflict-free column reads), so scores never travel through HBM:
 //   1. S = 0.125 * Q K^T   f32 MFMA, wave w takes key tiles w, w+8, ... (C2: one accumulator chain over d)
-//   2. row softmax in LDS   (4 rows per wave; max, e = (float) exp((double)(s - max)), double sum)
+//   2. row softmax in LDS   (4 rows per wave; max, e = canon_expf(s - max), double sum)
 //   3. O = P V              f32 MFMA, wave w owns chains 2w, 2w+1 of C5; p = e * inv formed at the operand read
 //   4. the 16 chains meet in LDS (aliasing the score tile) in tree order
 // ------------------------------------------------------------------------------------------------
@@ -598,12 +598,12 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
         float mx = -INFINITY;
         for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, s[j]);
         mx = wave_max(mx);
-        // four independent exp evaluations per lane and trip: the double-precision exp is a long dependent chain
+        // four independent exp evaluations per lane and trip
         double sum4[4] = {0.0, 0.0, 0.0, 0.0};
         for (int j = lane; j < valid; j += 256) {
             float e[4];
             #pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? (float) exp((double) (s[j + 64 * u] - mx)) : 0.0f;
+            for (int u = 0; u < 4; u++) e[u] = j + 64 * u < valid ? canon_expf(s[j + 64 * u] - mx) : 0.0f;
             #pragma unroll
             for (int u = 0; u < 4; u++) if (j + 64 * u < valid) { s[j + 64 * u] = e[u]; sum4[u] += (double) e[u]; }
         }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
 //      (half h, query q) of tile t holds key  2w + (r >> 3) + 16 (16 t + 2 (r & 7) + h)  - the K rows a lane supplies are permuted accordingly.
 //      C2: one accumulator per block of 16 d, (c0 + c1) + (c2 + c3), * 0.125.
 //   2. softmax in place (C4): a lane holds 64 scores of ITS query; maximum and double sum meet across the two halves by a lane swap and
-//      across the waves through 2 x 1 KB of LDS; e = (float) exp((double)(s - max)), p = e * (float)(1 / sum).
+//      across the waves through 2 x 1 KB of LDS; e = canon_expf(s - max), p = e * (float)(1 / sum).
 //   3. O = P V: register r of the lane IS the A operand of the MFMA that adds keys (.., h = 0) and (.., h = 1) - two consecutive keys of
 //      chain 2w + (r >> 3) - to that chain's accumulator: registers 8 b .. 8 b + 7 of tiles 0 .. 3 walk chain 2w + b in ascending key order.
 //   4. chains 2w + (2w + 1) meet in the wave, the eight waves through LDS in C5's tree order.
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     #pragma unroll
     for (int t = 0; t < 4; t++)
         #pragma unroll
-        for (int r = 0; r < 16; r++) { const float e = (float) exp((double) (sc[t][r] - mx)); sc[t][r] = e; ls[r & 3] += (double) e; }
+        for (int r = 0; r < 16; r++) { const float e = canon_expf(sc[t][r] - mx); sc[t][r] = e; ls[r & 3] += (double) e; }
     double lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
     lsum += __shfl_xor(lsum, 32, 64);
     if (half == 0) red_s[w][l31] = lsum;

@@ -105,6 +105,25 @@ DEVINL float wave_add_f32(float v) {
     v = wave_xor_add16(v);
     return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
+// C4e: THE exponential of every attention softmax: one stated f32 routine, bit-reproducible on a CPU and on CDNA4 because
+// it is made of correctly rounded single operations only (fmaf, one multiply, one subtraction, integer bit moves; the file is compiled with
+// -ffp-contract=off).  Algorithm and constants: the vector expf of ARM's optimised routines, which ggml's f32 soft_max carries as ggml_v_expf
+// (bark.cpp:1322,1513 -> ggml_soft_max_inplace): n = round(x log2 e) by the 1.5 x 2^23 shift, b = x - n ln2 in two steps (hi / lo), 2^n from the
+// exponent bits, degree-5 polynomial in b; 1.45 + 0.5 ulp.  The argument is s - max <= 0; below n = -125 (x < -86.3) the result is defined as +0
+// (no subnormal intermediate ever forms, so the denormal mode of either machine cannot matter).  Rounds 1 - 5 used (float) exp((double) x): 1360
+// fp64 instructions per wave of attn_window_kernel that could not overlap the matrix cores.
+DEVINL float canon_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    float b = fmaf(-n, 0x1.62e4p-1f, x);
+    b = fmaf(-n, 0x1.7f7d1cp-20f, b);
+    const float k = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, z) << 23) + 0x3f800000u);      // 2^n
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u, 0x1.ffffecp-1f * b);
+    return n < -125.0f ? 0.0f : fmaf(k, j, k);
+}
+
 // a / K in double, correctly rounded, for a compile-time row length K (LayerNorm mean and variance, ggml_norm divides the double sums by
 // the float count).  Powers of two scale exactly; otherwise (K = 768) one Newton step on a correctly rounded reciprocal: q0 = RN(a y),
 // r = a - K q0 exactly (fma), q = RN(q0 + r y) is the correctly rounded quotient (Markstein) - three dependent fp64 operations instead of

@@ -75,6 +75,11 @@ struct bark_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool use_graph = true;
+    // Order of the fine model's weight products on f16 model files.  0 (default policy): C1 - the restated reference order, on the
+    // f32 matrix cores - for bark_generate_audio and the stage-level entry points, C1m - the f16 matrix cores' own accumulation - inside lock-step jobs
+    // (in_job) and side-by-side fine passes; 1: C1 everywhere; 2: C1m everywhere (rounds 4 - 5).  BARK_HIP_FINE_ORDER=c1|c1m, bark_hip_set_fine_order.
+    int fine_order = 0;
+    bool in_job = false;                 // a lock-step job (engine_generate_batch) or a side-by-side fine pass is running on this context
     int fast_gemm = 0;                   // BARK_HIP_FAST_GEMM=1: N > 1 products on the f16 matrix cores in hardware accumulation order (non-canonical, tolerance mode)
     int decode_ng = 4;                                  // key groups (of 256) the decode kernels being enqueued may assume: ctx <= 256 ng
 
@@ -107,7 +112,7 @@ struct bark_context {
     barkhip::half_t * cbuf_hh[3] = {nullptr, nullptr, nullptr};
     float * c_gi = nullptr, * c_cell = nullptr, * c_cell2 = nullptr; barkhip::half_t * c_hseq_h = nullptr, * c_xt_h = nullptr, * c_hseq2_h = nullptr; size_t c_T = 0;
     int32_t * d_codes = nullptr; size_t d_codes_elems = 0;
-    hipGraphExec_t fine_graphs[8] = {};                 // one captured forward pass + pick per predicted codebook
+    hipGraphExec_t fine_graphs[16] = {};                // one captured forward pass + pick per predicted codebook, [8 * (products in C1m) + codebook]
     int * d_lstm_t = nullptr;                           // step counter of the replayed LSTM block
     int * d_codec_T = nullptr;                          // frame counts of the utterances being decoded and their prefix sums (CodecBatch)
     struct LstmGraph { hipGraphExec_t exec = nullptr; int B = 0; const float * out = nullptr; const float * gi = nullptr; } lstm_graph;    // 64 wave-front steps

@@ -34,10 +34,13 @@ float * layer_k(const GptModel & m, int l) { return m.kcache + m.kv_layer_stride
 float * layer_v(const GptModel & m, int l) { return m.vcache + m.kv_layer_stride * (size_t) l; }
 float * layer_vt(const GptModel & m, int l) { return m.vtcache ? m.vtcache + m.kv_layer_stride * (size_t) l : nullptr; }
 
-// BARK_HIP_CROSSCHECK bit 8 (256) keeps the fine model on the C1 chains of the f32 matrix cores (gemm_kernel) - the order of rounds 1 - 3, which the
-// oracle reproduces with set_fine_mfma(False)
+// The fine model's products of an f16 file: C1 chains on the f32 matrix cores (gemm_kernel; the restated reference order, the oracle's default) or C1m on
+// the f16 matrix cores (gemm_f16_tile_kernel; the oracle follows with set_fine_mfma(True)) - bark_context::fine_order.  Default policy: C1 for
+// bark_generate_audio and the stage entry points (config 2 is bit-exact to the restated reference end to end), C1m inside lock-step jobs, whose fine
+// stage is a third of the wall clock under C1.  BARK_HIP_CROSSCHECK bit 8 (256) = C1 everywhere (as in rounds 4 - 5).
 bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool causal) {
-    return !causal && &m == &c->gpt[2] && !m.q4 && !m.w32 && (m.hp.n_embd & 63) == 0 && !(crosscheck_mask() & 256);
+    if (causal || &m != &c->gpt[2] || m.q4 || m.w32 || (m.hp.n_embd & 63) != 0 || (crosscheck_mask() & 256)) return false;
+    return c->fine_order == 2 || (c->fine_order == 0 && c->in_job);
 }
 
 RowBufs own_rows(bark_context * c) {
@@ -628,7 +631,7 @@ std::vector<int32_t> engine_fine(bark_context * c, const std::vector<int32_t> & 
                     else launch_sample_rows_multinomial(c->stream, c->logits, cs, 1024, cs, p.fine_temp, c->d_u + (size_t) (nn - nc) * 1024, pick_dst, 1, c->d_state);
                 };
                 if (c->use_graph && rel == 0) {
-                    hipGraphExec_t & g = c->fine_graphs[nn];
+                    hipGraphExec_t & g = c->fine_graphs[nn + (fine_products_on_f16_mfma(c, m, false) ? 8 : 0)];
                     if (!g) {
                         hipGraph_t graph = nullptr;
                         HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -706,6 +709,7 @@ std::vector<std::vector<int32_t>> engine_fine_many(bark_context * c, const std::
     const int nc = p.n_coarse_codebooks, nf = p.n_fine_codebooks, cs = p.codebook_size;
     if (nc != 2 || nf != 8 || cs != 1024) throw std::runtime_error("fine: only 2 -> 8 codebooks of 1024 entries are supported");
     if (m.q4 || m.w32 || c->host_sampling) throw std::runtime_error("fine_many: f16 model files, device sampling");
+    const JobScope job(c);                                   // windows side by side are the job's pass: products in C1m under the default policy
     const int U = (int) coarse.size();
     const bool greedy = p.fine_temp == 0.0f;
     if (!greedy && (!rngs || (int) rngs->size() != U)) throw std::runtime_error("fine_many: one generator per utterance is needed for fine_temp > 0");

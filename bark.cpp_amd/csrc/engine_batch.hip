@@ -605,6 +605,7 @@ struct JobTail {
     std::vector<int> codec_wait;
     int good = 0;
     float saved_fine_temp = 0.0f;
+    std::unique_ptr<JobScope> tail_scope;                        // the clone runs the job's fine passes: same order of the products as the job's context
 
     JobTail(bark_context * job, std::vector<Utt> & utts, bool second_stream) : c(job), t(job), us(utts) {
         if (second_stream && !ensure_tail_context(c)) second_stream = false;
@@ -618,12 +619,13 @@ struct JobTail {
             t->stats = bark_hip_stats{}; t->stats.t_load_us = t_load;
         }
         saved_fine_temp = t->params.fine_temp;
-        if (t != c) th = std::thread([this] { run(); });
+        if (t != c) { t->fine_order = c->fine_order; tail_scope.reset(new JobScope(t)); th = std::thread([this] { run(); }); }
     }
     ~JobTail() {
         { std::lock_guard<std::mutex> g(mu); closed = true; abandon = true; }
         cv.notify_all();
         if (th.joinable()) th.join();
+        tail_scope.reset();
     }
     static void drop_fine_graphs_of(bark_context * x) { for (auto & g : x->fine_graphs) if (g) { (void) hipGraphExecDestroy(g); g = nullptr; } }
     void drop_fine_graphs() { drop_fine_graphs_of(t); }
@@ -737,6 +739,7 @@ struct JobTail {
 // waits the batch is compacted (the last slot moves into the hole), so every lock step runs over live utterances only.
 int engine_generate_batch(bark_context * c, const char * const * texts, int n, const uint32_t * seeds, const bark_hip_request_params * rps, const BatchAdmit * admit) {
     HIP_OK(hipSetDevice(c->device));
+    const JobScope job(c);
     const bark_context_params & p = c->params;
     if (n <= 0 || n > 4096) throw std::runtime_error("generate_batch: 1..4096 utterances per call");
     if (admit && (c->host_sampling || c->gpt[0].hp.n_embd != c->gpt[1].hp.n_embd || c->any_w32)) admit = nullptr;     // the sequential fallback takes the job as given

@@ -95,6 +95,13 @@ float * layer_vt(const GptModel & m, int l);
 struct RowBufs { float * x, * q; half_t * xn, * att, * hbuf, * q16, * k16, * vt16; float * logits; const int32_t * tokens; int plane; };
 RowBufs own_rows(bark_context * c);
 bool fine_products_on_f16_mfma(const bark_context * c, const GptModel & m, bool causal);
+// marks a context as running a lock-step job / a side-by-side fine pass for the lifetime of the object (bark_context::fine_order's default policy)
+struct JobScope {
+    bark_context * c; bool prev;
+    explicit JobScope(bark_context * ctx) : c(ctx), prev(ctx->in_job) { ctx->in_job = true; }
+    ~JobScope() { c->in_job = prev; }
+    JobScope(const JobScope &) = delete; JobScope & operator=(const JobScope &) = delete;
+};
 // seq > 0: the N rows are N / seq independent sequences (fine windows), sequence z with its cache at kbase / vbase + z * kv_seq_stride
 void run_layers_rows(bark_context * c, GptModel & m, int N, bool causal, float * kbase = nullptr, float * vbase = nullptr, int pos0 = 0,
                      const RowBufs * rb = nullptr, int seq = 0, size_t kv_seq_stride = 0, const SeqTab * seqtab = nullptr);

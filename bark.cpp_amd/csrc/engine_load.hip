@@ -233,6 +233,12 @@ bark_context * engine_load(const char * path, const bark_context_params & params
         if (!strcmp(e, "1")) ctx->fast_gemm = 1;
         else if (strcmp(e, "0") && *e) throw std::runtime_error("BARK_HIP_FAST_GEMM accepts 0 or 1");
     }
+    if (const char * e = getenv("BARK_HIP_FINE_ORDER")) {
+        // order of the fine model's products on f16 files (bark_context::fine_order): "c1" / "c1m" everywhere; unset or "" = the default policy
+        if (!strcmp(e, "c1")) ctx->fine_order = 1;
+        else if (!strcmp(e, "c1m")) ctx->fine_order = 2;
+        else if (*e) throw std::runtime_error("BARK_HIP_FINE_ORDER accepts c1 or c1m");
+    }
     // non-blocking: the legacy stream neither waits for this one nor is refused while it captures a graph - contexts (clones) of one process run
     // from several host threads, and a plain hipMemcpy of one thread must not collide with a capture of another (tools/staggered_jobs.py)
     HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -534,7 +540,7 @@ bark_context * engine_clone(bark_context * src, uint32_t seed) {
         ctx->gpt[g].bench_graph = nullptr;
     }
     ctx->codec = src->codec;
-    ctx->device = src->device; ctx->use_graph = src->use_graph; ctx->fast_gemm = src->fast_gemm;
+    ctx->device = src->device; ctx->use_graph = src->use_graph; ctx->fast_gemm = src->fast_gemm; ctx->fine_order = src->fine_order;
     ctx->weights = src->weights; ctx->weight_bytes = src->weight_bytes;
     ctx->max_E = src->max_E; ctx->max_H = src->max_H; ctx->P = src->P; ctx->any_q4 = src->any_q4; ctx->any_w32 = src->any_w32;
     HIP_OK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <stdexcept>
 
 using namespace barkhip;
@@ -170,6 +171,9 @@ double engine_time_fine_pass(bark_context * c, int iters, double * flops_per_pas
         HIP_OK(hipMemcpyAsync(c->fine_batch.tokens, buf.data(), buf.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     } else upload_tokens(c, buf.data(), buf.size());
+    // Z > 1 is the pass of a lock-step job (engine_fine_many): C1m products under the default policy of bark_context::fine_order
+    std::unique_ptr<JobScope> job;
+    if (Z > 1) job.reset(new JobScope(c));
     auto pass = [&](int nn) { if (Z > 1) run_fine_forward(c, nn, 1024, &rb, Z); else run_fine_forward(c, nn, 1024); };
     pass(4);
     HIP_OK(hipStreamSynchronize(c->stream));

@@ -347,6 +347,17 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
     }
     int tok = best;
     if (a.mode != 0) { eos_p = 0.0f; tok += a.token_base + ((step & 1) ? 1024 : 0); }     // slice start (bark.cpp:1829-1841)
+    // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
+    if (embed && np_next < a.P) {
+        const int t = min(max(tok, 0), a.n_in - 1);
+        a.x[(size_t) slot * a.E + tid] = wte_elem(a.wte, a.wte_q, a.E, t, tid) + pe_v;
+    }
+    // The state is rewritten LAST, behind a barrier that every wave reaches only after its last use of `step` / `np_next` (a load cannot be sunk below
+    // its use, so every wave's reads of the state are complete when it arrives here): the ordering of round 5's fix (volatile loads, kept above because
+    // they also keep the requests early) no longer rests on how the compiler treats a volatile access next to the barrier intrinsic (advisor, round 5).
+#ifndef BARK_DIAG_PLAIN_STATE_LOADS
+    __syncthreads();
+#endif
     if (tid == 0) {
         if (a.mode == 0) {
             // eos_p = probability of the LAST logit (bark.cpp:217-218,233-234)
@@ -360,11 +371,6 @@ __global__ __launch_bounds__(1024) void sample_greedy_kernel(const float * __res
         st->step = step + 1;
         st->n_past = np_next;
         st->last_eos_p = eos_p;
-    }
-    // embedding of the sampled token for the next decode step (bark.cpp:1250-1259): x = wte[tok] + wpe[n_past]
-    if (embed && np_next < a.P) {
-        const int t = min(max(tok, 0), a.n_in - 1);
-        a.x[(size_t) slot * a.E + tid] = wte_elem(a.wte, a.wte_q, a.E, t, tid) + pe_v;
     }
     TRACE_END(a.tr);
 #ifdef BARK_TRACE

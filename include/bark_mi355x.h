@@ -197,6 +197,12 @@ BARK_API double bark_hip_time_fine_pass(struct bark_context * bctx, int iters, d
 BARK_API double bark_hip_time_fine_passes(struct bark_context * bctx, int n_windows, int iters, double * flops_per_pass);
 
 /* Library / device description (static string). */
+// Order of the fine model's weight products on f16 model files (bark.cpp:1489,1533,1552,1558,1573: ggml_mul_mat of the fine graph).
+//   0  default policy: C1 (the restated reference order; f32 matrix cores) for bark_generate_audio and the stage-level entry points - greedy fine ids are
+//      bit-equal to the CPU restatement of the reference - and C1m (the f16 matrix cores' own accumulation, >= 98 % of the ids equal, logits within 2.5e-3)
+//      inside lock-step jobs (bark_hip_generate_batch*, the request collector) and bark_hip_fine_many;
+//   1  C1 everywhere;   2  C1m everywhere (the behaviour of rounds 4 - 5).     Environment: BARK_HIP_FINE_ORDER=c1|c1m at load.  Returns 0, -1 on a bad argument.
+BARK_API int bark_hip_set_fine_order(struct bark_context * bctx, int order);
 BARK_API const char * bark_hip_describe(struct bark_context * bctx);
 
 #ifdef __cplusplus

@@ -442,10 +442,10 @@ struct Numerics {
     //      path computes on an AVX2 host, restated from upstream ggml (not in /root/reference: SURVEY.md A.4)
     //   2  one sequential fmaf chain over ascending k
     int dot_order = 0;
-    // The fine model's weight products (f16 model files, act_round_f16 on, dot_order 0) in the order of CDNA4's v_mfma_f32_32x32x16_f16 - the
-    // instruction the engine runs them on - restated in mfma_f16_emu.h (C1m).  0: the C1 chains as for the other models
-    // (the CPU-friendly order: what bench.py's cpu_baseline leg times, and what the fixtures of rounds 1 - 3 were made with).
-    int fine_mfma = 1;
+    // The fine model's weight products (f16 model files, act_round_f16 on, dot_order 0).  0 (default since round 6): the C1 chains as for the other
+    // models - the restatement of the reference's arithmetic, what the engine's bark_generate_audio computes.  1: the order of CDNA4's
+    // v_mfma_f32_32x32x16_f16, restated in mfma_f16_emu.h (C1m) - what the engine's lock-step jobs run their fine passes in.
+    int fine_mfma = 0;
     // The codec's convolutions (every one whose input channel count is a multiple of 8) in the same matrix-core order, over the axis
     // kd = k * cin + ci (transposed conv: tap * cin + ci per output phase) - order C9m; 0: one fmaf chain in (ci, k) order (C9).
     int codec_mfma = 1;
@@ -520,14 +520,34 @@ static void round_rows(const Oracle & o, float * x, size_t n, int nth = 1) {
     #pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && n >= 65536)
     for (size_t i = 0; i < n; i++) x[i] = round_h(x[i]);
 }
-// ggml_soft_max over one row of `n` valid entries: max, exp, double sum, scale by (float)(1/sum).
-// Canonical exp: e = (float) exp((double)(s - max)) - a double-precision exp rounded once, so that
-// the CPU libm and the GPU's device libm (both < 1 ulp in double) agree on the float result.
+// C4e: the exponential of ggml's f32 soft_max (bark.cpp:1322,1513 -> ggml_soft_max_inplace -> ggml_vec_soft_max_f32).  ggml (third-party, its
+// submodule is absent from /root/reference) evaluates it with ggml_v_expf on the SIMD body of a row: the vector expf of ARM's optimised
+// routines - n = round(x log2 e) by adding 1.5 x 2^23, b = x - n ln2 (hi / lo split), 2^n built from the exponent bits, a degree-5 polynomial
+// in b, all fused multiply-adds.  Restated here operation for operation with that published routine's constants, as ONE scalar definition for
+// every element (ggml's scalar expf tail depends on the host's vector width).  x = s - max <= 0; below n = -125 the
+// value is defined as +0.  Every operation is a correctly rounded IEEE single operation: the same bits on any CPU and on CDNA4.
+// (Rounds 1 - 5 defined C4 as (float) exp((double) x): neither ggml's arithmetic nor cheap on a GPU.)
+static inline float canon_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    float b = fmaf(-n, 0x1.62e4p-1f, x);
+    b = fmaf(-n, 0x1.7f7d1cp-20f, b);
+    uint32_t zb; memcpy(&zb, &z, 4);
+    const uint32_t kb = (zb << 23) + 0x3f800000u;
+    float k; memcpy(&k, &kb, 4);                                  // 2^n
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u, 0x1.ffffecp-1f * b);
+    return n < -125.0f ? 0.0f : fmaf(k, j, k);
+}
+extern "C" float bark_oracle_canon_expf(float x) { return canon_expf(x); }       // tests: the routine against exact exponentials
+
+// ggml_soft_max over one row of `n` valid entries: max, exp (C4e), double sum, scale by (float)(1/sum).
 static void softmax_row(float * s, int n) {
     float mx = -INFINITY;
     for (int i = 0; i < n; i++) mx = std::max(mx, s[i]);
     double sum = 0.0;
-    for (int i = 0; i < n; i++) { float e = (float) exp((double) (s[i] - mx)); s[i] = e; sum += (double) e; }
+    for (int i = 0; i < n; i++) { float e = canon_expf(s[i] - mx); s[i] = e; sum += (double) e; }
     const float inv = (float) (1.0 / sum);
     for (int i = 0; i < n; i++) s[i] *= inv;
 }
@@ -1280,7 +1300,8 @@ static bool coarse_stage(Oracle & o, const Params & p, const std::vector<int32_t
 }
 
 // bark_eval_fine_encoder (bark.cpp:1961-2059).  coarse: [T][2] -> fine: [T][8].
-// T > 1024 is rejected: the reference's windowing there is undefined behaviour.
+// T > 1024 (several windows): implemented; the one place where the reference's store index is undefined behaviour is
+// restated from the algorithm it was ported from - see the comment at the store below.
 static bool fine_stage(Oracle & o, const Params & p, const std::vector<int32_t> & coarse, std::vector<int32_t> & fine_out, int nth) {
     Gpt & m = o.fine;
     const int64_t t0 = now_us();

@@ -35,6 +35,27 @@ class OrcResult(C.Structure):
                 ("n_sample_semantic", C.c_int64), ("n_sample_coarse", C.c_int64), ("n_sample_fine", C.c_int64)]
 
 
+# Which order the fine model's weight products follow when an Oracle instance has not been told explicitly (set_fine_mfma): False = C1, the
+# restatement of the reference's arithmetic (what bark_generate_audio and the stage-level entry points of the engine compute); True = C1m, the f16
+# matrix cores' accumulation order that lock-step jobs run their fine passes in.  tests/conftest.py switches it for tests marked `lock_step_job`.
+JOB_ORDER = False
+
+
+class job_order:
+    """with pyoracle.job_order(): ... - oracle calls inside compute what a lock-step job of the engine computes (fine products in C1m)."""
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global JOB_ORDER
+        self.prev, JOB_ORDER = JOB_ORDER, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global JOB_ORDER
+        JOB_ORDER = self.prev
+
+
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
@@ -68,6 +89,10 @@ class Oracle:
         if not self.h:
             raise RuntimeError(f"oracle: failed to load {model_path}")
         self.n_threads = n_threads
+        self._fine_mfma = None                      # None: follow pyoracle.JOB_ORDER at every call
+
+    def _sync_order(self):
+        self.lib.orc_set_fine_mfma(self.h, int(JOB_ORDER if self._fine_mfma is None else self._fine_mfma))
 
     def close(self):
         if self.h:
@@ -89,8 +114,10 @@ class Oracle:
         self.lib.orc_set_dot_order(self.h, int(order))
 
     def set_fine_mfma(self, on: bool = True):
-        """The fine model's weight products in the f16 matrix cores' order (default, what the engine computes) or as C1 chains (Numerics::fine_mfma)."""
-        self.lib.orc_set_fine_mfma(self.h, int(on))
+        """The fine model's weight products as C1 chains (False: the restated reference order, the default) or in the f16 matrix cores' order C1m (True: what
+        lock-step jobs of the engine compute; Numerics::fine_mfma).  None: back to following pyoracle.JOB_ORDER."""
+        self._fine_mfma = None if on is None else bool(on)
+        self._sync_order()
 
     def set_codec_mfma(self, on: bool = True):
         """The codec's convolutions in the f16 matrix cores' order over kd = k * cin + ci (default, C9m) or as (ci, k) fmaf chains (C9)."""
@@ -140,6 +167,7 @@ class Oracle:
         tokens = _i32(tokens_8x1024).reshape(8, 1024)
         n_out = self.hparams(2)["n_out"]
         logits = np.zeros((1024, n_out), np.float32)
+        self._sync_order()
         if self.lib.orc_fine_eval(self.h, tokens.ctypes.data, nn, logits.ctypes.data, self.n_threads) != 0:
             raise RuntimeError("oracle fine_eval failed")
         return logits
@@ -165,6 +193,7 @@ class Oracle:
     def fine(self, coarse_Tx2, p: OrcParams) -> np.ndarray:
         co = _i32(coarse_Tx2).reshape(-1, 2)
         out = np.zeros((max(len(co), 1), 8), np.int32)
+        self._sync_order()
         T = self.lib.orc_fine(self.h, C.byref(p), co.ctypes.data, len(co), out.ctypes.data, self.n_threads)
         if T < 0:
             raise RuntimeError("oracle fine stage failed")
@@ -194,6 +223,7 @@ class Oracle:
         fi = np.zeros((4096, 8), np.int32)
         pcm = np.zeros(4096 * 320, np.float32)
         res = OrcResult()
+        self._sync_order()
         rc = self.lib.orc_generate(self.h, C.byref(p), text.encode("utf-8"), sem.ctypes.data, co.ctypes.data,
                                    fi.ctypes.data, pcm.ctypes.data, C.byref(res), self.n_threads)
         if rc != 0:

@@ -12,6 +12,10 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "boundary: GPU suite group 2 - the reference's own binaries on this engine, ranks of bench.py")
+    config.addinivalue_line("markers", "lock_step_job: GPU suite group 3 - runs lock-step jobs; the oracle computes the fine products in the jobs' order (C1m)")
+    config.addinivalue_line("markers", "concurrency: GPU suite group 4 (last) - clones on host threads, request collector, servers, soaks")
+    config.addinivalue_line("markers", "job_order: the oracle computes the fine products in the lock-step jobs' order (C1m) during this test")
     # a fresh checkout has no binaries (they are git-ignored): build the product library and the oracle once, exactly as
     # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  A failed build fails the run - no fallback.
     import subprocess
@@ -24,25 +28,25 @@ def pytest_configure(config):
 
 # Order of the GPU suite (the driver runs `pytest tests -x -q -m gpu`): a failure must not hide the tests that pin the hot path row by row, so the
 # per-row parity tests run FIRST and the widest, most concurrent tests LAST (round 4 ended red on a concurrency test that was collected first and
-# hid ~100 row-level tests behind `-x`).  Groups, in order; inside a group the file order is kept:
-#   0 loader / device           1 per-row parity against the oracle (formats; bark-small / bark-large shapes)
-#   2 boundary binaries, ranks  3 lock-step jobs (N1)          4 concurrency: clones on host threads, request collector, servers, soaks, opt-in experiments
-_GPU_GROUP_BY_NAME = {
-    2: ("test_reference_cli_binary", "test_reference_http_server_binary", "test_two_ranks_", "test_config5_rank_shard"),
-    3: ("test_in_engine_batch", "test_larger_lock_step_batches", "test_batch_with_unequal_lengths", "test_lock_step_batch_", "test_q4_0_generate_and_lock_step_batch",
-        "test_randomised_lock_step_jobs", "test_job_larger_than_the_slots", "test_job_tail_on_a_second_stream", "test_small_ragged_job", "test_lock_step_time_line_hook",
-        "test_ragged_job_on_quantised", "test_few_slot_"),
-    4: ("test_cloned_contexts_", "test_request_batcher_", "test_request_collector_", "test_native_batch_server", "test_device_and_host_sampling_agree_on_many",
-        "test_concurrent_"),
-}
+# hid ~100 row-level tests behind `-x`).  The group of a test is set by an explicit marker (round 5's name-prefix lists are gone):
+#   0 loader / device (tests/test_gpu_loader.py, two named tests)
+#   1 per-row parity against the oracle (formats; bark-small / bark-large shapes): the unmarked
+#     tests of tests/test_gpu_parity.py
+#   2 @pytest.mark.boundary        the reference's own binaries on this engine, ranks of bench.py
+#   3 @pytest.mark.lock_step_job   lock-step jobs (N1)
+#   4 @pytest.mark.concurrency     clones on host threads, request collector, servers, soaks
+#   5 any other GPU test without a marker (a new file's tests land LAST, never in front of the row-level group)
+_GPU_GROUP_OF_MARKER = (("concurrency", 4), ("lock_step_job", 3), ("boundary", 2))
 
 
 def _gpu_group(item):
-    name = item.originalname if getattr(item, "originalname", None) else item.name
-    for grp, prefixes in _GPU_GROUP_BY_NAME.items():
-        if name.startswith(prefixes):
+    for marker, grp in _GPU_GROUP_OF_MARKER:
+        if item.get_closest_marker(marker):
             return grp
-    return 0 if "test_gpu_loader" in item.nodeid or name in ("test_library_describes_a_gfx950_device", "test_hparams") else 1
+    name = item.originalname if getattr(item, "originalname", None) else item.name
+    if "test_gpu_loader" in item.nodeid or name in ("test_library_describes_a_gfx950_device", "test_hparams"):
+        return 0
+    return 1 if "test_gpu_parity.py" in item.nodeid else 5
 
 
 def pytest_collection_modifyitems(config, items):
@@ -53,6 +57,19 @@ def pytest_collection_modifyitems(config, items):
     gpu_sorted = sorted(gpu, key=lambda it: order[id(it)])
     rest = [it for it in items if not it.get_closest_marker("gpu")]
     items[:] = rest + gpu_sorted
+
+
+@pytest.fixture(autouse=True)
+def _oracle_order_of_the_test(request):
+    """Tests marked `lock_step_job` or `job_order` compare lock-step jobs of the engine with the oracle: inside them the oracle computes the fine
+    model's products in the order the jobs use (C1m, pyoracle.JOB_ORDER); everywhere else it computes the restated reference order C1, which is what
+    bark_generate_audio and the stage-level entry points compute."""
+    if request.node.get_closest_marker("lock_step_job") or request.node.get_closest_marker("job_order"):
+        from oracle import pyoracle
+        with pyoracle.job_order(True):
+            yield
+    else:
+        yield
 
 
 @pytest.fixture(scope="session")

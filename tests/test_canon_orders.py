@@ -86,9 +86,46 @@ def test_c1_weight_dot(lib, K):
     assert abs(float(seq) - float(want)) < 1e-4
 
 
+def canon_expf(x) -> np.float32:
+    """C4e in exact rational arithmetic, one rounding per stated operation: n = round(x log2 e) by the 1.5 x 2^23 shift,
+    b = x - n ln2 (hi, lo), 2^n from the exponent bits, degree-5 polynomial - the vector expf of ARM's optimised routines / ggml_v_expf."""
+    f = np.float32
+    h = lambda t: f(float.fromhex(t))
+    x = f(x)
+    r = h("0x1.8p23")
+    z = fma32(x, h("0x1.715476p+0"), r)
+    n = add32(z, -r)
+    b = fma32(-n, h("0x1.62e4p-1"), x)
+    b = fma32(-n, h("0x1.7f7d1cp-20"), b)
+    k = np.array([(int(np.array([z], f).view(np.uint32)[0]) << 23) + 0x3f800000 & 0xffffffff], np.uint32).view(f)[0]
+    u = rn32(Fraction(float(b)) * Fraction(float(b)))
+    c1b = rn32(Fraction(float(h("0x1.ffffecp-1"))) * Fraction(float(b)))
+    j = fma32(fma32(fma32(h("0x1.0e4020p-7"), b, h("0x1.573e2ep-5")), u, fma32(h("0x1.555e66p-3"), b, h("0x1.fffdb6p-2"))), u, c1b)
+    return f(0.0) if n < -125 else fma32(k, j, k)
+
+
+def test_c4e_exponential_is_the_stated_routine_and_accurate(lib):
+    """The oracle's C4e routine equals the exact-arithmetic restatement bit for bit and stays within 2 ulp of exp()."""
+    lib.bark_oracle_canon_expf.restype = C.c_float
+    lib.bark_oracle_canon_expf.argtypes = [C.c_float]
+    rng = np.random.default_rng(4)
+    xs = np.concatenate([-rng.random(600) * 12, -rng.random(200) * 86, [0.0, -1e-7, -3e-4, -86.0, -86.5, -86.9, -87.5, -200.0, -1e4]]).astype(np.float32)
+    worst = 0.0
+    for x in xs:
+        got = np.float32(lib.bark_oracle_canon_expf(float(x)))
+        want = canon_expf(x)
+        assert got.tobytes() == want.tobytes(), (x, got, want)
+        t = math.exp(float(x))
+        if x > -86.0:
+            worst = max(worst, abs(float(got) - t) / float(np.spacing(np.float32(t))))
+        elif x < -87.4:
+            assert got == 0.0
+    assert worst < 2.0, worst
+
+
 def softmax_rows(s, valid):
     mx = np.float32(max(s[:valid]))
-    e = [np.float32(math.exp(float(np.float32(v - mx)))) for v in s[:valid]]
+    e = [canon_expf(np.float32(v - mx)) for v in s[:valid]]
     tot = 0.0
     for v in e:
         tot += float(v)                              # double accumulation

@@ -41,6 +41,7 @@ def _check_job(tag, res, orc, texts, reqs, **ctx_params):
         _exact(t + " pcm", r["pcm"], ref["pcm"])
 
 
+@pytest.mark.lock_step_job
 @pytest.mark.parametrize("preset", ["toy", "mini"])
 def test_randomised_lock_step_jobs_against_the_oracle(preset):
     """A seeded sweep: job sizes 2..40 on 8 / 16 / 64 slots, per-utterance caps 1..120 (one utterance per preset runs past 1024 frames:
@@ -86,6 +87,7 @@ def test_randomised_lock_step_jobs_against_the_oracle(preset):
         orc.close()
 
 
+@pytest.mark.lock_step_job
 def test_job_larger_than_the_slots_equals_the_job_on_enough_slots(toy_model):
     """23 utterances through 8 slots (queue, refills, compaction) against the same 23 on 32 slots: the company an utterance travels in
     changes nothing."""
@@ -104,6 +106,7 @@ def test_job_larger_than_the_slots_equals_the_job_on_enough_slots(toy_model):
             _exact(f"utterance {i} {k}", a[k], b[k])
 
 
+@pytest.mark.lock_step_job
 def test_job_tail_on_a_second_stream_equals_the_one_stream_job(toy_model, monkeypatch):
     """The fine passes and the codec of utterances that have left the coarse stage run on a clone of the context beside the lock steps of the
     others (engine_batch.hip: JobTail); BARK_HIP_TAIL_STREAM=0 keeps them behind the coarse stage on the job's own stream.  Same job (31 utterances
@@ -149,6 +152,7 @@ def test_job_tail_on_a_second_stream_equals_the_one_stream_job(toy_model, monkey
     assert any(not np.array_equal(a["fine"], b["fine"]) for a, b in zip(got[0], got[1])), "the sampled fine stage should differ from the greedy one"
 
 
+@pytest.mark.lock_step_job
 @pytest.mark.slow
 def test_small_ragged_job_matches_committed_oracle_outputs(small_model):
     """bark-small shapes, 16 slots, the ragged form of BASELINE config 5 (bench.ragged_caps: step caps 64..256 by prompt length): every
@@ -177,6 +181,8 @@ def test_small_ragged_job_matches_committed_oracle_outputs(small_model):
     ctx.free()
 
 
+@pytest.mark.concurrency
+@pytest.mark.job_order
 def test_request_collector_admits_late_requests_with_their_own_parameters(toy_model, toy_oracle):
     """bark_hip_batcher with continuous admission: a long request opens a job; requests submitted while it is in its semantic stage join the
     running job (free slots, nobody of the job waiting) instead of waiting for the next one.  Every request carries its own parameters and
@@ -214,6 +220,7 @@ def test_request_collector_admits_late_requests_with_their_own_parameters(toy_mo
         c.free()
 
 
+@pytest.mark.lock_step_job
 def test_lock_step_time_line_hook(toy_model):
     """bark_hip_profile_lock_step: one entry per launch site of a lock step in launch order (5 per layer + LM head + sampler), closed by the
     graph-replayed step; the eager sites add up to more than the replayed step (event records sit between the launches)."""
@@ -235,6 +242,7 @@ def test_lock_step_time_line_hook(toy_model):
         ctx.free()
 
 
+@pytest.mark.lock_step_job
 @pytest.mark.parametrize("kind", ["q4_0", "f32"])
 def test_ragged_job_on_quantised_and_f32_model_files(kind, toy_q4_model, toy_f32_model):
     """Per-utterance parameters on the other weight formats: a q4_0 file runs the lock-step path on the per-pair VALU products, an f32 file the
@@ -257,6 +265,7 @@ def test_ragged_job_on_quantised_and_f32_model_files(kind, toy_q4_model, toy_f32
         ctx.free(); orc.close()
 
 
+@pytest.mark.concurrency
 def test_device_and_host_sampling_agree_on_many_sampled_utterances():
     """tools/sampling_soak.py: 64 sampled utterances (temp 0.7 / 1.0, fine_temp 0.5, own seeds) as one lock-step job with the device multinomial
     kernels against the same utterances with BARK_HIP_HOST_SAMPLING=1 (std::discrete_distribution on fetched logits): ~45 000 ids and
@@ -267,6 +276,7 @@ def test_device_and_host_sampling_agree_on_many_sampled_utterances():
     assert " 0 arrays differ" in r.stdout
 
 
+@pytest.mark.concurrency
 def test_cloned_contexts_serve_jobs_from_concurrent_host_threads():
     """Four clones of one context (shared weights, own stream / caches / graphs), one host thread each, three different jobs per thread back to
     back: every thread captures its lock-step graphs while the others copy results to the host.  The context streams are non-blocking and no call

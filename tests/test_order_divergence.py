@@ -43,4 +43,4 @@ def test_matrix_core_orders_stay_within_tolerance_of_the_reference_restatement(p
         snr = 10 * np.log10(float((pb.astype(np.float64) ** 2).sum()) / max(float((err.astype(np.float64) ** 2).sum()), 1e-30))
         assert snr >= 55.0 and np.abs(err).max() <= 2e-2, f"codec: SNR {snr:.1f} dB, max |diff| {np.abs(err).max()}"
     finally:
-        o.set_fine_mfma(True); o.set_codec_mfma(True)
+        o.set_fine_mfma(None); o.set_codec_mfma(True)

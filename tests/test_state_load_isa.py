@@ -41,3 +41,16 @@ def test_the_round_4_form_of_the_kernel_had_the_load_behind_the_barriers():
     barriers = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
     late = [i for i, l in enumerate(body) if i > barriers[1] and re.match(r"s_load_dword s\d+, s\[\d+:\d+\], 0x8$", l)]
     assert late, "the plain-load form no longer shows the sunk load (compiler changed?)"
+
+
+def test_the_state_is_rewritten_behind_the_kernels_last_barrier():
+    """Round 6 (advisor): the ordering is structural as well - thread 0's stores of the state {n_past, cur_token, step} (one global_store_dwordx3 through the
+    state's scalar base) follow the LAST s_barrier of the kernel, which every wave reaches only after its last use of `step` / `np_next`; the volatile
+    loads checked above stay as the second guard."""
+    body = _sampler_asm()
+    last_barrier = max(i for i, l in enumerate(body) if l.startswith("s_barrier"))
+    x3 = [i for i, l in enumerate(body) if re.match(r"global_store_dwordx3 v\d+, v\[\d+:\d+\], s\[\d+:\d+\]$", l)]
+    assert x3, "the store of {n_past, cur_token, step} was not found (did the layout of StepState change?)"
+    assert all(i > last_barrier for i in x3), (last_barrier, x3)
+    # and the next step's embedding row (the other waves' last use of the loaded state) is written in front of that barrier
+    assert any(re.match(r"global_store_dword v", l) for l in body[last_barrier - 12:last_barrier])

@@ -28,3 +28,25 @@ def test_gpu_suite_runs_row_level_parity_first_and_concurrency_last():
         before(job, "test_cloned_contexts_serve_jobs_from_concurrent_host_threads")
         before(job, "test_request_batcher_serves_concurrent_submitters")
     assert ids[-1].split("::")[1].startswith(("test_concurrent_", "test_native_batch_server", "test_request_batcher", "test_cloned_contexts"))
+
+
+def test_tests_that_run_lock_step_jobs_say_so():
+    """A GPU test that runs lock-step jobs (generate_batch / Batcher / fine_many) must carry one of the group markers: they set its place in the suite
+    (conftest.py) and, for `lock_step_job` / `job_order`, the order the oracle computes the fine products in.  A new job test without a marker would fall
+    into the row-level group and compare C1m ids with the oracle's C1."""
+    import ast
+    need = ("generate_batch", "Batcher", "fine_many")
+    ok = {"lock_step_job", "concurrency", "boundary", "job_order"}
+    missing = []
+    for fn in ("test_gpu_parity.py", "test_gpu_batch_ragged.py"):
+        src = open(os.path.join(ROOT, "tests", fn)).read()
+        for node in ast.parse(src).body:
+            if not (isinstance(node, ast.FunctionDef) and node.name.startswith("test_")):
+                continue
+            body = ast.get_source_segment(src, node)
+            if not any(k in body for k in need):
+                continue
+            marks = {d.attr if isinstance(d, ast.Attribute) else getattr(getattr(d, "func", None), "attr", None) for d in node.decorator_list}
+            if not (marks & ok) and "job_order(" not in body:            # (a test may also switch the oracle's order itself, around the job it compares)
+                missing.append(f"{fn}::{node.name}")
+    assert not missing, missing

@@ -8,8 +8,8 @@ the other codebook's token offset and writes its 64 elements of the next token's
 happened about once per 10^6 lock steps (tools/clone_stress.py); here it is forced: two diagnostic builds of the library in which waves 1 .. 15
 of the sampler sleep ~16 us behind the second barrier (-DBARK_DIAG_LAG_WAVES=4),
 
-    lib/libbark_lag_old.so   the state loads as they were (-DBARK_DIAG_PLAIN_STATE_LOADS; tools/state_race_demo.sh checks the ISA: s_load behind the lag)
-    lib/libbark_lag_fix.so   the volatile loads of the fix (issued before the first barrier)
+    lib/diag/libbark_lag_old.so   the state loads as they were (-DBARK_DIAG_PLAIN_STATE_LOADS; tools/state_race_demo.sh checks the ISA: s_load behind the lag)
+    lib/diag/libbark_lag_fix.so   the volatile loads of the fix (issued before the first barrier)
 
 each generating one toy utterance (single-utterance path) and one 5-utterance lock-step job, compared with the oracle.
 Expected: lag_old - coarse ids differ; lag_fix - everything equal.   python tools/state_race_demo.py <variant>"""
@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 variant = sys.argv[1]
-os.environ["BARK_HIP_LIBRARY"] = os.path.join(ROOT, "bark.cpp_amd", "lib", "libbark_%s.so" % variant)
+os.environ["BARK_HIP_LIBRARY"] = os.path.join(ROOT, "bark.cpp_amd", "lib", "diag", "libbark_%s.so" % variant)
 
 import numpy as np                                   # noqa: E402
 import bench                                         # noqa: E402

@@ -3,19 +3,10 @@
 # sits relative to the barriers, the injected lag (s_sleep) and thread 0's store of the state: the evidence behind DESIGN.md section 10.  CPU only.
 set -e
 R="$(cd "$(dirname "$0")/.." && pwd)"
-# the two diagnostic libraries differ from the product in ONE object (misc_kernels.o): compile that, link it with the product's other objects
-[ -f "$R/bark.cpp_amd/lib/obj/kernels.o" ] || "$R/bark.cpp_amd/build.sh" > /dev/null
-variant() {
-    local suf=$1; shift
-    local O="$R/bark.cpp_amd/lib/obj"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 \
-        -Wall -Wno-unused-function -I"$R/include" -I"$R/bark.cpp_amd/csrc" "$@" -c "$R/bark.cpp_amd/csrc/misc_kernels.hip" -o "$O/misc_kernels_$suf.o"
-    local objs=()
-    for f in kernels fast_kernels quant_kernels attention_kernels codec_kernels engine_load engine engine_codec engine_batch engine_timing api batcher model_file tokenizer quantize; do objs+=("$O/$f.o"); done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/bark.cpp_amd/lib/libbark_$suf.so" "${objs[@]}" "$O/misc_kernels_$suf.o"
-}
-variant lag_old -DBARK_DIAG_PLAIN_STATE_LOADS -DBARK_DIAG_LAG_WAVES=4
-variant lag_fix -DBARK_DIAG_LAG_WAVES=4
+# the two diagnostic libraries differ from the product in ONE object (misc_kernels.o); bark.cpp_amd/build.sh --variant compiles it with the product's own
+# flags and links it with the product's own object list into lib/diag/ (nothing is duplicated here)
+"$R/bark.cpp_amd/build.sh" --variant lag_old -DBARK_DIAG_PLAIN_STATE_LOADS -DBARK_DIAG_LAG_WAVES=4
+"$R/bark.cpp_amd/build.sh" --variant lag_fix -DBARK_DIAG_LAG_WAVES=4
 [ "$1" = "--build-only" ] && exit 0
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -mllvm -amdgpu-kernarg-preload-count=16 -I$R/include -I$R/bark.cpp_amd/csrc -S --cuda-device-only"
 show() {
