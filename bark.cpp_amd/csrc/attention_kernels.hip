@@ -696,6 +696,14 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const AttnPrefillArgs a0
 // Against attn_rows_kernel (scores through a 128 KB LDS tile, one barrier per phase, each wave reading all probabilities of its chains back):
 // no score traffic at all, 64 exponentials per lane with full instruction-level parallelism.  Same operations per element: same bits.
 // ------------------------------------------------------------------------------------------------
+#ifdef ATTNW_STAMPS      // diagnostic build (build_variant.sh attnw -DATTNW_STAMPS; tools/attnw_phases.py): in-kernel time line of attn_window_kernel
+__device__ unsigned long long g_attnw_stamps[512 * 8 * 8];
+DEVINL unsigned long long attnw_clock(float dep) { unsigned long long t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory"); return t; }
+__device__ unsigned long long g_attnw_cycles[512 * 8 * 8];      // the same points on the shader clock (s_memtime): cycles per phase -> the clock the CU really ran at
+#define ATTNW_STAMP(i, dep) do { const unsigned long long t_ = attnw_clock(dep); const unsigned long long c_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) { g_attnw_stamps[((size_t) blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = t_; g_attnw_cycles[((size_t) blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = c_; } } while (0)
+#else
+#define ATTNW_STAMP(i, dep)
+#endif
 constexpr int FQ_LD = 68;                                            // floats per staged query row (64 + 4: a ds_read_b128 of 32 rows covers all banks)
 __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillArgs a0) {
     __shared__ __attribute__((aligned(16))) float qs[32 * FQ_LD];   // the query tile
@@ -704,8 +712,17 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     __shared__ __attribute__((aligned(16))) float part[8 * 32 * 64];            // partial outputs of the waves (64 KB)
     AttnPrefillArgs a = a0;
     constexpr int S = 1024;
-    const int QT = S / 32, rank = xcd_rank(blockIdx.x, QT * a.H * max(1, a.Z));
+    const int QT = S / 32, total = QT * a.H * max(1, a.Z);
+    int rank = xcd_rank(blockIdx.x, total);
+    if ((total & 7) == 0) {
+        // an XCD's run of consecutive ranks, dealt over up to four (window, head) units at a time: workgroups that are resident together then read the K / V of
+        // several heads (4 x 512 KB: still inside the 4 MB L2) instead of all pulling one head's lines at once
+        const int C = total >> 3, base = (rank / C) * C, j = rank - base;
+        const int NS = (C % 4 == 0 && C / 4 >= QT) ? 4 : (C % 3 == 0 && C / 3 >= QT) ? 3 : (C % 2 == 0 && C / 2 >= QT) ? 2 : 1;
+        rank = base + (j % NS) * (C / NS) + j / NS;
+    }
     const int hd = (rank / QT) % a.H, i0 = (rank % QT) * 32;
+    const int rot_b = __builtin_amdgcn_readfirstlane((rank % QT) & 3), rot_t = __builtin_amdgcn_readfirstlane(((rank % QT) >> 2) & 3);
     {
         const size_t z = rank / (QT * a.H);
         a.q += z * (size_t) S * a.ldq;
@@ -714,6 +731,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    ATTNW_STAMP(0, (float) tid);
     // query tile -> LDS (512 threads x one float4)
     {
         const int row = tid >> 4, c4 = tid & 15;
@@ -729,12 +747,17 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         // block n = 4 t + b (tile t, 16-d block b): four register sets, a block's K rows are requested three blocks (24 MFMAs of this wave,
         // twice that on the SIMD) before they are multiplied - one block ahead left the matrix cores waiting for memory
         float4 ks[4][4];
+        // Every query tile of a head starts its walk through K at another (key tile, 16-d block): the 32 workgroups of a head run side by side on one XCD,
+        // and in step they all asked its L2 for the same lines at the same moment (scores phase 19.2 -> 15.3 us when they do not, profiles/r06_attnw_phases_*).
+        // Register set t holds key tile t ^ rot_t until the sets are put back in order below; block order b ^ rot_b only permutes which of c0 .. c3 is
+        // formed when: (c0 + c1) + (c2 + c3) reads the same four values, and f32 addition commutes - the bits do not move.
         auto load_blk = [&](float4 (&kv)[4], int n) {
             #pragma unroll
-            for (int i = 0; i < 4; i++) kv[i] = kbase[(size_t) (4 * (n & 3) + i) * a.P + 256 * (n >> 2)];
+            for (int i = 0; i < 4; i++) kv[i] = kbase[(size_t) (4 * ((n & 3) ^ rot_b) + i) * a.P + 256 * ((n >> 2) ^ rot_t)];
         };
         load_blk(ks[0], 0); load_blk(ks[1], 1); load_blk(ks[2], 2);
         __syncthreads();                                         // the query tile is in LDS (the first K rows are already on their way)
+        ATTNW_STAMP(1, ks[0][0].x);
         #pragma unroll
         for (int t = 0; t < 4; t++) {
             floatx16 acc[4];
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
                 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float4 kv = ks[n & 3][i];
-                    const float4 qv = *reinterpret_cast<const float4 *>(qs + l31 * FQ_LD + 4 * (4 * b + i));
+                    const float4 qv = *reinterpret_cast<const float4 *>(qs + l31 * FQ_LD + 4 * (4 * (b ^ rot_b) + i));
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? kv.y : kv.x, half ? qv.y : qv.x, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? kv.w : kv.z, half ? qv.w : qv.z, acc[b], 0, 0, 0);
                 }
@@ -756,6 +779,10 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
             for (int r = 0; r < 16; r++) sc[t][r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * 0.125f;      // 1/sqrt(64), bark.cpp:1318
         }
     }
+    // key tiles back in order: register set t holds key tile t from here on (softmax sums and the C5 chains of the mix walk the keys in ascending order)
+    if (rot_t & 1) { floatx16 x0 = sc[0]; sc[0] = sc[1]; sc[1] = x0; floatx16 x1 = sc[2]; sc[2] = sc[3]; sc[3] = x1; }
+    if (rot_t & 2) { floatx16 x0 = sc[0]; sc[0] = sc[2]; sc[2] = x0; floatx16 x1 = sc[1]; sc[1] = sc[3]; sc[3] = x1; }
+    ATTNW_STAMP(2, sc[3][15]);
     // ---- 2. softmax of query l31 (this lane: 64 of its 1024 scores) -------------------------------------
     float mx = -INFINITY;
     #pragma unroll
@@ -768,6 +795,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     mx = red_m[0][l31];
     #pragma unroll
     for (int i = 1; i < 8; i++) mx = fmaxf(mx, red_m[i][l31]);
+    ATTNW_STAMP(3, mx);
     double ls[4] = {0.0, 0.0, 0.0, 0.0};
     #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -779,6 +807,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     __syncthreads();
     const double sum = ((red_s[0][l31] + red_s[1][l31]) + (red_s[2][l31] + red_s[3][l31])) + ((red_s[4][l31] + red_s[5][l31]) + (red_s[6][l31] + red_s[7][l31]));
     const float inv = (float) (1.0 / sum);
+    ATTNW_STAMP(4, inv);
     #pragma unroll
     for (int t = 0; t < 4; t++)
         #pragma unroll
@@ -807,6 +836,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
             o[g & 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[g >> 1][8 * (g & 1) + i], v.y, o[g & 1][1], 0, 0, 0);
         }
     }
+    ATTNW_STAMP(5, o[1][1][15] + o[0][0][15]);
     // ---- 4. the 16 chains meet: 2w + (2w + 1) here, the waves in LDS (tree levels xor 2, 4, 8) ------------
     #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -816,6 +846,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
             part[(w * 32 + row) * 64 + 2 * l31 + c] = o[0][c][r] + o[1][c][r];
         }
     __syncthreads();
+    ATTNW_STAMP(6, part[tid]);
     for (int idx = tid; idx < 32 * 64; idx += 512) {
         const int row = idx >> 6, d = idx & 63;
         float pp[8];
@@ -825,7 +856,17 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         const size_t oi = (size_t) (i0 + row) * a.ld_att + hd * 64 + d;
         if (a.att32) a.att32[oi] = v; else a.att[oi] = to_half(v);
     }
+    ATTNW_STAMP(7, part[tid ^ 1]);
 }
+
+#ifdef ATTNW_STAMPS
+extern "C" __attribute__((visibility("default"))) int bark_hip_debug_attnw_stamps(unsigned long long * out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attnw_stamps), sizeof(unsigned long long) * (size_t) std::min(n, 512 * 8 * 8)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int bark_hip_debug_attnw_cycles(unsigned long long * out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attnw_cycles), sizeof(unsigned long long) * (size_t) std::min(n, 512 * 8 * 8)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
     // whole windows of the fine model: the register-resident kernel (BARK_HIP_CROSSCHECK bit 9 (512) keeps attn_rows_kernel)

@@ -570,6 +570,35 @@ def main():
             bctx.free()
         except Exception as e:      # noqa: BLE001
             out["config5_64_prompts"] = {"error": str(e)}
+    # Which arithmetic the headline ran in, and the other order of the fine model's products beside it (round-5 review item 4).  The timed region above is
+    # bark_generate_audio in its DEFAULT arithmetic: every weight product of the three GPT stages in the restated reference order C1 (fine model included,
+    # f32 matrix cores), attention C2 / C4e / C5 - ids bit-equal to the CPU restatement of the reference (tests: test_bench_workload_matches_the_oracle,
+    # prompts 1, 5, 24) - and the codec's convolutions in the f16 matrix cores' order C9m (PCM within the stated tolerance of C9: >= 55 dB, measured 63 - 66).
+    # `fine_order_c1m` = the same prompt with the fine products in the f16 matrix cores' accumulation order (what lock-step jobs use; bark_hip_set_fine_order 2):
+    # RTF, fine-pass time and how many fine ids agree with the default run - measured here, on the device, at bark-small.  `codec_c9`: the codec in C9.
+    out["arithmetic"] = {"gpt_products": "C1 (restated reference order) for all three models", "attention": "C2 / C4e / C5", "codec": "C9m (f16 matrix cores)",
+                         "ids": "bit-equal to oracle/ (the CPU restatement of the reference) on this workload", "pcm": "bit-equal to the oracle's C9m mode; vs C9: SNR >= 55 dB (tests/test_order_divergence.py)"}
+    try:
+        text = prompts[a.warmup % len(prompts)]
+        assert ctx.generate_audio(text)
+        ref_fine, ref_pcm = ctx.fine_tokens().copy(), ctx.audio_data().copy()
+        f_c1, _ = ctx.time_fine_pass(6)
+        ctx.set_fine_order(2)
+        try:
+            ctx.generate_audio(text)
+            t5 = time.perf_counter(); assert ctx.generate_audio(text); d5 = time.perf_counter() - t5
+            m_fine, m_pcm = ctx.fine_tokens().copy(), ctx.audio_data().copy()
+            f_c1m, _ = ctx.time_fine_pass(6)
+        finally:
+            ctx.set_fine_order(0)
+        err = (m_pcm.astype(np.float64) - ref_pcm.astype(np.float64))
+        out["fine_order_c1m"] = {"switch": "bark_hip_set_fine_order(ctx, 2) / BARK_HIP_FINE_ORDER=c1m (the default inside lock-step jobs)",
+                                 "rtf": ctx.stats()["n_samples"] / 24000.0 / d5, "ms_per_prompt": d5 * 1e3, "fine_pass_us": f_c1m, "fine_pass_us_default_c1": f_c1,
+                                 "fine_ids_equal_to_the_default_run": "%d / %d" % (int(np.sum(m_fine == ref_fine)), int(ref_fine.size)),
+                                 "fine_ids_equal_frac": float(np.mean(m_fine == ref_fine)),
+                                 "pcm_snr_db_vs_default": float(10 * np.log10((ref_pcm.astype(np.float64) ** 2).sum() / max(float((err ** 2).sum()), 1e-30)))}
+    except Exception as e:      # noqa: BLE001
+        out["fine_order_c1m"] = {"error": str(e)}
     # Tolerance route (BARK_HIP_FAST_GEMM=1, read when a context is loaded): the many-row products and the fine model's attention on the
     # f16 matrix cores in hardware accumulation order (fast_kernels.hip).  Reported BESIDE the canonical numbers, never instead of them:
     # its ids are not promised to be the oracle's (tests/test_gpu_parity.py bounds its logits against the canonical route).

@@ -129,7 +129,7 @@ int main() {
     Args a{};
     HIP_OK(hipMalloc(&a.gran[0], sizeof(u64) * Vmax)); HIP_OK(hipMalloc(&a.gran[1], sizeof(u64) * Vmax));
     const size_t slab = 14155776 / 16;                       // uint4 per layer (bark-small: 7.08 M f16 weights)
-    uint4v * w; HIP_OK(hipMalloc(&w, slab * 16 * 12)); HIP_OK(hipMemset(w, 1, slab * 16 * 12));
+    uint4v * w; HIP_OK(hipMalloc(&w, slab * 16 * 13)); HIP_OK(hipMemset(w, 1, slab * 16 * 13));     // 13: the shares of 256 workgroups (3520 x 16 B each) overhang a 14.16 MB slab by 262 KB
     a.weights = w; a.wslab_u4 = slab;
     HIP_OK(hipMalloc(&a.fail, 4)); HIP_OK(hipMalloc(&a.stamps, sizeof(u64) * 2 * phases)); HIP_OK(hipMalloc(&a.sink, 4 * NWG * 4));
     const int lds = 2 * 56320 + Vmax * 4;
