@@ -475,7 +475,7 @@ def main():
         step_us = 1000.0 * out["stage_ms_per_token"]["semantic"]
         us, nbytes = ctx.time_gemv(0, 2, 2400)
         pmc = {}
-        for name in ("r05_pmc_decode_step.json", "r04_pmc_decode_step.json", "r03_pmc_gemv_fc.json"):
+        for name in ("r06_pmc_decode_step.json", "r05_pmc_decode_step.json", "r04_pmc_decode_step.json"):
             f = os.path.join(ROOT, "profiles", name)
             if os.path.exists(f):
                 pmc = json.load(open(f)); pmc["file"] = "profiles/" + name
@@ -497,12 +497,14 @@ def main():
             u, nb = ctx.time_gemv(0, op, 1200)
             gem[name] = {"us": u, "GB/s": nb / (u * 1e-6) / 1e9}
         out["roofline_gemv_variants"] = gem
-        # fine forward pass: products on the f16 matrix cores (canonical order C1m), attention on the f32 matrix cores (C2 / C5 keep q, k, v in f32)
+        # fine forward pass, default order C1: products and attention on the f32 matrix cores
         fus, flops = ctx.time_fine_pass(6)
         att_flops = 12 * 12 * 2 * 2 * 1024 * 1024 * 64 if a.preset == "small" else None
-        out["roofline_fine_pass"] = {"bound": "mfma", "achieved": flops / (fus * 1e-6) / 1e12, "unit": "TFLOP/s", "us_per_pass": fus,
-                                     "peak_note": "products (%.0f %% of the flops) run at the f16 rate (peak 2500), the attention at the f32 rate (peak 157.3)" % (100.0 * (1 - att_flops / flops) if att_flops else 0),
-                                     "frac_of_f16_mfma_peak_2500TF": flops / (fus * 1e-6) / 2.5e15, "frac_of_f32_mfma_peak_157TF": flops / (fus * 1e-6) / 157.3e12}
+        out["roofline_fine_pass"] = {"bound": "mfma", "achieved": flops / (fus * 1e-6) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (fus * 1e-6) / 157.3e12, "us_per_pass": fus,
+                                     "peak_note": "one window through the single-utterance path = the DEFAULT arithmetic: products (%.0f %% of the flops) in the reference order C1 and the attention "
+                                                  "(C2 / C4e / C5) both on the f32 matrix cores (v_mfma_f32_32x32x2_f32, dense peak 157.3 TFLOP/s); `eight_windows_side_by_side` is the pass of a "
+                                                  "lock-step job: products in C1m on the f16 matrix cores (peak 2500), attention on the f32 cores" % (100.0 * (1 - att_flops / flops) if att_flops else 0),
+                                     "frac_of_f32_mfma_peak_157TF": flops / (fus * 1e-6) / 157.3e12}
         # north_star's phrasing ("HBM roofline on the fine-model forward"), SURVEY.md 8(d): algorithmic bytes of one pass = the fine model's weights
         # + the window ids in + the picks out, over the pass time and the 8 TB/s datasheet rate.  The pass is MFMA-bound (arithmetic intensity
         # flops / bytes ~ 1.2 k FLOP/B against a ridge of ~ 312): the >= 40 % HBM target cannot apply to it, the MFMA fractions above are the binding ones
@@ -514,10 +516,11 @@ def main():
             out["roofline_fine_pass"].update({"hbm_algorithmic_bytes": fine_bytes, "hbm_achieved_GBps": fine_bytes / (fus * 1e-6) / 1e9,
                                               "hbm_frac": fine_bytes / (fus * 1e-6) / 8.0e12, "arithmetic_intensity_flop_per_byte": flops / fine_bytes,
                                               "hbm_target_note": "north_star's >= 40 % HBM roofline on the fine forward is inapplicable: at ~1.2 k FLOP/B the pass is bound by the matrix cores, "
-                                                                 "not by memory (ridge ~312 FLOP/B at 2.5 PFLOP/s over 8 TB/s); hbm_frac is reported for completeness"})
+                                                                 ""
+                                                                 "not by memory (ridge ~20 FLOP/B at the f32 matrix cores' 157 TFLOP/s over 8 TB/s, ~312 at the f16 cores' 2.5 PFLOP/s); hbm_frac is reported for completeness"})
         # the pass a lock-step batch runs: the fine windows of 8 utterances side by side (engine_fine_many)
         fus8, flops8 = ctx.time_fine_pass(3, 8)
-        out["roofline_fine_pass"]["eight_windows_side_by_side"] = {"us_per_window": fus8 / 8, "achieved": flops8 / (fus8 * 1e-6) / 1e12,
+        out["roofline_fine_pass"]["eight_windows_side_by_side"] = {"order": "C1m (lock-step jobs)", "us_per_window": fus8 / 8, "achieved": flops8 / (fus8 * 1e-6) / 1e12,
                                                                    "frac_of_f16_mfma_peak_2500TF": flops8 / (fus8 * 1e-6) / 2.5e15}
     except Exception as e:      # noqa: BLE001
         out["roofline"] = {"error": str(e)}
