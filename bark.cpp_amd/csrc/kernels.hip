@@ -604,16 +604,25 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const LinArgs a) {
 // Operands are staged through LDS as f16 whole rows, fetched once per workgroup (round 3; before, every wave fetched 16-byte pieces of
 // the same rows itself: 3.6 % slower, profiles/r03_gemm_lds.txt).  The 16 chains meet in LDS and are added in the C1 tree order.
 // ------------------------------------------------------------------------------------------------
-constexpr int GEMM_TM = 64, GEMM_TN = 64;
-constexpr int GEMM_LDS_BYTES = 8 * 64 * 64 * 4;                  // the reduction tree of the epilogue (8 x 64 x 64 f32); the two staging buffers (2 x 2 x 64 rows x 272 bytes = 68 KB) re-use it
+// Two tile shapes (round 6): 64 x 64, and 32 rows x 96 columns for the products whose 64 x 64 tiles fill the chip's 256 persistent workgroups badly - one
+// fine window's QKV (576 tiles: 2.25 rounds), proj and MLP-proj (192 tiles: three quarters of the CUs) become 768 / 256 / 256 tiles.  Same chains, same
+// order per accumulator: the bits do not depend on the shape (launch_linear picks by the share of busy workgroup rounds).
+constexpr int GL_LD = 136;                                        // halfs per staged row (272 bytes: the 16-byte chunks a ds_read_b128 takes from 16 consecutive rows cover all 64 banks)
+template <int TN, int TM> constexpr int gemm_lds_bytes() {       // the reduction tree of the epilogue (8 x TN x TM f32); the two staging buffers re-use it
+    return 8 * TN * TM * 4 > 2 * (TN + TM) * GL_LD * 2 ? 8 * TN * TM * 4 : 2 * (TN + TM) * GL_LD * 2;
+}
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 DEVINL float half_of(const uint4 & u, int e) {                 // element e (compile-time) of eight packed f16 values, widened
     const unsigned word = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
     return (float) __builtin_bit_cast(half_t, (unsigned short) ((e & 1) ? (word >> 16) : word));
 }
 DEVINL uint4 ld_u4(const half_t * p) { return *reinterpret_cast<const uint4 *>(p); }
+template <int TN, int TM>
 __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int ncol, const int nrow, const int pw) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][64][64]
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [8][TN][TM]
+    constexpr int NI = TN / 32, NJ = TM / 32;                    // 32 x 32 MFMA tiles per chain along n and m
+    constexpr int CX = TN * 16 / 512, CW = TM * 16 / 512;        // 16-byte chunks per thread and K block (x rows, weight rows)
+    static_assert(TN % 32 == 0 && TM % 32 == 0 && CX >= 1 && CW >= 1 && CX * 512 == TN * 16 && CW * 512 == TM * 16, "tile shape");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     // Persistent: the grid is one workgroup per CU (128 KB of LDS each); workgroup b walks the virtual ids b, b + grid, ... (same XCD: the grid is
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     if (vb >= ntiles) return;
     int n0, m0;
     const int K = a.K, nblk = K >> 7;
-    floatx16 acc[2][2][2];
+    floatx16 acc[2][NI][NJ];
 
     // Operand staging: the workgroup fetches the K block (128 elements = 256 bytes per row) of its 64 x rows and 64 weight rows ONCE, as
     // whole rows (a wave covers 4 rows x 256 contiguous bytes; gemm_kernel's waves fetch 16-byte pieces of those rows separately and depend
@@ -632,50 +641,50 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     // consecutive rows cover all 64 banks) and every wave reads the chunks of ITS two chains from there; conversions stay in the matrix waves.
     // Two LDS buffers, one barrier per K block: block b + 1 travels through registers (requested one block = ~4096 matrix-core cycles ahead)
     // and is written behind the MFMAs of block b.  The staging buffers (68 KB) are re-used by the reduction tree of the epilogue (128 KB).
-    constexpr int GL_LD = 136;                                   // halfs per staged row
-    half_t * stg = reinterpret_cast<half_t *>(lds);              // [buffer][x | w][64][GL_LD]
-    const half_t * xsrc[2]; const half_t * wsrc[2]; int sdst[2];
+    half_t * stg = reinterpret_cast<half_t *>(lds);              // [buffer][x rows TN | w rows TM][GL_LD]
+    constexpr int CMAX = CX > CW ? CX : CW;
+    const half_t * xsrc[CX]; const half_t * wsrc[CW]; int sdst[CMAX];
     #pragma unroll
-    for (int i = 0; i < 2; i++) { const int c = threadIdx.x + 512 * i; sdst[i] = (c >> 4) * GL_LD + (c & 15) * 8; }
+    for (int i = 0; i < CMAX; i++) { const int c = threadIdx.x + 512 * i; sdst[i] = (c >> 4) * GL_LD + (c & 15) * 8; }
     auto setup_tile = [&](int id) {
         int trow, tcol;
         panel_tile(xcd_rank(id, ntiles), nrow, ncol, pw, trow, tcol);      // XCD-aware tile order (device_utils.h)
-        n0 = trow * GEMM_TN; m0 = tcol * GEMM_TM;
+        n0 = trow * TN; m0 = tcol * TM;
         #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int c = threadIdx.x + 512 * i, row = c >> 4, ch = c & 15;
-            xsrc[i] = a.x_f16 + (size_t) min(n0 + row, a.N - 1) * K + ch * 8;
-            wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + ch * 8;
-        }
+        for (int i = 0; i < CX; i++) { const int c = threadIdx.x + 512 * i, row = c >> 4, ch = c & 15; xsrc[i] = a.x_f16 + (size_t) min(n0 + row, a.N - 1) * K + ch * 8; }
+        #pragma unroll
+        for (int i = 0; i < CW; i++) { const int c = threadIdx.x + 512 * i, row = c >> 4, ch = c & 15; wsrc[i] = a.W + (size_t) min(m0 + row, a.M - 1) * K + ch * 8; }
     };
-    uint4 rx[2], rw[2];
-#define GL_FETCH(B) { _Pragma("unroll") for (int i = 0; i < 2; i++) { rx[i] = ld_u4(xsrc[i] + ((B) << 7)); rw[i] = ld_u4(wsrc[i] + ((B) << 7)); } }
-#define GL_STAGE(BUF) { half_t * d_ = stg + (BUF) * 2 * 64 * GL_LD;                                                         \
-        _Pragma("unroll") for (int i = 0; i < 2; i++) { *reinterpret_cast<uint4 *>(d_ + sdst[i]) = rx[i];                   \
-                                                        *reinterpret_cast<uint4 *>(d_ + 64 * GL_LD + sdst[i]) = rw[i]; } }
-    half8 xa0[2][2], wb0[2][2];
+    uint4 rx[CX], rw[CW];
+#define GL_FETCH(B) { _Pragma("unroll") for (int i = 0; i < CX; i++) rx[i] = ld_u4(xsrc[i] + ((B) << 7));                    \
+                      _Pragma("unroll") for (int i = 0; i < CW; i++) rw[i] = ld_u4(wsrc[i] + ((B) << 7)); }
+#define GL_STAGE(BUF) { half_t * d_ = stg + (BUF) * (TN + TM) * GL_LD;                                                      \
+        _Pragma("unroll") for (int i = 0; i < CX; i++) *reinterpret_cast<uint4 *>(d_ + sdst[i]) = rx[i];                    \
+        _Pragma("unroll") for (int i = 0; i < CW; i++) *reinterpret_cast<uint4 *>(d_ + TN * GL_LD + sdst[i]) = rw[i]; }
+    half8 xa0[2][NI], wb0[2][NJ];
 #define GEMM_LOAD_BLOCK(XA, WB, BUF)                                                                     \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
-        const half_t * src_ = stg + (BUF) * 2 * 64 * GL_LD + ((2 * w + s) << 3);                          \
-        _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                  \
-            XA[s][t] = *reinterpret_cast<const half8 *>(src_ + (t * 32 + l31) * GL_LD);                   \
-            WB[s][t] = *reinterpret_cast<const half8 *>(src_ + 64 * GL_LD + (t * 32 + l31) * GL_LD);      \
-        }                                                                                                \
+        const half_t * src_ = stg + (BUF) * (TN + TM) * GL_LD + ((2 * w + s) << 3);                       \
+        _Pragma("unroll") for (int t = 0; t < NI; t++) XA[s][t] = *reinterpret_cast<const half8 *>(src_ + (t * 32 + l31) * GL_LD);               \
+        _Pragma("unroll") for (int t = 0; t < NJ; t++) WB[s][t] = *reinterpret_cast<const half8 *>(src_ + TN * GL_LD + (t * 32 + l31) * GL_LD);  \
     }
 #define GEMM_MFMA_BLOCK(XA, WB)                                                                          \
     _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                      \
-        uint4 xu[2], wu[2];                                                                              \
-        _Pragma("unroll") for (int t = 0; t < 2; t++) { xu[t] = __builtin_bit_cast(uint4, XA[s][t]); wu[t] = __builtin_bit_cast(uint4, WB[s][t]); } \
+        uint4 xu[NI], wu[NJ];                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NI; t++) xu[t] = __builtin_bit_cast(uint4, XA[s][t]);      \
+        _Pragma("unroll") for (int t = 0; t < NJ; t++) wu[t] = __builtin_bit_cast(uint4, WB[s][t]);      \
         _Pragma("unroll") for (int kp = 0; kp < 4; kp++) {                                               \
-            float av[2], bv[2];                                                                          \
-            _Pragma("unroll") for (int t = 0; t < 2; t++) {                                              \
+            float av[NI], bv[NJ];                                                                        \
+            _Pragma("unroll") for (int t = 0; t < NI; t++) {                                             \
                 const unsigned xr = kp == 0 ? xu[t].x : kp == 1 ? xu[t].y : kp == 2 ? xu[t].z : xu[t].w; \
-                const unsigned wr = kp == 0 ? wu[t].x : kp == 1 ? wu[t].y : kp == 2 ? wu[t].z : wu[t].w; \
                 av[t] = (float) __builtin_bit_cast(half_t, (unsigned short) (xr >> sh16));               \
+            }                                                                                            \
+            _Pragma("unroll") for (int t = 0; t < NJ; t++) {                                             \
+                const unsigned wr = kp == 0 ? wu[t].x : kp == 1 ? wu[t].y : kp == 2 ? wu[t].z : wu[t].w; \
                 bv[t] = (float) __builtin_bit_cast(half_t, (unsigned short) (wr >> sh16));               \
             }                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < 2; i++)                                                \
-                _Pragma("unroll") for (int j = 0; j < 2; j++)                                            \
+            _Pragma("unroll") for (int i = 0; i < NI; i++)                                               \
+                _Pragma("unroll") for (int j = 0; j < NJ; j++)                                           \
                     acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[s][i][j], 0, 0, 0); \
         }                                                                                                \
     }
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     GL_FETCH(0)
     while (true) {
     #pragma unroll
-    for (int s = 0; s < 2; s++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++)
+    for (int s = 0; s < 2; s++) for (int i = 0; i < NI; i++) for (int j = 0; j < NJ; j++)
         for (int r = 0; r < 16; r++) acc[s][i][j][r] = 0.0f;
     GL_STAGE(0)
     if (nblk > 1) GL_FETCH(1)
@@ -710,35 +719,37 @@ __global__ __launch_bounds__(512) void gemm_kernel(const LinArgs a, const int nc
     const bool more = nvb < ntiles;
     if (more) { setup_tile(nvb); GL_FETCH(0) }                  // in flight during the epilogue
     // chain pair (2w, 2w+1) -> LDS; accumulator register r of lane l holds row (r&3)+8(r>>2)+4*half, col l31
-    float * mine = lds + (size_t) w * (GEMM_TN * GEMM_TM);
+    float * mine = lds + (size_t) w * (TN * TM);
     #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NI; i++)
         #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NJ; j++)
             #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, col = j * 32 + l31;
-                mine[row * GEMM_TM + col] = acc[0][i][j][r] + acc[1][i][j][r];
+                mine[row * TM + col] = acc[0][i][j][r] + acc[1][i][j][r];
             }
     __syncthreads();
     // each thread finishes 2 x 4 adjacent outputs: every epilogue operand is fetched as one 16-byte access and all
     // of them are requested before the first is used
-    float4 bias4[2], res4[2];
-    int nn[2], mm[2];
+    constexpr int Q4 = TN * TM / 4, ER = (Q4 + 511) / 512, TM4 = TM / 4;      // float4 outputs of the tile, rounds of 512 threads over them
+    float4 bias4[ER], res4[ER];
+    int nn[ER], mm[ER];
     #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < ER; r++) {
         const int idx4 = threadIdx.x + 512 * r;
-        nn[r] = cn0 + (idx4 >> 4); mm[r] = cm0 + ((idx4 & 15) << 2);
-        const bool ok = nn[r] < a.N && mm[r] < a.M;
+        nn[r] = cn0 + idx4 / TM4; mm[r] = cm0 + ((idx4 % TM4) << 2);
+        const bool ok = idx4 < Q4 && nn[r] < a.N && mm[r] < a.M;
         bias4[r] = (a.bias && ok) ? *reinterpret_cast<const float4 *>(a.bias + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
         res4[r] = (a.epi == EPI_RESID && ok) ? *reinterpret_cast<const float4 *>(a.res + (size_t) nn[r] * a.M + mm[r]) : float4{0.f, 0.f, 0.f, 0.f};
     }
     #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < ER; r++) {
         const int idx4 = threadIdx.x + 512 * r;
+        if (idx4 >= Q4) continue;
         float4 p[8];
         #pragma unroll
-        for (int q = 0; q < 8; q++) p[q] = *reinterpret_cast<const float4 *>(lds + q * (GEMM_TN * GEMM_TM) + idx4 * 4);
+        for (int q = 0; q < 8; q++) p[q] = *reinterpret_cast<const float4 *>(lds + q * (TN * TM) + idx4 * 4);
         float v[4];
         v[0] = ((p[0].x + p[1].x) + (p[2].x + p[3].x)) + ((p[4].x + p[5].x) + (p[6].x + p[7].x));
         v[1] = ((p[0].y + p[1].y) + (p[2].y + p[3].y)) + ((p[4].y + p[5].y) + (p[6].y + p[7].y));
@@ -997,14 +1008,26 @@ void launch_linear(hipStream_t s, const LinArgs & a) {
         return;
     }
     if (a.epi == EPI_QKV16) kernel_fail("bark-hip: the f16 QKV epilogue exists on the tolerance route only");
-    const int ncol = (a.M + GEMM_TM - 1) / GEMM_TM, nrow = (a.N + GEMM_TN - 1) / GEMM_TN;
     static const int n_cu = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
-    const int grid = std::min(ncol * nrow, std::max(8, n_cu / 8 * 8));                  // persistent: one workgroup per CU
-    hipLaunchKernelGGL(gemm_kernel, dim3(grid), dim3(512), GEMM_LDS_BYTES, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+    const int gmax = std::max(8, n_cu / 8 * 8);                                         // persistent: one workgroup per CU
+    // tile shape by the share of busy workgroup rounds: tiles / (rounds x workgroups); 64 x 64 unless 32 x 96 keeps clearly more of the chip busy
+    auto tiles = [&](int tn, int tm) { return (long) ((a.M + tm - 1) / tm) * ((a.N + tn - 1) / tn); };
+    auto busy = [&](long t) { return (double) t / (double) (((t + gmax - 1) / gmax) * gmax); };
+    const bool wide = !(crosscheck_mask() & 2048) && a.M % 96 == 0 && busy(tiles(32, 96)) > busy(tiles(64, 64)) + 0.08;
+    if (wide) {
+        const int ncol = (a.M + 95) / 96, nrow = (a.N + 31) / 32;
+        constexpr int lds_bytes = gemm_lds_bytes<32, 96>();
+        hipLaunchKernelGGL((gemm_kernel<32, 96>), dim3(std::min(ncol * nrow, gmax)), dim3(512), lds_bytes, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+    } else {
+        const int ncol = (a.M + 63) / 64, nrow = (a.N + 63) / 64;
+        constexpr int lds_bytes = gemm_lds_bytes<64, 64>();
+        hipLaunchKernelGGL((gemm_kernel<64, 64>), dim3(std::min(ncol * nrow, gmax)), dim3(512), lds_bytes, s, a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol));
+    }
 }
 
 void init_kernel_attributes() {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<64, 64>());
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<32, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes<32, 96>());
     init_attention_attributes();
     init_quant_attributes();
     init_fast_attributes();

@@ -118,11 +118,17 @@ int sim_proj(int route, const void * W, const void * xh, const float * bias, flo
 }
 
 // N rows through the prefill product (gemm_kernel: persistent workgroups, C1 chains on v_mfma_f32_32x32x2_f32): out [N][M] f32 = x [N][K] f16 x W [M][K] f16 + bias
-int sim_gemm(const void * W, const void * xh, const float * bias, float * out, int N, int K, int M, int grid) {
+// wide: the 32-row x 96-column tile shape (round 6) instead of 64 x 64
+int sim_gemm(const void * W, const void * xh, const float * bias, float * out, int N, int K, int M, int grid, int wide) {
     LinArgs a;
     a.W = (const half_t *) W; a.M = M; a.K = K; a.N = N; a.x_f16 = (const half_t *) xh; a.bias = bias; a.epi = EPI_LOGITS; a.out = out; a.ld_out = M;
-    const int ncol = (M + 63) / 64, nrow = (N + 63) / 64;
-    sim::launch(dim3(std::min(grid, ncol * nrow)), 512, [&] { gemm_kernel(a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol)); });
+    if (wide) {
+        const int ncol = (M + 95) / 96, nrow = (N + 31) / 32;
+        sim::launch(dim3(std::min(grid, ncol * nrow)), 512, [&] { gemm_kernel<32, 96>(a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol)); });
+    } else {
+        const int ncol = (M + 63) / 64, nrow = (N + 63) / 64;
+        sim::launch(dim3(std::min(grid, ncol * nrow)), 512, [&] { gemm_kernel<64, 64>(a, ncol, nrow, xcd_panel_width(ncol * nrow, ncol)); });
+    }
     return 0;
 }
 
