@@ -541,7 +541,8 @@ def main():
                                          "wall_ms": dtb * 1e3, "slots": min(64, len(prompts)),
                                          "stage_ms": {k: stb["t_%s_us" % k] / 1e3 for k in ("semantic", "coarse", "fine", "codec")},
                                          "note": "bark_hip_generate_batch: lock-step decode, window prompts of all slots in one pass, fine windows of 8 utterances side by side, "
-                                                 "codec of all utterances in one pass; per-utterance results bit-identical to the single path"}
+                                                 "codec of all utterances in one pass; fine products in C1m (the jobs' order: bark_hip_set_fine_order); per-utterance results are those of bark_generate_audio "
+                                                 "bit for bit in the semantic and coarse ids always, and in fine ids / PCM when the single path runs the same order"}
             run_shard(bctx, prompts, idx, caps)                      # warm-up of the ragged job (graphs of the shrinking slot counts)
             tb = time.perf_counter()
             pcms = run_shard(bctx, prompts, idx, caps)
@@ -670,7 +671,7 @@ def main():
                                                         "coarse": lagg["t_coarse_us"] / 1000.0 / max(1, lagg["n_sample_coarse"]),
                                                         "fine": lagg["t_fine_us"] / 1000.0 / max(1, lagg["n_sample_fine"]), "codec_ms": lagg["t_codec_us"] / 2000.0},
                                  "decode_step_us": dus, "decode_step_GB/s": dbytes / (dus * 1e-6) / 1e9, "decode_step_hbm_frac": dbytes / (dus * 1e-6) / 8e12,
-                                 "fine_pass_us": fus, "fine_pass_TFLOP/s": flops / (fus * 1e-6) / 1e12, "fine_pass_frac_of_f16_mfma_peak": flops / (fus * 1e-6) / 2.5e15,
+                                 "fine_pass_us": fus, "fine_pass_TFLOP/s": flops / (fus * 1e-6) / 1e12, "fine_pass_frac_of_f32_mfma_peak": flops / (fus * 1e-6) / 157.3e12,
                                  "parity": "tests/test_gpu_parity.py::test_large_model_shapes (64- and 256-step oracle fixtures of this model file)"}
             lctx.free()
         except Exception as e:      # noqa: BLE001
