@@ -1,10 +1,10 @@
 """How far the matrix-core orders (C1m: fine model, C9m: codec convolutions - oracle/mfma_f16_emu.h) sit from the reference restatement.
 
 The reference accumulates f16 products in f32 (ggml's f16 dot / im2col + mul_mat); the oracle restates that as
-the orders C1 / C9 (`set_fine_mfma(False)`, `set_codec_mfma(False)`), and THAT mode is the restatement of the reference.  The engine's default
-for the fine model and the codec is the arithmetic of `v_mfma_f32_32x32x16_f16` (C1m / C9m), which the oracle emulates bit for bit - so
-"bit-exact against the oracle" pins indexing, layout and control flow there, while agreement with the reference's own arithmetic is a
-TOLERANCE statement.  This file is that statement, measured between the oracle's two modes on the same inputs (round 4's review: the two
+the orders C1 / C9 (`set_fine_mfma(False)` - the oracle's default since round 6 -, `set_codec_mfma(False)`), and THAT mode is the restatement of the
+reference.  The engine runs the codec everywhere, and the fine model inside lock-step jobs, in the arithmetic of `v_mfma_f32_32x32x16_f16`
+(C1m / C9m), which the oracle emulates bit for bit - so "bit-exact against the oracle" pins indexing, layout and control flow there, while agreement
+with the reference's own arithmetic is a TOLERANCE statement (bark_generate_audio's fine stage runs C1 itself: no tolerance there).  This file is that statement, measured between the oracle's two modes on the same inputs (round 4's review: the two
 orders were each only tested against themselves):
 
   * fine logits of one forward pass: max |diff| <= 2.5e-3 (f16 rounding noise of the activations; measured 3e-4 toy, 8e-4 mini, scale 1.2 - 1.6)
@@ -12,7 +12,8 @@ orders were each only tested against themselves):
   * fine stage on the same coarse ids: >= 98 % of the ids equal (measured 100 % toy, 99.7 % mini; a flipped id feeds later codebooks)
   * codec on the same codes: SNR >= 55 dB, max |diff| <= 2e-2 at a peak of 5 - 6 (measured 63 - 66 dB, 5.6e-3)
 
-bark-small on the device (BARK_HIP_CROSSCHECK=1280 keeps C1 / C9 there): profiles/r05_order_divergence_small.txt.
+bark-small: the 64 bench prompts in both orders are committed (tests/golden/oracle_small_batch64.npz: 98.6 - 100 % of the fine ids equal, mean 99.4 %), and
+the bench line measures it on the device for the timed prompt (profiles/r06_bench_small_n1.json, `fine_order_c1m`: 3056 / 3072 fine ids equal).
 Reference: /root/reference/bark.cpp:1416-1584 (fine graph), encodec.cpp's decoder."""
 import numpy as np
 import pytest
