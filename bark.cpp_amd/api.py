@@ -74,7 +74,7 @@ EXPORTS = [
     "bark_hip_hparams", "bark_hip_set_params", "bark_hip_tokenize", "bark_hip_bert_tokenize", "bark_hip_gpt_eval",
     "bark_hip_fine_eval", "bark_hip_semantic", "bark_hip_coarse", "bark_hip_fine", "bark_hip_fine_many", "bark_hip_codec_decode", "bark_hip_codec_tap",
     "bark_hip_clone_context", "bark_hip_generate_audio_batch", "bark_hip_generate_batch", "bark_hip_generate_batch_seeded", "bark_hip_generate_batch_ex", "bark_hip_reserve_batch", "bark_hip_profile_lock_step", "bark_hip_batch_audio", "bark_hip_batch_tokens", "bark_hip_get_semantic_tokens", "bark_hip_get_coarse_tokens", "bark_hip_get_fine_tokens", "bark_hip_get_stats",
-    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe", "bark_hip_set_fine_order",
+    "bark_hip_time_decode_step", "bark_hip_time_gemv", "bark_hip_time_slots", "bark_hip_time_fine_pass", "bark_hip_time_fine_passes", "bark_hip_describe", "bark_hip_set_fine_order", "bark_hip_load_model_on_device", "bark_hip_batcher_create_multi",
     "bark_hip_batcher_create", "bark_hip_batcher_create_ex", "bark_hip_batcher_submit", "bark_hip_batcher_submit_ex", "bark_hip_batcher_wait", "bark_hip_batcher_stats", "bark_hip_batcher_admitted", "bark_hip_batcher_free",
 ]
 
@@ -146,6 +146,10 @@ def load_library() -> C.CDLL:
     lib.bark_hip_batcher_create.argtypes = [vp, C.c_int, C.c_int]
     lib.bark_hip_batcher_create_ex.restype = vp
     lib.bark_hip_batcher_create_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.bark_hip_load_model_on_device.restype = vp
+    lib.bark_hip_load_model_on_device.argtypes = [C.c_char_p, BarkContextParams, C.c_uint32, C.c_int]
+    lib.bark_hip_batcher_create_multi.restype = vp
+    lib.bark_hip_batcher_create_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
     lib.bark_hip_batcher_submit.restype = C.c_int64
     lib.bark_hip_batcher_submit.argtypes = [vp, C.c_char_p, C.c_uint32]
     lib.bark_hip_batcher_submit_ex.restype = C.c_int64
@@ -186,10 +190,14 @@ class BarkContext:
 
     # ---- bark.h ---------------------------------------------------------------------------------
     @classmethod
-    def load_model(cls, model_path: str, params: BarkContextParams | None = None, seed: int = 0) -> "BarkContext":
+    def load_model(cls, model_path: str, params: BarkContextParams | None = None, seed: int = 0, device: int | None = None) -> "BarkContext":
+        """device None: bark_load_model (BARK_HIP_DEVICE / the current device); an ordinal: bark_hip_load_model_on_device (one process, several GPUs)"""
         lib = load_library()
         params = params if params is not None else default_params()
-        h = lib.bark_load_model(os.fsencode(model_path), params, seed)
+        if device is None:
+            h = lib.bark_load_model(os.fsencode(model_path), params, seed)
+        else:
+            h = lib.bark_hip_load_model_on_device(os.fsencode(model_path), params, seed, int(device))
         if not h:
             raise RuntimeError(f"bark_load_model failed for {model_path}")
         ctx = cls(h, lib)
@@ -467,10 +475,17 @@ class Batcher:
     """bark_hip_batcher: thread-safe submit / wait in front of the context's lock-step batches (the context is owned by the batcher's
     worker thread while it lives)."""
 
-    def __init__(self, ctx: "BarkContext", max_batch: int = 32, max_wait_ms: int = 2, streams: int = 1):
-        self._lib = ctx._lib
-        self._ctx = ctx                                 # the worker thread runs on this context: it must outlive the batcher
-        self._b = self._lib.bark_hip_batcher_create_ex(ctx._h, max_batch, max_wait_ms, streams)     # streams > 1: further workers on clones of ctx
+    def __init__(self, ctx, max_batch: int = 32, max_wait_ms: int = 2, streams: int = 1):
+        """ctx: one BarkContext (streams > 1: further workers on clones of it, same GPU), or a list of contexts - one worker each, typically one per GPU
+        (bark_hip_batcher_create_multi)."""
+        ctxs = list(ctx) if isinstance(ctx, (list, tuple)) else [ctx]
+        self._lib = ctxs[0]._lib
+        self._ctx = ctxs                                # the worker threads run on these contexts: they must outlive the batcher
+        if len(ctxs) > 1:
+            arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+            self._b = self._lib.bark_hip_batcher_create_multi(arr, len(ctxs), max_batch, max_wait_ms)
+        else:
+            self._b = self._lib.bark_hip_batcher_create_ex(ctxs[0]._h, max_batch, max_wait_ms, streams)     # streams > 1: further workers on clones of ctx
         if not self._b:
             raise RuntimeError("bark_hip_batcher_create failed")
 

@@ -213,6 +213,15 @@ int bark_hip_fine_many(struct bark_context * bctx, const int32_t * coarse_concat
     });
 }
 
+struct bark_context * bark_hip_load_model_on_device(const char * model_path, struct bark_context_params params, uint32_t seed, int device) {
+    if (!model_path) { fprintf(stderr, "bark_hip_load_model_on_device: null path\n"); return nullptr; }
+    if (device < 0) { fprintf(stderr, "bark_hip_load_model_on_device: negative device ordinal\n"); return nullptr; }
+    const int64_t t0 = wall_us();
+    bark_context * ctx = guarded("bark_hip_load_model_on_device", (bark_context *) nullptr, [&] { return engine_load(model_path, params, seed, device); });
+    if (ctx) ctx->stats.t_load_us = wall_us() - t0;
+    return ctx;
+}
+
 int bark_hip_set_fine_order(struct bark_context * bctx, int order) {
     if (!bctx || order < 0 || order > 2) return -1;
     return guarded("bark_hip_set_fine_order", -1, [&] {

@@ -27,7 +27,8 @@ using namespace barkhip;
 struct bark_hip_batcher {
     struct Req { std::string text; bark_hip_request_params rp{}; std::vector<float> pcm; bool done = false, ok = false; };
     bark_context * ctx = nullptr;                          // worker 0's context (the caller's); request defaults are read from it
-    std::vector<bark_context *> ctxs;                      // one per worker; ctxs[1 ..] are clones owned by the batcher
+    std::vector<bark_context *> ctxs;                      // one per worker; ctxs[1 ..] are clones owned by the batcher ...
+    bool owns_workers = true;                              // ... unless the caller brought every context itself (bark_hip_batcher_create_multi: one per GPU)
     int max_batch = 32;
     std::chrono::microseconds max_wait{2000};
     std::mutex mu;
@@ -41,7 +42,7 @@ struct bark_hip_batcher {
 
     void run(int wi) {
         bark_context * ctx = ctxs[(size_t) wi];
-        bool first = wi > 0;
+        bool first = wi > 0 && owns_workers;              // job streams on ONE GPU are kept out of phase (file header); workers on GPUs of their own need not be
         std::unique_lock<std::mutex> lk(mu);
         while (true) {
             cv_work.wait(lk, [&] { return stop || !queue.empty(); });
@@ -110,6 +111,32 @@ BARK_API struct bark_hip_batcher * bark_hip_batcher_create_ex(struct bark_contex
         return nullptr;
     }
 }
+// Several GPUs behind ONE queue (north_star: many prompts sharded across the GPUs of a node as an embarrassingly-parallel split, no collective inside an
+// utterance - here natively, without torch.distributed): worker i is the caller's context i, typically loaded on device i with
+// bark_hip_load_model_on_device; every engine entry point selects its context's device first, so a worker thread needs no device state of its own.
+// The collector does not own these contexts (bark_free them after bark_hip_batcher_free).  Request defaults are read from ctxs[0].
+BARK_API struct bark_hip_batcher * bark_hip_batcher_create_multi(struct bark_context * const * ctxs, int n_ctx, int max_batch, int max_wait_ms) {
+    if (!ctxs || n_ctx < 1 || n_ctx > 64 || max_batch < 1 || max_batch > 256 || max_wait_ms < 0) return nullptr;
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i]) return nullptr;
+        for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return nullptr;            // one worker per context
+    }
+    std::unique_ptr<bark_hip_batcher> b(new bark_hip_batcher());
+    try {
+        b->ctx = ctxs[0]; b->max_batch = max_batch; b->max_wait = std::chrono::microseconds((int64_t) max_wait_ms * 1000);
+        b->owns_workers = false;
+        for (int i = 0; i < n_ctx; i++) b->ctxs.push_back(ctxs[i]);
+        for (bark_context * c : b->ctxs) engine_reserve_batch(c, std::min(max_batch, 64));
+        bark_hip_batcher * raw = b.get();
+        for (int i = 0; i < n_ctx; i++) b->workers.emplace_back([raw, i] { raw->run(i); });
+        return b.release();
+    } catch (const std::exception & e) {
+        fprintf(stderr, "bark_hip_batcher_create_multi: %s\n", e.what());
+        { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }
+        for (auto & w : b->workers) if (w.joinable()) w.join();
+        return nullptr;
+    }
+}
 BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context * bctx, int max_batch, int max_wait_ms) {
     return bark_hip_batcher_create_ex(bctx, max_batch, max_wait_ms, 1);
 }
@@ -173,7 +200,7 @@ BARK_API void bark_hip_batcher_free(struct bark_hip_batcher * b) {
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->cv_work.notify_all(); }
     for (auto & w : b->workers) if (w.joinable()) w.join();    // pending requests are still served
     { std::lock_guard<std::mutex> lk(b->mu); b->tickets.clear(); }   // tickets nobody waited for
-    for (size_t i = 1; i < b->ctxs.size(); i++) delete b->ctxs[i];
+    if (b->owns_workers) for (size_t i = 1; i < b->ctxs.size(); i++) delete b->ctxs[i];
     delete b;
 }
 

@@ -169,7 +169,7 @@ struct bark_context {
 namespace barkhip {
 
 // All functions throw std::runtime_error on failure; the C API catches at the boundary.
-bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed);
+bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed, int device = -1);      // device < 0: BARK_HIP_DEVICE / the current device
 bark_context * engine_clone(bark_context * src, uint32_t seed);          // same weights, own stream / caches / scratch
 void engine_invalidate_graphs(bark_context * ctx);
 

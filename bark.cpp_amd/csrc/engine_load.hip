@@ -215,16 +215,18 @@ static void init_runtime(bark_context * ctxp, bool weights_uploaded_now) {
 }
 
 // bark_load_model_from_file (bark.cpp:1080-1163): parse the container, upload every tensor of the hot path.
-bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed) {
+bark_context * engine_load(const char * path, const bark_context_params & params, uint32_t seed, int device) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         throw std::runtime_error("no HIP device available (this engine has no CPU path)");
     std::unique_ptr<bark_context> ctx(new bark_context());
     ctx->params = params;
     ctx->rng = std::mt19937(seed);                       // bark.cpp:1179
-    if (const char * e = getenv("BARK_HIP_DEVICE")) ctx->device = atoi(e);
+    // device: the caller's (bark_hip_load_model_on_device: one process, several GPUs), else BARK_HIP_DEVICE (one process per GPU), else the current one
+    if (device >= 0) ctx->device = device;
+    else if (const char * e = getenv("BARK_HIP_DEVICE")) ctx->device = atoi(e);
     else (void) hipGetDevice(&ctx->device);
-    if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("BARK_HIP_DEVICE out of range");
+    if (ctx->device < 0 || ctx->device >= n_dev) throw std::runtime_error("HIP device ordinal out of range (BARK_HIP_DEVICE / bark_hip_load_model_on_device)");
     HIP_OK(hipSetDevice(ctx->device));
     if (const char * e = getenv("BARK_HIP_GRAPH")) ctx->use_graph = atoi(e) != 0;
     if (const char * e = getenv("BARK_HIP_FAST_GEMM")) {

@@ -7,7 +7,7 @@
 // a counter starting at the server's --seed); its audio is what a fresh context loaded with that seed generates, whatever batch it joined.
 // Plain POSIX sockets, one thread per connection, Connection: close; no third-party code.
 //
-//   bark_batch_server -m model.bin [-a 127.0.0.1] [-p 1337] [-s seed] [--max-batch 32] [--max-wait-ms 5] [--streams 1] [--temp t] [--fine-temp t]
+//   bark_batch_server -m model.bin [-a 127.0.0.1] [-p 1337] [-s seed] [--max-batch 32] [--max-wait-ms 5] [--streams 1] [--devices 0,1,...] [--temp t] [--fine-temp t]
 #include "bark.h"
 #include "bark_mi355x.h"
 #include "http_util.h"
@@ -33,6 +33,7 @@ using barkhttp::json_string; using barkhttp::json_uint; using barkhttp::wav_f32;
 struct Options {
     std::string model, host = "127.0.0.1";
     int port = 1337, max_batch = 32, max_wait_ms = 5, streams = 1;
+    std::vector<int> devices;                      // --devices 0,1,...: one context (own copy of the weights) and one worker per listed GPU, one queue
     uint32_t seed = 0;
     float temp = -1.0f, fine_temp = -1.0f;
 };
@@ -111,7 +112,7 @@ void serve(int fd, bark_hip_batcher * batcher, int sample_rate) {
 }
 
 void usage(const char * argv0) {
-    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 256; the context serves up to 64 at a time)] [--max-wait-ms n] [--streams n (1 .. 4 jobs in flight)] [--temp t] [--fine-temp t]\n", argv0);
+    fprintf(stderr, "usage: %s -m model.bin [-a host] [-p port] [-s seed] [--max-batch n (<= 256; the context serves up to 64 at a time)] [--max-wait-ms n] [--streams n (1 .. 4 jobs in flight)] [--devices 0,1,... (one context and one worker per GPU, one queue)] [--temp t] [--fine-temp t]\n", argv0);
 }
 
 }  // namespace
@@ -128,6 +129,7 @@ int main(int argc, char ** argv) {
         else if (a == "--max-batch") o.max_batch = atoi(next("--max-batch"));
         else if (a == "--max-wait-ms") o.max_wait_ms = atoi(next("--max-wait-ms"));
         else if (a == "--streams") o.streams = atoi(next("--streams"));
+        else if (a == "--devices") { for (const char * p = next("--devices"); *p;) { char * e = nullptr; o.devices.push_back((int) strtol(p, &e, 10)); if (e == p) { usage(argv[0]); return 1; } p = *e == ',' ? e + 1 : e; } }
         else if (a == "--temp") o.temp = (float) atof(next("--temp"));
         else if (a == "--fine-temp") o.fine_temp = (float) atof(next("--fine-temp"));
         else { usage(argv[0]); return a == "-h" || a == "--help" ? 0 : 1; }
@@ -137,10 +139,15 @@ int main(int argc, char ** argv) {
     bark_context_params params = bark_context_default_params();
     if (o.temp >= 0.0f) params.temp = o.temp;
     if (o.fine_temp >= 0.0f) params.fine_temp = o.fine_temp;
-    bark_context * ctx = bark_load_model(o.model.c_str(), params, o.seed);
-    if (!ctx) { fprintf(stderr, "%s: could not load the model\n", argv[0]); return 1; }
-    bark_hip_batcher * batcher = bark_hip_batcher_create_ex(ctx, o.max_batch, o.max_wait_ms, o.streams);
-    if (!batcher) { fprintf(stderr, "%s: could not create the request collector\n", argv[0]); bark_free(ctx); return 1; }
+    // one GPU: the context of bark_load_model (+ --streams job streams on clones of it); --devices: a context per listed GPU behind one queue
+    std::vector<bark_context *> ctxs;
+    if (o.devices.empty()) ctxs.push_back(bark_load_model(o.model.c_str(), params, o.seed));
+    else for (int d : o.devices) ctxs.push_back(bark_hip_load_model_on_device(o.model.c_str(), params, o.seed, d));
+    for (bark_context * c : ctxs) if (!c) { fprintf(stderr, "%s: could not load the model\n", argv[0]); for (bark_context * x : ctxs) if (x) bark_free(x); return 1; }
+    bark_context * ctx = ctxs[0];
+    bark_hip_batcher * batcher = ctxs.size() > 1 ? bark_hip_batcher_create_multi(ctxs.data(), (int) ctxs.size(), o.max_batch, o.max_wait_ms)
+                                                 : bark_hip_batcher_create_ex(ctx, o.max_batch, o.max_wait_ms, o.streams);
+    if (!batcher) { fprintf(stderr, "%s: could not create the request collector\n", argv[0]); for (bark_context * x : ctxs) bark_free(x); return 1; }
     next_seed = o.seed;
 
     const int lfd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -150,7 +157,7 @@ int main(int argc, char ** argv) {
     addr.sin_family = AF_INET; addr.sin_port = htons((uint16_t) o.port);
     if (inet_pton(AF_INET, o.host.c_str(), &addr.sin_addr) != 1 || bind(lfd, reinterpret_cast<sockaddr *>(&addr), sizeof(addr)) != 0 || listen(lfd, 128) != 0) {
         fprintf(stderr, "couldn't bind to server socket: hostname=%s port=%d\n", o.host.c_str(), o.port);
-        bark_hip_batcher_free(batcher); bark_free(ctx);
+        bark_hip_batcher_free(batcher); for (bark_context * x : ctxs) bark_free(x);
         return 1;
     }
     printf("\nbark batch server listening at http://%s:%d (lock-step batches of up to %d requests, %d ms to fill)\n\n", o.host.c_str(), o.port, o.max_batch, o.max_wait_ms);

@@ -139,6 +139,12 @@ BARK_API struct bark_hip_batcher * bark_hip_batcher_create(struct bark_context *
  * same queue, so up to n_streams jobs are in flight on the GPU at once - two decode chains share the chip (two streams of 64-slot jobs:
  * +14 % prompts/s under load).  Results do not depend on the stream a request travelled in. */
 BARK_API struct bark_hip_batcher * bark_hip_batcher_create_ex(struct bark_context * bctx, int max_batch, int max_wait_ms, int n_streams);
+// One process, several GPUs.  bark_load_model (bark.h / bark.cpp:1165) takes the device from BARK_HIP_DEVICE or the current device; this variant takes it as an
+// argument.  bark_hip_batcher_create_multi: a request collector whose workers are the caller's contexts - one per GPU - behind one queue (request-level
+// data parallelism: no collective inside an utterance; the reference's server holds one context behind one mutex, examples/server/server.cpp:76-94).  The
+// collector does not own the contexts; request defaults come from ctxs[0].  nullptr on a bad argument (null / repeated context, n_ctx outside 1 .. 64).
+BARK_API struct bark_context * bark_hip_load_model_on_device(const char * model_path, struct bark_context_params params, uint32_t seed, int device);
+BARK_API struct bark_hip_batcher * bark_hip_batcher_create_multi(struct bark_context * const * ctxs, int n_ctx, int max_batch, int max_wait_ms);
 BARK_API int64_t bark_hip_batcher_submit(struct bark_hip_batcher * b, const char * text, uint32_t seed);
 /* a request with its own parameters (nullptr: the context's) */
 BARK_API int64_t bark_hip_batcher_submit_ex(struct bark_hip_batcher * b, const char * text, const struct bark_hip_request_params * params);

@@ -31,8 +31,10 @@ def main():
     KEYS = ("semantic", "coarse", "fine", "pcm")
     import bench
     from bark_amd_loader import load_package
+    from oracle import pyoracle
     from oracle.pyoracle import Oracle
     from tools.make_synth_model import ensure_model
+    pyoracle.JOB_ORDER = True          # everything here is a lock-step job: the oracle computes the fine products in the jobs' order (C1m)
     pkg = load_package()
     path = ensure_model(preset, 0)
     cap = 24
