@@ -162,6 +162,55 @@ def test_attention_rank_order_keeps_a_head_on_one_xcd():
         assert len(owner) == H * Z and all(len(v) <= QT // share + 2 for v in owner.values())
 
 
+def _window_rank(b, QT, H, Z):
+    """attn_window_kernel (round 6): blockIdx.x -> rank.  xcd_rank, then - when the grid is a multiple of 8 - an XCD's run of C consecutive ranks is dealt
+    over NS (window, head) units at a time: j -> (j % NS) * (C / NS) + j / NS."""
+    total = QT * H * Z
+    rank = _xcd_rank(b, total)
+    if total % 8 == 0:
+        C = total // 8
+        base, j = (rank // C) * C, rank % C
+        NS = 4 if (C % 4 == 0 and C // 4 >= QT) else 3 if (C % 3 == 0 and C // 3 >= QT) else 2 if (C % 2 == 0 and C // 2 >= QT) else 1
+        rank = base + (j % NS) * (C // NS) + j // NS
+    return rank
+
+
+def test_window_attention_deals_an_xcds_run_over_several_heads_and_spreads_the_k_walks():
+    """attn_window_kernel's workgroup mapping of round 6, restated: (1) still a bijection onto (window, head, query tile), every XCD keeping its own run of
+    ranks (K / V of a unit stay in one L2); (2) the 32 workgroups an XCD runs side by side (consecutive b on that XCD) belong to NS different units once the
+    run is long enough - one window: 1, two windows: 3, eight: 4; (3) the K walk of query tile q starts at key tile (q >> 2) & 3 and 16-d block q & 3, so the
+    tiles of one unit that run side by side start from all sixteen (tile, block) positions, every (tile, block) is visited exactly once per workgroup, and
+    the register sets come back in key order by the two conditional swaps."""
+    for QT, H, Z, want_units in [(32, 12, 1, 1), (32, 12, 2, 3), (32, 12, 8, 4), (32, 16, 1, 2), (32, 16, 5, 4)]:
+        n = QT * H * Z
+        ranks = [_window_rank(b, QT, H, Z) for b in range(n)]
+        assert sorted(ranks) == list(range(n))                                            # (1) bijection
+        C = n // 8
+        for x in range(8):
+            mine = [ranks[b] for b in range(x, n, 8)]                                     # XCD x, in the order its workgroups start
+            assert sorted(mine) == list(range(x * C, (x + 1) * C)), (QT, H, Z, x)         # its own run of consecutive ranks, nothing else
+            first = mine[:32]                                                             # resident together (one workgroup per CU, 32 CUs per XCD)
+            units = {r // QT for r in first}
+            assert len(units) >= want_units, (QT, H, Z, x, len(units))                    # (2)
+    # (3) rotation: block order b ^ rot_b, tile order t ^ rot_t, sets restored by swaps on bit 0 then bit 1
+    starts = set()
+    for q in range(32):
+        rot_b, rot_t = q & 3, (q >> 2) & 3
+        visited = [((n >> 2) ^ rot_t, (n & 3) ^ rot_b) for n in range(16)]                # load_blk(n): (key tile, 16-d block)
+        assert sorted(visited) == [(t, b) for t in range(4) for b in range(4)]
+        starts.add(visited[0])
+        sets = [t ^ rot_t for t in range(4)]                                              # register set t holds key tile t ^ rot_t after the scores
+        if rot_t & 1:
+            sets[0], sets[1] = sets[1], sets[0]; sets[2], sets[3] = sets[3], sets[2]
+        if rot_t & 2:
+            sets[0], sets[2] = sets[2], sets[0]; sets[1], sets[3] = sets[3], sets[1]
+        assert sets == [0, 1, 2, 3], (q, sets)
+        for t in range(4):                                                                # accumulator b of a tile holds block b ^ rot_b: (a0 + a1) + (a2 + a3) is
+            acc = [b ^ rot_b for b in range(4)]                                           # (c0 + c1) + (c2 + c3) up to commuted operands
+            assert {frozenset(acc[0:2]), frozenset(acc[2:4])} == {frozenset((0, 1)), frozenset((2, 3))}
+    assert len(starts) == 16
+
+
 # ---- lock-step route for few slots (default up to 8 live slots, BARK_HIP_FEW_SLOTS): gemv_ln_slots_ps_kernel (kernels.hip) -> attn_fused_ps_kernel (attention_kernels.hip) ----
 def _mul32(a, b):
     return np.float32(np.float32(a) * np.float32(b))
