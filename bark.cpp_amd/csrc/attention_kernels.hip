@@ -705,6 +705,13 @@ __device__ unsigned long long g_attnw_cycles[512 * 8 * 8];      // the same poin
 #define ATTNW_STAMP(i, dep)
 #endif
 constexpr int FQ_LD = 68;                                            // floats per staged query row (64 + 4: a ds_read_b128 of 32 rows covers all banks)
+// CAUSAL (round 6): the same register-resident structure for the prompt passes of the causal models (semantic prompt, coarse window prompts, the all-slots
+// prompt pass of a lock-step job; any N <= 1024 rows, rows continue a cache at n_past, ragged sequences through SeqTab; block_size 1024): a query tile sees
+// the keys below jend = n_past + i0 + 32, so only the first ceil(jend / 256) key tiles are requested and multiplied; inside them a score whose key lies behind
+// the query's own position is -inf in front of the maximum (its exponential is +0), and the V operand of a key at or beyond jend is 0 (cache rows beyond the
+// context hold whatever was there).  Orders C2 / C4e / C5 as in the whole-window form and in attn_rows_kernel, which stays as the route for other block sizes
+// and as the cross-check (BARK_HIP_CROSSCHECK bit 512).
+template <bool CAUSAL>
 __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillArgs a0) {
     __shared__ __attribute__((aligned(16))) float qs[32 * FQ_LD];   // the query tile
     __shared__ float red_m[8][32];
@@ -712,18 +719,33 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     __shared__ __attribute__((aligned(16))) float part[8 * 32 * 64];            // partial outputs of the waves (64 KB)
     AttnPrefillArgs a = a0;
     constexpr int S = 1024;
-    const int QT = S / 32, total = QT * a.H * max(1, a.Z);
+    const int QT = CAUSAL ? (a.N + 31) >> 5 : S / 32, total = QT * a.H * max(1, a.Z);
     int rank = xcd_rank(blockIdx.x, total);
-    if ((total & 7) == 0) {
+    if (!CAUSAL && (total & 7) == 0) {
         // an XCD's run of consecutive ranks, dealt over up to four (window, head) units at a time: workgroups that are resident together then read the K / V of
         // several heads (4 x 512 KB: still inside the 4 MB L2) instead of all pulling one head's lines at once
         const int C = total >> 3, base = (rank / C) * C, j = rank - base;
         const int NS = (C % 4 == 0 && C / 4 >= QT) ? 4 : (C % 3 == 0 && C / 3 >= QT) ? 3 : (C % 2 == 0 && C / 2 >= QT) ? 2 : 1;
         rank = base + (j % NS) * (C / NS) + j / NS;
     }
-    const int hd = (rank / QT) % a.H, i0 = (rank % QT) * 32;
-    const int rot_b = __builtin_amdgcn_readfirstlane((rank % QT) & 3), rot_t = __builtin_amdgcn_readfirstlane(((rank % QT) >> 2) & 3);
-    {
+    // CAUSAL: a head's query tiles in DESCENDING order - the last tile sees all keys, the first 32 of them, and workgroups start in rank order: the long ones
+    // first, the short ones fill the tail of the launch (336 workgroups on 256 CUs at 887 rows: 54 us per layer in ascending order)
+    const int hd = (rank / QT) % a.H, i0 = (CAUSAL ? QT - 1 - rank % QT : rank % QT) * 32;
+    const int rot_b = __builtin_amdgcn_readfirstlane((rank % QT) & 3), rot_t = CAUSAL ? 0 : __builtin_amdgcn_readfirstlane(((rank % QT) >> 2) & 3);
+    if constexpr (CAUSAL) {
+        if (a.Z > 1 || a.seqtab) {                                      // sequence z: its own rows of q / att and its own cache (as attn_rows_kernel)
+            const size_t z = rank / (QT * a.H);
+            a.q += z * (size_t) a.N * a.ldq;
+            if (a.att) a.att += z * (size_t) a.N * a.ld_att;
+            if (a.att32) a.att32 += z * (size_t) a.N * a.ld_att;
+            if (a.seqtab) {
+                const SeqTab t = a.seqtab[z];
+                a.kc += (size_t) t.slot * a.kv_seq_stride; a.vc += (size_t) t.slot * a.kv_seq_stride;
+                a.N = t.len; a.n_past = t.pos0;
+                if (i0 >= a.N) return;                                  // a tile of padding rows (the whole workgroup leaves)
+            } else { a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride; }
+        }
+    } else {
         const size_t z = rank / (QT * a.H);
         a.q += z * (size_t) S * a.ldq;
         if (a.att) a.att += z * (size_t) S * a.ld_att;
@@ -731,11 +753,17 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         a.kc += z * a.kv_seq_stride; a.vc += z * a.kv_seq_stride;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    // CAUSAL: keys this tile can see, key tiles (of 256) it needs, and this lane's query: the number of keys it may attend to
+    const int ctx = CAUSAL ? a.n_past + a.N : S;
+    const int jend = CAUSAL ? min(ctx, a.n_past + i0 + 32) : S;
+    const int nt = CAUSAL ? __builtin_amdgcn_readfirstlane((jend + 255) >> 8) : 4;
+    const int valid_q = CAUSAL ? min(ctx, a.n_past + min(i0 + l31, a.N - 1) + 1) : S;
     ATTNW_STAMP(0, (float) tid);
     // query tile -> LDS (512 threads x one float4)
     {
         const int row = tid >> 4, c4 = tid & 15;
-        *reinterpret_cast<float4 *>(qs + row * FQ_LD + 4 * c4) = *reinterpret_cast<const float4 *>(a.q + (size_t) (i0 + row) * a.ldq + hd * 64 + 4 * c4);
+        const int irow = CAUSAL ? min(i0 + row, a.N - 1) : i0 + row;
+        *reinterpret_cast<float4 *>(qs + row * FQ_LD + 4 * c4) = *reinterpret_cast<const float4 *>(a.q + (size_t) irow * a.ldq + hd * 64 + 4 * c4);
     }
     // the key whose K row this lane supplies to tile t (A operand: lane l31 = tile row rho = (r & 3) + 8 (r >> 2) + 4 h')
     const int hp = (l31 >> 2) & 1, rr = (l31 & 3) + 4 * (l31 >> 3);
@@ -760,11 +788,16 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         ATTNW_STAMP(1, ks[0][0].x);
         #pragma unroll
         for (int t = 0; t < 4; t++) {
+            if (CAUSAL && t >= nt) {                             // uniform: no key of this tile is visible to the query tile
+                #pragma unroll
+                for (int r = 0; r < 16; r++) sc[t][r] = -INFINITY;
+                continue;
+            }
             floatx16 acc[4];
             #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int n = 4 * t + b;
-                if (n + 3 < 16) load_blk(ks[(n + 3) & 3], n + 3);
+                if (n + 3 < 16 && (!CAUSAL || n + 3 < 4 * nt)) load_blk(ks[(n + 3) & 3], n + 3);
                 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[b][r] = 0.0f;
                 #pragma unroll
@@ -776,7 +809,11 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
                 }
             }
             #pragma unroll
-            for (int r = 0; r < 16; r++) sc[t][r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * 0.125f;      // 1/sqrt(64), bark.cpp:1318
+            for (int r = 0; r < 16; r++) {
+                const float v = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * 0.125f;      // 1/sqrt(64), bark.cpp:1318
+                // register r of lane (half, query l31) holds key 2w + (r >> 3) + 16 (16 t + 2 (r & 7) + half)
+                sc[t][r] = (!CAUSAL || 2 * w + (r >> 3) + 16 * (16 * t + 2 * (r & 7) + half) < valid_q) ? v : -INFINITY;
+            }
         }
     }
     // key tiles back in order: register set t holds key tile t from here on (softmax sums and the C5 chains of the mix walk the keys in ascending order)
@@ -800,7 +837,11 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     #pragma unroll
     for (int t = 0; t < 4; t++)
         #pragma unroll
-        for (int r = 0; r < 16; r++) { const float e = canon_expf(sc[t][r] - mx); sc[t][r] = e; ls[r & 3] += (double) e; }
+        for (int r = 0; r < 16; r++) {
+            float e = canon_expf(sc[t][r] - mx);
+            if (CAUSAL) e = sc[t][r] == -INFINITY ? 0.0f : e;              // a masked key: p == 0 (said outright instead of through the routine's cut-off)
+            sc[t][r] = e; ls[r & 3] += (double) e;
+        }
     double lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);
     lsum += __shfl_xor(lsum, 32, 64);
     if (half == 0) red_s[w][l31] = lsum;
@@ -828,10 +869,15 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
     load_v(vs[0], 0); load_v(vs[1], 1); load_v(vs[2], 2);
     #pragma unroll
     for (int g = 0; g < 8; g++) {
-        if (g + 3 < 8) load_v(vs[(g + 3) & 3], g + 3);
+        if (CAUSAL && g >= 2 * nt) break;                      // uniform: the tiles behind jend hold no visible key
+        if (g + 3 < 8 && (!CAUSAL || g + 3 < 2 * nt)) load_v(vs[(g + 3) & 3], g + 3);
         #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float2 v = vs[g & 3][i];
+            float2 v = vs[g & 3][i];
+            if (CAUSAL) {                                        // rows at or beyond jend were never written for this sequence: their p is 0, their bits anything
+                const bool ok = 2 * w + (g & 1) + 16 * (16 * (g >> 1) + 2 * i + half) < jend;
+                v.x = ok ? v.x : 0.0f; v.y = ok ? v.y : 0.0f;
+            }
             o[g & 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[g >> 1][8 * (g & 1) + i], v.x, o[g & 1][0], 0, 0, 0);
             o[g & 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[g >> 1][8 * (g & 1) + i], v.y, o[g & 1][1], 0, 0, 0);
         }
@@ -853,6 +899,7 @@ __global__ __launch_bounds__(512, 1) void attn_window_kernel(const AttnPrefillAr
         #pragma unroll
         for (int q = 0; q < 8; q++) pp[q] = part[(q * 32 + row) * 64 + d];
         const float v = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+        if (CAUSAL && i0 + row >= a.N) continue;
         const size_t oi = (size_t) (i0 + row) * a.ld_att + hd * 64 + d;
         if (a.att32) a.att32[oi] = v; else a.att[oi] = to_half(v);
     }
@@ -871,7 +918,12 @@ extern "C" __attribute__((visibility("default"))) int bark_hip_debug_attnw_cycle
 void launch_attn_prefill(hipStream_t s, const AttnPrefillArgs & a) {
     // whole windows of the fine model: the register-resident kernel (BARK_HIP_CROSSCHECK bit 9 (512) keeps attn_rows_kernel)
     if (!a.causal && a.N == 1024 && a.n_past == 0 && !a.seqtab && a.P >= 1024 && !(crosscheck_mask() & 512)) {
-        hipLaunchKernelGGL(attn_window_kernel, dim3(32 * a.H * std::max(1, a.Z)), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((attn_window_kernel<false>), dim3(32 * a.H * std::max(1, a.Z)), dim3(512), 0, s, a);
+        return;
+    }
+    // prompt passes of the causal models at block_size 1024: the same register-resident kernel with the causal mask (bit 512 keeps attn_rows_kernel here too)
+    if (a.causal && a.P == 1024 && a.N >= 1 && a.n_past + a.N <= 1024 && !(crosscheck_mask() & 512)) {
+        hipLaunchKernelGGL((attn_window_kernel<true>), dim3((a.N + 31) / 32 * a.H * std::max(1, a.Z)), dim3(512), 0, s, a);
         return;
     }
     hipLaunchKernelGGL(attn_rows_kernel, dim3((a.N + 31) / 32 * a.H * std::max(1, a.Z)), dim3(512), 32 * ATT_LD * sizeof(float), s, a);

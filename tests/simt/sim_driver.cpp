@@ -144,13 +144,18 @@ int sim_gemm_f16(const void * W, const void * xh, const float * bias, float * ou
 }
 
 // N queries at positions n_past .. against the cache of one sequence (prefill: causal; fine model: whole windows, N == 1024, n_past == 0, not causal).
-// kernel 0: attn_rows_kernel (scores in an LDS tile), 1: attn_window_kernel (scores in registers; whole windows only).  q [N][E] f32, att [N][E] f16
+// kernel 0: attn_rows_kernel (scores in an LDS tile), 1: attn_window_kernel<causal> (scores in registers).  q [N][E] f32, att [N][E] f16
 int sim_attention_rows(int kernel, const float * q, const float * kc, const float * vc, void * att, int H, int N, int n_past, int causal) {
     AttnPrefillArgs a;
     a.q = q; a.ldq = H * 64; a.kc = kc; a.vc = vc; a.H = H; a.P = 1024; a.N = N; a.n_past = n_past; a.causal = causal; a.att = (half_t *) att; a.ld_att = H * 64;
     if (kernel == 1) {
-        if (causal || N != 1024 || n_past != 0) return -1;
-        sim::launch(dim3(32 * H), 512, [&] { attn_window_kernel(a); });
+        if (causal) {                                          // round 6: the register-resident kernel with the causal mask (any N, continues a cache at n_past)
+            if (n_past + N > 1024) return -1;
+            sim::launch(dim3((N + 31) / 32 * H), 512, [&] { attn_window_kernel<true>(a); });
+        } else {
+            if (N != 1024 || n_past != 0) return -1;
+            sim::launch(dim3(32 * H), 512, [&] { attn_window_kernel<false>(a); });
+        }
     } else sim::launch(dim3((N + 31) / 32 * H), 512, [&] { attn_rows_kernel(a); });
     return 0;
 }

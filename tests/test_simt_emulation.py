@@ -291,18 +291,24 @@ def _orc_attention():
     return orc
 
 
-@pytest.mark.parametrize("N,n_past", [(70, 5), (33, 0), (1, 40)])
-def test_prefill_attention_run_on_the_host_equals_the_oracle(sim, N, n_past):
-    """attn_rows_kernel (causal prompt passes: 32-query tiles, the score tile in LDS, C2 / C4 / C5 on v_mfma_f32_32x32x2_f32) against the oracle's attention."""
+@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("N,n_past", [(70, 5), (33, 0), (1, 40), (300, 250)])
+def test_prefill_attention_run_on_the_host_equals_the_oracle(sim, N, n_past, kernel):
+    """The causal prompt-pass attention against the oracle's: kernel 1 = attn_window_kernel<true> (round 6: scores in registers, only the key tiles in front of
+    the query tile's last position are requested, masked scores are -inf, V rows beyond the context are never multiplied - the cache rows there hold NaN in
+    this test), kernel 0 = attn_rows_kernel (32-query tiles, the score tile in LDS).  C2 / C4e / C5 on v_mfma_f32_32x32x2_f32."""
     orc = _orc_attention()
     rng = np.random.default_rng(N)
     H, P = 2, 1024
     ctx = n_past + N
     kc = rng.standard_normal(H * 16 * P * 4).astype(np.float32)
     vc = rng.standard_normal(H * P * 64).astype(np.float32)
+    # rows at or beyond the context were never written: poison them (BARK_HIP_POISON does the same to the engine's caches) - nothing may leak into the result
+    kc.reshape(H, 16, P, 4)[:, :, ctx:, :] = np.nan
+    vc.reshape(H, P, 64)[:, ctx:, :] = np.nan
     q = rng.standard_normal((N, H * 64)).astype(np.float32)
     att = np.zeros((N, H * 64), np.float16)
-    assert sim.sim_attention_rows(0, _p(q), _p(kc), _p(vc), _p(att), H, N, n_past, 1) == 0
+    assert sim.sim_attention_rows(kernel, _p(q), _p(kc), _p(vc), _p(att), H, N, n_past, 1) == 0
     assert att.tobytes() == _attention_reference(orc, q, kc, vc, H, N, ctx, n_past, 1).tobytes()
 
 
