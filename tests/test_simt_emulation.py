@@ -292,7 +292,7 @@ def _orc_attention():
 
 
 @pytest.mark.parametrize("kernel", [1, 0])
-@pytest.mark.parametrize("N,n_past", [(70, 5), (33, 0), (1, 40), (300, 250)])
+@pytest.mark.parametrize("N,n_past", [(70, 5), (33, 0), (1, 40), (300, 250), (100, 924)])
 def test_prefill_attention_run_on_the_host_equals_the_oracle(sim, N, n_past, kernel):
     """The causal prompt-pass attention against the oracle's: kernel 1 = attn_window_kernel<true> (round 6: scores in registers, only the key tiles in front of
     the query tile's last position are requested, masked scores are -inf, V rows beyond the context are never multiplied - the cache rows there hold NaN in
