@@ -1,9 +1,11 @@
-// attention_kernels.hip - attention over the f32 KV cache: single-query decode kernels (orders C2 / C4 / C5 on VALU) and the
-// multi-query prefill / fine kernel (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
-//   attn_ps_kernel    decode, one sequence, block_size 1024: finishes the partial scores the QKV kernel formed (the default)
-//   attn_fused_kernel decode, any block size, one workgroup per (head, slot): lock-step batches, f32 model files, and the
-//                     cross-check route of attn_ps_kernel (BARK_HIP_CROSSCHECK bit 2)
-//   attn_rows_kernel  prefill / fine (N queries)
+// attention_kernels.hip - attention over the f32 KV cache: single-query decode kernels (orders C2 / C4e / C5 on VALU) and the
+// multi-query prompt-pass / fine kernels (the same orders on v_mfma_f32_32x32x2_f32, one accumulator = one chain).
+//   attn_ps_kernel              decode, one sequence, block_size 1024: finishes the partial scores the QKV kernel formed (the default)
+//   attn_fused_kernel           decode, any block size, one workgroup per (head, slot): lock-step batches, f32 model files, and the
+//                               cross-check route of attn_ps_kernel (BARK_HIP_CROSSCHECK bit 2)
+//   attn_window_kernel<CAUSAL>  N queries with the scores in registers: whole windows of the fine model (false), prompt passes of the causal models
+//                               at block_size 1024 (true, round 6)
+//   attn_rows_kernel            N queries with the score tile in LDS: other block sizes, and the cross-check of the kernel above (bit 512)
 // (the two-launch, value-sliced, wide and materialised variants of rounds 1-2 lost their A/Bs and are gone: git history)
 #include "device_utils.h"
 
